@@ -1,0 +1,194 @@
+/*
+ * ofl.h -- C ABI of the MI355X-native optical-flow-field engine (libofl_hip.so).
+ *
+ * The reference (oflibnumpy 1.1.1, pure Python) has no FFI; its hot path funnels through ONE
+ * Python seam, `apply_flow(flow, target, ref, mask)` (src/oflibnumpy/utils.py:199-261), plus the
+ * expressions built on it in src/oflibnumpy/flow_class.py.  Every entry point below names the
+ * reference lines it replaces.  A maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, ints.  No torch / numpy types.
+ *   - every function returns OFL_OK (0) or a negative OFL_E* code; ofl_last_error() gives the text.
+ *   - *_dev entry points take DEVICE pointers (from ofl_malloc) and a stream handle (NULL = the
+ *     library's default stream); they enqueue work and return without synchronising.
+ *   - host entry points (no suffix) take caller-owned, C-contiguous HOST buffers, do
+ *     H2D -> kernel -> D2H on the default stream and return when the result is in host memory.
+ *     Nothing is retained after return.
+ *   - layouts: flow vecs float32 [H][W][2] (channel 0 = x / horizontal, 1 = y / vertical),
+ *     masks uint8 [H][W] with values 0/1, images [H][W][C] C-contiguous.
+ *   - one process drives one GPU (ofl_init(device) once per process); the library is re-entrant
+ *     across streams of that device.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry fails with
+ *     OFL_E_NODEVICE.
+ */
+#ifndef OFL_H
+#define OFL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFL_ABI_VERSION 1
+
+/* status codes */
+enum {
+    OFL_OK          = 0,
+    OFL_E_INVALID   = -1,   /* bad argument (shape, dtype, NULL pointer, unsupported combination) */
+    OFL_E_NODEVICE  = -2,   /* no HIP device / ofl_init not called */
+    OFL_E_HIP       = -3,   /* a HIP runtime call failed (text in ofl_last_error) */
+    OFL_E_NOMEM     = -4,
+    OFL_E_NOPOINTS  = -5,   /* scatter: no valid source points (qhull "No points given" in the reference) */
+    OFL_E_RCCL      = -6
+};
+
+/* element types of warp targets (what cv2.remap accepts for INTER_LINEAR) */
+enum { OFL_U8 = 0, OFL_I16 = 1, OFL_U16 = 2, OFL_F32 = 3, OFL_F64 = 4 };
+
+/* sample-position quantisation of the bilinear gather */
+enum {
+    OFL_QUANT_OPENCV = 0,   /* cv2.remap semantics: coordinates snapped to 1/32 px (INTER_BITS = 5) */
+    OFL_QUANT_EXACT  = 1    /* floor / fractional part in float32, no snapping (extension) */
+};
+
+/* arithmetic of the blend for 8-bit sources */
+enum {
+    OFL_ARITH_NATIVE    = 0,  /* u8: 15-bit fixed point, (acc + 2^14) >> 15; others float/double */
+    OFL_ARITH_FLOAT_RNE = 1   /* u8 riding in an int16 concat (flow_class.py:615,644): float sum, round-half-even */
+};
+
+/* how "warped_mask == 1" (flow_class.py:668) evaluates for the dtype the reference's concat had */
+enum {
+    OFL_RULE_EQ1     = 0,   /* float concat: interpolated mask == 1 exactly */
+    OFL_RULE_GE_HALF = 1,   /* uint8 concat (fixed point): interpolated >= 0.5 */
+    OFL_RULE_GT_HALF = 2    /* int16 concat (round-half-even): interpolated > 0.5 */
+};
+
+/* bits written by the zero-flow statistics (ofl_flow_stats_dev, and the fused compose kernel) */
+enum {
+    OFL_STAT_NONZERO_MASKED     = 1,  /* some vector component != 0 where mask   (Flow.is_zero(thresholded=False), flow_class.py:1244) */
+    OFL_STAT_NONZERO_TH_MASKED  = 2,  /* some |component| >= 1e-3 where mask     (Flow.is_zero(thresholded=True)) */
+    OFL_STAT_NONZERO            = 4,  /* some component != 0 anywhere            (is_zero_flow(thresholded=False), utils.py:527) */
+    OFL_STAT_NONZERO_TH         = 8,  /* some |component| >= 1e-3 anywhere       (is_zero_flow(thresholded=True), utils.py:215) */
+    OFL_STAT_NONFINITE          = 16  /* NaN / Inf present                       (validate_flow_array, utils.py:86) */
+};
+
+/* ------------------------------------------------------------------ runtime / device memory */
+int         ofl_abi_version(void);
+const char *ofl_last_error(void);
+int         ofl_device_count(int *count);
+int         ofl_init(int device);                 /* select device, create default stream */
+int         ofl_device_name(char *buf, size_t buflen);
+int         ofl_malloc(void **dptr, size_t bytes);
+int         ofl_free(void *dptr);
+int         ofl_memset(void *dptr, int value, size_t bytes, void *stream);
+int         ofl_upload(void *dptr, const void *host, size_t bytes, void *stream);     /* async on stream; pinned staging not required */
+int         ofl_download(void *host, const void *dptr, size_t bytes, void *stream);
+int         ofl_copy_dev(void *dst, const void *src, size_t bytes, void *stream);
+int         ofl_stream_create(void **stream);
+int         ofl_stream_destroy(void *stream);
+int         ofl_stream_sync(void *stream);        /* NULL = default stream */
+int         ofl_device_sync(void);
+int         ofl_event_create(void **event);
+int         ofl_event_destroy(void *event);
+int         ofl_event_record(void *event, void *stream);
+int         ofl_event_sync(void *event);
+int         ofl_event_elapsed_ms(void *start, void *stop, float *ms);
+int         ofl_mem_info(size_t *free_bytes, size_t *total_bytes);
+
+/* ------------------------------------------------------------------ K2: fused mode-3 composition
+ * Replaces Flow.combine_with(mode=3) numerics, flow_class.py:1412-1422 (+ Flow.apply :632-684,
+ * apply_flow 't' utils.py:231-236, Flow.__add__ :332-334):
+ *     out  = fb + B(fa; x + sign*fb)                 B = cv2.remap bilinear, 0 outside
+ *     mout = mb & [B(ma; x + sign*fb) == 1]
+ *   ref 't': fa/ma = self (f1), fb/mb = flow (f2), sign = -1
+ *   ref 's': fa/ma = flow (f2), fb/mb = self (f1), sign = +1
+ * batch fields are stored back to back ([batch][H][W][..]).  `stats` (device, uint32[batch][8] or
+ * NULL) receives zero-flow flag WORDS: stats[b][k] (k = 0..3, the OFL_STAT_* bit index) for fa/ma
+ * and stats[b][4 + k] for fb/mb; a word is set to 1 when the condition holds and is never cleared,
+ * so the caller zeroes the words beforehand (plain idempotent stores -- no atomics on the hot path).
+ * With stats != NULL the kernel additionally streams fa/ma once so that the reference's early-exit
+ * predicates (flow_class.py:1339-1354, utils.py:215) can be honoured without separate passes.
+ * The host entry returns the same information folded into bit masks: stats_host[2*b] = OFL_STAT_*
+ * bits of fa, stats_host[2*b+1] = bits of fb.
+ */
+int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const uint8_t *mb,
+                     int sign, int H, int W, int batch, float *out, uint8_t *mout,
+                     uint32_t *stats, int quant, void *stream);
+int ofl_compose3(const float *fa, const uint8_t *ma, const float *fb, const uint8_t *mb,
+                 int sign, int H, int W, int batch, float *out, uint8_t *mout,
+                 uint32_t *stats_host, int quant);
+
+/* ------------------------------------------------------------------ K1: general bilinear gather
+ * Replaces apply_flow(flow, target, 't') utils.py:231-236 and the mask handling around it in
+ * Flow.apply flow_class.py:632-695, valid_target :1148-1150, valid_source :1179-1183:
+ *     dst[y][x][c] = B(src[..][c]; (x, y) + sign * flow[y - pad_top][x - pad_left])
+ *     valid[y][x]  = rule(B(smask; ...)) [& fmask[y - pad_top][x - pad_left], 0 outside the flow area]
+ *   src/dst [H][W][C] of `dtype`; flow [fH][fW][2] located at (pad_top, pad_left) inside the
+ *   H x W target with ZERO flow elsewhere (Flow.pad mode 'constant', flow_class.py:652-659);
+ *   smask [H][W] or NULL (all ones); valid [H][W] or NULL; fmask [fH][fW] or NULL.
+ *   C == 0 with src = dst = NULL computes `valid` only (warp of an all-ones / smask image).
+ */
+int ofl_gather_bilinear_dev(const void *src, int dtype, int C, int H, int W,
+                            const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
+                            const uint8_t *smask, const uint8_t *fmask,
+                            void *dst, uint8_t *valid,
+                            int quant, int arith, int rule, void *stream);
+int ofl_gather_bilinear(const void *src, int dtype, int C, int H, int W,
+                        const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
+                        const uint8_t *smask, const uint8_t *fmask,
+                        void *dst, uint8_t *valid,
+                        int quant, int arith, int rule);
+
+/* ------------------------------------------------------------------ K4: zero-flow / finite statistics
+ * Replaces is_zero_flow utils.py:527-544, threshold_vectors :298-316, Flow.is_zero
+ * flow_class.py:1230-1245 and the finite check of validate_flow_array utils.py:86.
+ * stats: one uint32 (device for _dev, host otherwise), OR of OFL_STAT_* bits; zeroed by the callee.
+ */
+int ofl_flow_stats_dev(const float *flow, const uint8_t *mask, size_t n_px, float threshold,
+                       uint32_t *stats, void *stream);
+int ofl_flow_stats(const float *flow, const uint8_t *mask, size_t n_px, float threshold,
+                   uint32_t *stats_host);
+
+/* ------------------------------------------------------------------ K5: element-wise epilogues
+ * Flow.__add__/__sub__/__neg__ flow_class.py:310-375, 479-489:  out = a + alpha*b, mout = ma & mb.
+ * b/mb may be NULL (then out = alpha * a, mout = ma: negation / scaling).
+ */
+int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_t *mb, float alpha,
+                 size_t n_px, float *out, uint8_t *mout, void *stream);
+
+/* ------------------------------------------------------------------ K3: scattered -> regular grid
+ * Replaces apply_flow(flow, target, 's', mask) utils.py:237-258 (scipy.interpolate.griddata
+ * 'linear', NaN -> 0) and the inline griddata of mode 2 / ref 't' flow_class.py:1398-1410.
+ * Source point i sits at (x, y) + sign*flow[i] and carries vals[i][0..C) (float32); points with
+ * pmask[i] == 0 are dropped (pmask NULL = keep all).  Output: out[H][W][C] float32 interpolated
+ * piecewise-linearly on the triangulated warped grid, 0 where no triangle covers the pixel and
+ * the pixel is outside the convex hull of the kept points; `covered` (uint8 [H][W] or NULL) is 1
+ * where a value was produced.  query == NULL evaluates at the regular grid nodes; otherwise
+ * query [H][W][2] holds absolute (x, y) positions (mode 2 't').
+ */
+int ofl_scatter_linear_dev(const float *flow, int sign, const uint8_t *pmask,
+                           const float *vals, int C, int H, int W,
+                           const float *query, float *out, uint8_t *covered,
+                           void *workspace, size_t workspace_bytes, void *stream);
+int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes);
+int ofl_scatter_linear(const float *flow, int sign, const uint8_t *pmask,
+                       const float *vals, int C, int H, int W,
+                       const float *query, float *out, uint8_t *covered);
+
+/* ------------------------------------------------------------------ C1: shared-source broadcast (RCCL)
+ * The only exchange step of the sharded workload: one broadcast of a shared source image / flow
+ * from rank `root` to all ranks over xGMI.  The 128-byte unique id is created on rank 0 with
+ * ofl_comm_unique_id and distributed by the launcher (torch.distributed store / gloo).
+ */
+int ofl_comm_unique_id(void *id128);
+int ofl_comm_init(const void *id128, int rank, int world);
+int ofl_comm_broadcast(void *dptr, size_t bytes, int root, void *stream);
+int ofl_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFL_H */

@@ -1,0 +1,57 @@
+"""Builds oflibnumpy_amd/libofl_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this also runs in the build container.  The .so is
+git-ignored but travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libofl_hip.so")
+OBJ_DIR = os.path.join(CSRC, "_obj")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X engine cannot be built on this machine")
+    return exe
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build_native(force=False, verbose=False):
+    """Compile every csrc/*.hip for gfx950 and link libofl_hip.so.  Returns the library path."""
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "ofl.h"))
+    newest_hdr = max(os.path.getmtime(h) for h in headers)
+    objs, relink = [], force or not os.path.exists(OUT)
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+            relink = True
+    if relink or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

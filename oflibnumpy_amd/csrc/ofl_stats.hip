@@ -1,0 +1,150 @@
+// ofl_stats.hip -- K4 zero-flow / finite statistics and K5 element-wise epilogues (gfx950).
+// Pure streaming kernels: 16-byte loads per lane, grid-stride over at most 2048 workgroups.
+#include "ofl_common.h"
+
+#pragma clang fp contract(off)
+
+using namespace ofl;
+
+namespace {
+
+__device__ __forceinline__ bool finite2(float a, float b)
+{
+    return (fabsf(a) <= 3.402823466e38f) && (fabsf(b) <= 3.402823466e38f);   // false for NaN / Inf
+}
+
+// stats[0] receives the OR of OFL_STAT_* bits.  One atomicOr per WORKGROUP, and only for bits the
+// word does not hold yet, keeps same-address traffic to a handful of operations per launch.
+__global__ __launch_bounds__(256)
+void flow_stats_kernel(const float *__restrict__ flow, const uint8_t *__restrict__ mask, size_t n_px,
+                       float th, uint32_t *__restrict__ stats)
+{
+    __shared__ uint32_t block_bits;
+    if (threadIdx.x == 0) block_bits = 0;
+    __syncthreads();
+
+    uint32_t bits = 0;
+    const size_t n2 = n_px / 2;                    // pixel pairs (float4)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const float4 f = reinterpret_cast<const float4 *>(flow)[i];
+        bool m0 = true, m1 = true;
+        if (mask) {
+            const uint16_t m = reinterpret_cast<const uint16_t *>(mask)[i];
+            m0 = (m & 0xffu) != 0; m1 = (m & 0xff00u) != 0;
+        }
+        bits |= stat_bits(f.x, f.y, m0, th) | stat_bits(f.z, f.w, m1, th);
+        if (!finite2(f.x, f.y) || !finite2(f.z, f.w)) bits |= OFL_STAT_NONFINITE;
+    }
+    if ((n_px & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd tail pixel
+        const size_t i = n_px - 1;
+        const float u = flow[2 * i], v = flow[2 * i + 1];
+        bits |= stat_bits(u, v, mask ? mask[i] != 0 : true, th);
+        if (!finite2(u, v)) bits |= OFL_STAT_NONFINITE;
+    }
+    // wave OR via ballots, one LDS atomic per wave, one global atomic per workgroup
+    uint32_t wbits = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wbits |= (__ballot((bits >> k) & 1u) != 0ull) ? (1u << k) : 0u;
+    if ((threadIdx.x & 63) == 0 && wbits) atomicOr(&block_bits, wbits);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_bits) {
+        const uint32_t cur = __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur | block_bits) != cur) atomicOr(stats, block_bits);
+    }
+}
+
+// out = a + alpha * b, mout = ma & mb  (b/mb optional: out = alpha * a, mout = ma)
+__global__ __launch_bounds__(256)
+void axpy_kernel(const float *__restrict__ a, const uint8_t *__restrict__ ma,
+                 const float *__restrict__ b, const uint8_t *__restrict__ mb, float alpha, size_t n_px,
+                 float *__restrict__ out, uint8_t *__restrict__ mout)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n2 = n_px / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const float4 va = reinterpret_cast<const float4 *>(a)[i];
+        float4 r;
+        if (b) {
+            const float4 vb = reinterpret_cast<const float4 *>(b)[i];
+            r = make_float4(__fadd_rn(va.x, __fmul_rn(alpha, vb.x)), __fadd_rn(va.y, __fmul_rn(alpha, vb.y)),
+                            __fadd_rn(va.z, __fmul_rn(alpha, vb.z)), __fadd_rn(va.w, __fmul_rn(alpha, vb.w)));
+        } else {
+            r = make_float4(__fmul_rn(alpha, va.x), __fmul_rn(alpha, va.y), __fmul_rn(alpha, va.z), __fmul_rn(alpha, va.w));
+        }
+        reinterpret_cast<float4 *>(out)[i] = r;
+        if (mout) {
+            uint16_t m = reinterpret_cast<const uint16_t *>(ma)[i];
+            if (mb) m &= reinterpret_cast<const uint16_t *>(mb)[i];
+            reinterpret_cast<uint16_t *>(mout)[i] = m;
+        }
+    }
+    if ((n_px & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const size_t i = n_px - 1;
+        for (int c = 0; c < 2; ++c)
+            out[2 * i + c] = b ? __fadd_rn(a[2 * i + c], __fmul_rn(alpha, b[2 * i + c])) : __fmul_rn(alpha, a[2 * i + c]);
+        if (mout) mout[i] = (uint8_t)(ma[i] & (mb ? mb[i] : 1));
+    }
+}
+
+int stream_grid(size_t n_items)
+{
+    size_t nb = (n_items + 255) / 256;
+    if (nb < 1) nb = 1;
+    const size_t cap = (size_t)rt().n_cu * 8;
+    return (int)(nb < cap ? nb : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofl_flow_stats_dev(const float *flow, const uint8_t *mask, size_t n_px, float threshold,
+                       uint32_t *stats, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!flow || !stats) return fail(OFL_E_INVALID, "ofl_flow_stats: NULL pointer");
+    hipStream_t s = stream_of(stream);
+    OFL_HIP(hipMemsetAsync(stats, 0, sizeof(uint32_t), s));
+    if (n_px == 0) return OFL_OK;
+    hipLaunchKernelGGL(flow_stats_kernel, dim3(stream_grid(n_px / 2)), dim3(256), 0, s, flow, mask, n_px, threshold, stats);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_flow_stats(const float *flow, const uint8_t *mask, size_t n_px, float threshold, uint32_t *stats_host)
+{
+    OFL_TRY(need_device());
+    if (!flow || !stats_host) return fail(OFL_E_INVALID, "ofl_flow_stats: NULL pointer");
+    hipStream_t s = rt().stream;
+    void *df = nullptr, *dm = nullptr, *ds = nullptr;
+    int rc = OFL_OK;
+    hipError_t e;
+    if ((e = hipMalloc(&df, n_px * 8 + 16)) != hipSuccess) return hip_fail(e, "hipMalloc");
+    if ((e = hipMalloc(&ds, 16)) != hipSuccess) { (void)hipFree(df); return hip_fail(e, "hipMalloc"); }
+    if (mask && (e = hipMalloc(&dm, n_px + 16)) != hipSuccess) { (void)hipFree(df); (void)hipFree(ds); return hip_fail(e, "hipMalloc"); }
+    do {
+        if ((e = hipMemcpyAsync(df, flow, n_px * 8, hipMemcpyHostToDevice, s)) != hipSuccess) { rc = hip_fail(e, "H2D"); break; }
+        if (mask && (e = hipMemcpyAsync(dm, mask, n_px, hipMemcpyHostToDevice, s)) != hipSuccess) { rc = hip_fail(e, "H2D"); break; }
+        if ((rc = ofl_flow_stats_dev((const float *)df, (const uint8_t *)dm, n_px, threshold, (uint32_t *)ds, s)) != OFL_OK) break;
+        if ((e = hipMemcpyAsync(stats_host, ds, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) { rc = hip_fail(e, "D2H"); break; }
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) { rc = hip_fail(e, "sync"); break; }
+    } while (0);
+    (void)hipFree(df); (void)hipFree(ds); if (dm) (void)hipFree(dm);
+    return rc;
+}
+
+int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_t *mb, float alpha,
+                 size_t n_px, float *out, uint8_t *mout, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!a || !out) return fail(OFL_E_INVALID, "ofl_axpy: NULL pointer");
+    if (mout && !ma) return fail(OFL_E_INVALID, "ofl_axpy: mout requires ma");
+    if (n_px == 0) return OFL_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n_px / 2)), dim3(256), 0, stream_of(stream),
+                       a, ma, b, mb, alpha, n_px, out, mout);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+}  // extern "C"

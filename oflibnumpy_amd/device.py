@@ -1,0 +1,408 @@
+"""HBM-resident flow fields and the device-side flow algebra.
+
+`DeviceFlow` mirrors the hot-path methods of the reference's `Flow` (apply / switch_ref / invert /
+combine_with / valid_target / valid_source / + - neg / is_zero; src/oflibnumpy/flow_class.py) but
+keeps vectors and mask in GPU memory between operations, so chains such as combine_with(mode=1)
+(1 scatter + 2 gathers, flow_class.py:1369-1370) never cross PCIe.  The host `Flow` class is a thin
+upload -> DeviceFlow op -> download wrapper around this module.
+
+Data layout in HBM: vecs float32 [H][W][2] interleaved (x, y) -- the same layout as the reference,
+so a pixel's vector is one 8-byte element and two horizontally adjacent bilinear taps are one
+16-byte load; mask uint8 [H][W] (0/1).
+"""
+import ctypes
+import weakref
+
+import numpy as np
+
+from . import _native as nat
+
+DEFAULT_THRESHOLD = 1e-3          # src/oflibnumpy/utils.py:22
+_DT_CODE = {np.dtype('uint8'): nat.U8, np.dtype('int16'): nat.I16, np.dtype('uint16'): nat.U16,
+            np.dtype('float32'): nat.F32, np.dtype('float64'): nat.F64}
+
+
+def _lib():
+    nat.ensure_device()
+    return nat.load()
+
+
+# ------------------------------------------------------------------------------ memory
+class _Pool:
+    """Size-bucketed free lists: hipFree synchronises the device, so chained operations recycle
+    their intermediates instead of returning them to the driver."""
+
+    def __init__(self):
+        self.free = {}
+        self.cached_bytes = 0
+        self.limit = 64 << 30
+
+    def take(self, nbytes):
+        lst = self.free.get(nbytes)
+        if lst:
+            self.cached_bytes -= nbytes
+            return lst.pop()
+        p = ctypes.c_void_p()
+        try:
+            nat.check(_lib().ofl_malloc(ctypes.byref(p), nbytes))
+        except nat.NativeError:
+            self.trim()
+            nat.check(_lib().ofl_malloc(ctypes.byref(p), nbytes))
+        return p.value
+
+    def give(self, ptr, nbytes):
+        if self.cached_bytes + nbytes > self.limit:
+            nat.load().ofl_free(ptr)
+            return
+        self.free.setdefault(nbytes, []).append(ptr)
+        self.cached_bytes += nbytes
+
+    def trim(self):
+        lib = nat.load()
+        for lst in self.free.values():
+            for p in lst:
+                lib.ofl_free(p)
+        self.free.clear()
+        self.cached_bytes = 0
+
+
+_pool = _Pool()
+
+
+def empty_cache():
+    _pool.trim()
+
+
+def _release(ptr, nbytes):
+    try:
+        _pool.give(ptr, nbytes)
+    except Exception:       # interpreter shutdown
+        pass
+
+
+class DeviceBuffer:
+    """A block of HBM owned by this process (ofl_malloc / pooled)."""
+
+    __slots__ = ("ptr", "nbytes", "_fin", "__weakref__")
+
+    def __init__(self, nbytes):
+        self.nbytes = max(int(nbytes), 16)
+        self.ptr = _pool.take(self.nbytes)
+        self._fin = weakref.finalize(self, _release, self.ptr, self.nbytes)
+
+    @classmethod
+    def from_host(cls, arr, stream=None):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(arr.nbytes)
+        if arr.nbytes:
+            nat.check(_lib().ofl_upload(buf.ptr, arr.ctypes.data, arr.nbytes, stream))
+            # the source array may be a temporary: make the (possibly staged) copy complete now
+            nat.check(_lib().ofl_stream_sync(stream))
+        return buf
+
+    @classmethod
+    def zeros(cls, nbytes, stream=None):
+        buf = cls(nbytes)
+        nat.check(_lib().ofl_memset(buf.ptr, 0, buf.nbytes, stream))
+        return buf
+
+    def to_host(self, shape, dtype, stream=None):
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            nat.check(_lib().ofl_download(out.ctypes.data, self.ptr, out.nbytes, stream))
+        return out
+
+
+def sync(stream=None):
+    nat.check(_lib().ofl_stream_sync(stream))
+
+
+class DeviceImage:
+    """A warp target in HBM: [H][W][C] of uint8 / int16 / uint16 / float32 / float64."""
+
+    def __init__(self, buf, shape, dtype):
+        self.buf, self.shape, self.dtype = buf, tuple(shape), np.dtype(dtype)
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.ndim == 2:
+            arr = arr[..., None]
+        if arr.dtype not in _DT_CODE:
+            raise TypeError("warp targets must be uint8, int16, uint16, float32 or float64 "
+                            "(what cv2.remap accepts), got {}".format(arr.dtype))
+        return cls(DeviceBuffer.from_host(arr), arr.shape, arr.dtype)
+
+    def to_host(self):
+        return self.buf.to_host(self.shape, self.dtype)
+
+
+# ------------------------------------------------------------------------------ kernels
+def gather_bilinear(src, flow_buf, flow_shape, sign, smask=None, fmask=None, want_valid=False,
+                    pad=(0, 0), quant=nat.QUANT_OPENCV, arith=nat.ARITH_NATIVE, rule=nat.RULE_EQ1,
+                    stream=None):
+    """K1: dst = B(src; x + sign*flow) (+ validity).  Replaces apply_flow 't', utils.py:231-236."""
+    H, W, C = src.shape
+    dst = DeviceImage(DeviceBuffer(H * W * C * src.dtype.itemsize), src.shape, src.dtype)
+    valid = DeviceBuffer(H * W) if want_valid else None
+    nat.check(_lib().ofl_gather_bilinear_dev(
+        src.buf.ptr, _DT_CODE[src.dtype], C, H, W, flow_buf.ptr, flow_shape[0], flow_shape[1],
+        pad[0], pad[1], sign, smask.ptr if smask is not None else None,
+        fmask.ptr if fmask is not None else None, dst.buf.ptr,
+        valid.ptr if valid is not None else None, quant, arith, rule, stream))
+    return dst, valid
+
+
+def gather_valid_only(H, W, flow_buf, flow_shape, sign, smask=None, fmask=None, pad=(0, 0),
+                      quant=nat.QUANT_OPENCV, rule=nat.RULE_EQ1, stream=None):
+    """K1 without image channels: where does a warped all-ones (or smask) image stay == 1?
+    (valid_target 't' flow_class.py:1148-1150, valid_source 's' :1179-1183)."""
+    valid = DeviceBuffer(H * W)
+    nat.check(_lib().ofl_gather_bilinear_dev(
+        None, nat.U8, 0, H, W, flow_buf.ptr, flow_shape[0], flow_shape[1], pad[0], pad[1], sign,
+        smask.ptr if smask is not None else None, fmask.ptr if fmask is not None else None,
+        None, valid.ptr, quant, nat.ARITH_NATIVE, rule, stream))
+    return valid
+
+
+def flow_stats(vecs_buf, mask_buf, n_px, stream=None):
+    """K4: OFL_STAT_* bits of one field (utils.py:527-544, flow_class.py:1230-1245)."""
+    out = DeviceBuffer(16)
+    nat.check(_lib().ofl_flow_stats_dev(vecs_buf.ptr, mask_buf.ptr if mask_buf is not None else None,
+                                        n_px, np.float32(DEFAULT_THRESHOLD), out.ptr, stream))
+    return int(out.to_host((1,), np.uint32, stream)[0])
+
+
+def _fold_stat_words(words):
+    a = sum((1 << k) for k in range(4) if words[k])
+    b = sum((1 << k) for k in range(4) if words[4 + k])
+    return a, b
+
+
+def compose3_launch(fa, fb, sign, out, stats_buf=None, stats_offset=0, batch=1, quant=nat.QUANT_OPENCV,
+                    stream=None):
+    """K2 launch on raw DeviceFlow-like triples; asynchronous.  stats_buf: uint32[batch][8] words."""
+    H, W = fa.shape
+    sp = None if stats_buf is None else stats_buf.ptr + stats_offset
+    nat.check(_lib().ofl_compose3_dev(fa.vecs.ptr, fa.mask.ptr, fb.vecs.ptr, fb.mask.ptr, sign, H, W, batch,
+                                      out.vecs.ptr, out.mask.ptr, sp, quant, stream))
+
+
+# ------------------------------------------------------------------------------ DeviceFlow
+class DeviceFlow:
+    """(vecs, mask, ref) resident in HBM.  Buffers are immutable once wrapped."""
+
+    def __init__(self, vecs, mask, shape, ref, stats=None):
+        self.vecs, self.mask = vecs, mask
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.ref = ref
+        self._stats = stats
+
+    # -- construction / transfer
+    @classmethod
+    def empty(cls, shape, ref):
+        n = int(shape[0]) * int(shape[1])
+        return cls(DeviceBuffer(n * 8), DeviceBuffer(n), shape, ref)
+
+    @classmethod
+    def from_host(cls, vecs, ref='t', mask=None):
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        h, w = vecs.shape[:2]
+        m = np.ones((h, w), np.uint8) if mask is None else np.ascontiguousarray(mask).astype(np.uint8)
+        return cls(DeviceBuffer.from_host(vecs), DeviceBuffer.from_host(m), (h, w), ref)
+
+    def to_host(self):
+        """-> (vecs float32 [H,W,2], mask bool [H,W])"""
+        h, w = self.shape
+        return self.vecs.to_host((h, w, 2), np.float32), self.mask.to_host((h, w), np.uint8).astype(bool)
+
+    def relabel(self, ref):
+        return DeviceFlow(self.vecs, self.mask, self.shape, ref, self._stats)
+
+    @property
+    def n_px(self):
+        return self.shape[0] * self.shape[1]
+
+    # -- predicates
+    def stats(self):
+        if self._stats is None:
+            self._stats = flow_stats(self.vecs, self.mask, self.n_px)
+        return self._stats
+
+    def is_zero(self, thresholded=True, masked=True):
+        """Flow.is_zero, flow_class.py:1230-1245."""
+        s = self.stats()
+        if masked:
+            bit = nat.STAT_NONZERO_TH_MASKED if thresholded else nat.STAT_NONZERO_MASKED
+        else:
+            bit = nat.STAT_NONZERO_TH if thresholded else nat.STAT_NONZERO
+        return not (s & bit)
+
+    # -- element-wise algebra (Flow.__add__/__sub__/__neg__, flow_class.py:310-375, 479-489)
+    def _axpy(self, other, alpha):
+        out = DeviceFlow.empty(self.shape, self.ref)
+        nat.check(_lib().ofl_axpy_dev(self.vecs.ptr, self.mask.ptr,
+                                      other.vecs.ptr if other is not None else None,
+                                      other.mask.ptr if other is not None else None,
+                                      np.float32(alpha), self.n_px, out.vecs.ptr, out.mask.ptr, None))
+        return out
+
+    def __add__(self, other):
+        return self._axpy(other, 1.0)
+
+    def __sub__(self, other):
+        return self._axpy(other, -1.0)
+
+    def __neg__(self):
+        return self._axpy(None, -1.0)
+
+    # -- warping
+    def apply(self, target, consider_mask=True, quant=nat.QUANT_OPENCV):
+        """Flow.apply with a Flow target (flow_class.py:600-603, 632-684): the target's vectors and mask
+        are warped together; the result keeps the TARGET's reference."""
+        if self.ref == 't':
+            if self.is_zero(thresholded=True, masked=False):          # utils.py:215-216
+                return target._and_mask(self)
+            src = DeviceImage(target.vecs, self.shape + (2,), np.float32)
+            dst, valid = gather_bilinear(src, self.vecs, self.shape, -1, smask=target.mask, fmask=self.mask,
+                                         want_valid=True, quant=quant)
+            return DeviceFlow(dst.buf, valid, self.shape, target.ref)
+        return self._scatter_flow(target, consider_mask)
+
+    def _and_mask(self, other):
+        """vecs unchanged, mask = self.mask & other.mask (zero-flow identity warp of a Flow target)."""
+        out_mask = DeviceBuffer(self.n_px)
+        scratch = DeviceBuffer(self.n_px * 8)
+        nat.check(_lib().ofl_axpy_dev(self.vecs.ptr, self.mask.ptr, None, other.mask.ptr, np.float32(1.0),
+                                      self.n_px, scratch.ptr, out_mask.ptr, None))
+        return DeviceFlow(scratch, out_mask, self.shape, self.ref)
+
+    def _scatter_flow(self, target, consider_mask=True, sign=1):
+        """'s'-reference apply of a Flow target: utils.py:237-258 + flow_class.py:634-643, 668."""
+        if self.is_zero(thresholded=True, masked=False):
+            return target._and_mask(self)
+        h, w = self.shape
+        out = DeviceFlow.empty(self.shape, target.ref)
+        vmask = DeviceBuffer(self.n_px)
+        _mask_and(target.mask, self.mask, vmask, self.n_px)      # mask channel, flow_class.py:643
+        scatter_linear(self.vecs, sign, self.mask if consider_mask else None, target.vecs, 2, vmask,
+                       h, w, None, out.vecs, out.mask, 0)
+        return out
+
+    def switch_ref(self):
+        """Flow.switch_ref(mode='valid'), flow_class.py:716-726."""
+        other = 't' if self.ref == 's' else 's'
+        if self.is_zero(thresholded=False):
+            return self.relabel(other)
+        if self.ref == 's':
+            return self.apply(self).relabel('t')
+        as_s = self.relabel('s')
+        return (-as_s).apply(as_s)
+
+    def invert(self, ref=None):
+        """Flow.invert, flow_class.py:735-753."""
+        ref = self.ref if ref is None else ref
+        if self.ref == 's':
+            return self.apply(-self) if ref == 's' else (-self).relabel('t')
+        if ref == 's':
+            return (-self).relabel('s')
+        return self.invert('s').switch_ref()
+
+    def combine_with(self, flow, mode, thresholded=False, quant=nat.QUANT_OPENCV):
+        """Flow.combine_with, flow_class.py:1338-1424.  Returns `self` / `flow` themselves on the
+        reference's zero-flow early exits."""
+        if mode == 3:
+            return self._combine3(flow, thresholded, quant)
+        if self.is_zero(thresholded=thresholded):
+            return flow
+        if flow.is_zero(thresholded=thresholded):
+            return self.invert()
+        s = self.ref == 's'
+        if mode == 1:
+            if s:                                                            # flow_class.py:1369-1370
+                g = flow.invert('t')
+                return flow - (g + g.apply(self.switch_ref())).apply(self)
+            a = self.switch_ref()                                            # flow_class.py:1383-1385
+            res = flow.switch_ref() - (a + a.invert(ref='t').apply(flow.invert('s'))).apply(a)
+            return res.switch_ref()
+        if s:
+            return self.apply(flow - self)                                   # flow_class.py:1390
+        return flow - self._resample_to(flow)                                # flow_class.py:1398-1410
+
+    def _combine3(self, flow, thresholded, quant):
+        """Mode 3 through the fused kernel K2.  The early-exit predicates of flow_class.py:1339-1354 and
+        utils.py:215 are evaluated by the same launch (stat words) and honoured afterwards."""
+        if self.ref == 's':
+            fa, fb, sign = flow, self, +1          # self + self.invert('t').apply(flow)   (:1418)
+        else:
+            fa, fb, sign = self, flow, -1          # flow + flow.apply(self)               (:1422)
+        out = DeviceFlow.empty(self.shape, self.ref)
+        need = fa._stats is None or fb._stats is None
+        words = DeviceBuffer.zeros(32) if need else None
+        compose3_launch(fa, fb, sign, out, words, quant=quant)
+        if need:
+            sa, sb = _fold_stat_words(words.to_host((8,), np.uint32))
+            # the fused launch does not look for NaN/Inf: flows are validated finite at upload
+            fa._stats = sa if fa._stats is None else fa._stats
+            fb._stats = sb if fb._stats is None else fb._stats
+        if self.is_zero(thresholded=thresholded):
+            return flow
+        if flow.is_zero(thresholded=thresholded):
+            return self
+        if fb.is_zero(thresholded=True, masked=False):
+            # apply_flow returned the target untouched (utils.py:215-216): plain vector sum
+            return fb + fa if self.ref == 't' else fb + fa
+        return out
+
+    def _resample_to(self, flow3):
+        """Mode 2 / ref 't' (flow_class.py:1398-1410): self sampled from the points x - self onto the
+        points x - flow3; mask = interpolated mask > 0.99."""
+        h, w = self.shape
+        out = DeviceFlow.empty(self.shape, 't')
+        query = DeviceBuffer(self.n_px * 8)
+        grid_minus(flow3.vecs, query, h, w)
+        scatter_linear(self.vecs, -1, None, self.vecs, 2, self.mask, h, w, query, out.vecs, out.mask, 1)
+        return out
+
+    def valid_target(self, consider_mask=True, quant=nat.QUANT_OPENCV):
+        """flow_class.py:1113-1151 -> uint8 mask buffer."""
+        h, w = self.shape
+        if self.ref == 't':
+            if self.is_zero(thresholded=True, masked=False):
+                return self.mask
+            return gather_valid_only(h, w, self.vecs, self.shape, -1, fmask=self.mask, quant=quant)
+        return self._scatter_mask(+1, consider_mask)
+
+    def valid_source(self, consider_mask=True, quant=nat.QUANT_OPENCV):
+        """flow_class.py:1153-1195 -> uint8 mask buffer."""
+        h, w = self.shape
+        if self.ref == 's':
+            if self.is_zero(thresholded=True, masked=False):
+                return self.mask
+            return gather_valid_only(h, w, self.vecs, self.shape, +1, fmask=self.mask, quant=quant)
+        return self._scatter_mask(-1, consider_mask)
+
+    def _scatter_mask(self, sign, consider_mask):
+        """apply_flow(+-vecs, mask.astype('f'), 's', mask|None) == 1  (flow_class.py:1140-1141, 1190-1193)."""
+        if self.is_zero(thresholded=True, masked=False):
+            return self.mask
+        h, w = self.shape
+        valid = DeviceBuffer(self.n_px)
+        scatter_linear(self.vecs, sign, self.mask if consider_mask else None, None, 0, self.mask,
+                       h, w, None, None, valid, 0)
+        return valid
+
+
+# ------------------------------------------------------------------------------ small helpers
+def _mask_and(a, b, out, n):
+    """out = a & b for uint8 masks, via the axpy kernel's mask lane (vector lane discarded)."""
+    raise NotImplementedError
+
+
+def grid_minus(vecs, out, h, w):
+    raise NotImplementedError
+
+
+def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, valid_rule, stream=None):
+    """K3: scattered -> regular-grid linear interpolation.  Replaces utils.py:237-258."""
+    raise NotImplementedError

@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Generates tests/golden/ref_scipy_paths.npz by RUNNING THE REAL REFERENCE in the build container.
+
+The reference (/root/reference, oflibnumpy 1.1.1) imports cv2 at module import time and cv2 is not
+installed here (ordinary ModuleNotFoundError, no permission denial).  A stub module whose functions
+raise is registered as `cv2` so that the package imports; every path that reaches cv2.remap therefore
+raises and is NOT captured here.  What is captured is the reference's genuine arithmetic on every
+SciPy-backed path of the hot path ('s' apply, invert s->s / t->t, switch_ref, valid_target('s'),
+valid_source('t'), combine_with mode 2).
+
+Only inputs and expected outputs are stored (data, not source).  The reference never travels to the
+GPU box; the tests read the .npz only.
+
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    cv2 = types.ModuleType("cv2")
+
+    def _unavailable(*a, **k):
+        raise RuntimeError("cv2 is not available in this container")
+
+    for name in ("remap", "imread", "resize", "cvtColor", "imshow", "waitKey", "findContours",
+                 "drawContours", "estimateAffine2D", "estimateAffinePartial2D", "findHomography",
+                 "arrowedLine", "line"):
+        setattr(cv2, name, _unavailable)
+    cv2.INTER_LINEAR = 1
+    sys.modules["cv2"] = cv2
+    sys.path.insert(0, "/root/reference/src")
+    import oflibnumpy
+    return oflibnumpy
+
+
+def main():
+    of = _import_reference()
+    Flow = of.Flow
+    out = {}
+    rng = np.random.default_rng(7)
+
+    def put(tag, flow, res):
+        out[tag + "/in_vecs"] = flow.vecs
+        out[tag + "/in_mask"] = flow.mask
+        out[tag + "/in_ref"] = np.array(flow.ref)
+        if isinstance(res, Flow):
+            out[tag + "/out_vecs"] = res.vecs
+            out[tag + "/out_mask"] = res.mask
+            out[tag + "/out_ref"] = np.array(res.ref)
+        else:
+            out[tag + "/out"] = res
+
+    shape = (24, 32)
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype('f')
+    wobble = np.stack([0.5 * np.sin(2 * np.pi * xx / 17.0) * np.cos(2 * np.pi * yy / 13.0),
+                       0.4 * np.cos(2 * np.pi * xx / 19.0) * np.sin(2 * np.pi * yy / 11.0)], -1).astype('f')
+    hole = np.ones(shape, bool)
+    hole[8:14, 10:18] = False
+    speckle = rng.random(shape) > 0.1
+
+    flows = {}
+    for ref in ('s', 't'):
+        flows["rot_" + ref] = Flow.from_transforms([['rotation', 12, 10, -20]], shape, ref)
+        flows["scale_" + ref] = Flow.from_transforms([['scaling', 10, 8, 0.85]], shape, ref)
+        flows["rotscale_" + ref] = Flow.from_transforms([['rotation', 16, 12, 15], ['scaling', 5, 5, 1.1]], shape, ref)
+        flows["transl_" + ref] = Flow.from_transforms([['translation', 3, -2]], shape, ref)
+        f = Flow.from_transforms([['rotation', 16, 12, -10], ['scaling', 16, 12, 0.95]], shape, ref)
+        flows["wobble_" + ref] = Flow(f.vecs + wobble, ref)
+        flows["rot_hole_" + ref] = Flow.from_transforms([['rotation', 12, 10, -20]], shape, ref, hole)
+        flows["rot_speckle_" + ref] = Flow.from_transforms([['rotation', 12, 10, -20]], shape, ref, speckle)
+
+    img = rng.random(shape + (3,), dtype=np.float32)
+    img_u8 = (rng.random(shape + (3,)) * 255).astype(np.uint8)
+    out["img_f32"] = img
+    out["img_u8"] = img_u8
+
+    for name, f in flows.items():
+        put("invert/" + name, f, f.invert())
+        put("switch_ref/" + name, f, f.switch_ref())
+        if f.ref == 's':
+            put("valid_target/" + name, f, f.valid_target())
+            put("valid_target_nomask/" + name, f, f.valid_target(consider_mask=False))
+            w, v = f.apply(img, return_valid_area=True)
+            put("apply_img/" + name, f, w)
+            out["apply_img/" + name + "/out_valid"] = v
+            w, v = f.apply(img, return_valid_area=True, consider_mask=False)
+            put("apply_img_nomask/" + name, f, w)
+            out["apply_img_nomask/" + name + "/out_valid"] = v
+            put("apply_u8/" + name, f, f.apply(img_u8))
+        else:
+            put("valid_source/" + name, f, f.valid_source())
+            put("valid_source_nomask/" + name, f, f.valid_source(consider_mask=False))
+
+    # combine_with mode 2 (both refs): f1 (+) f2 = f3, recover f2
+    for ref in ('s', 't'):
+        t1 = [['rotation', 16, 12, -12]]
+        t2 = [['scaling', 8, 6, 0.9]]
+        f1 = Flow.from_transforms(t1, shape, ref)
+        f3 = Flow.from_transforms(t1 + t2, shape, ref)
+        r = f1.combine_with(f3, 2)
+        put("combine2/" + ref, f1, r)
+        out["combine2/" + ref + "/in2_vecs"] = f3.vecs
+        out["combine2/" + ref + "/in2_mask"] = f3.mask
+        f1w = flows["wobble_" + ref]
+        r = f1w.combine_with(f3, 2)
+        put("combine2_wobble/" + ref, f1w, r)
+        out["combine2_wobble/" + ref + "/in2_vecs"] = f3.vecs
+        out["combine2_wobble/" + ref + "/in2_mask"] = f3.mask
+
+    # 7x7 known-answer geometry of tests/test_flow_class.py:852-980, captured from the reference itself
+    s7 = (7, 7)
+    m_s = np.ones(s7, bool)
+    m_s[4:, :3] = False
+    m_t = np.ones(s7, bool)
+    m_t[:3, 4:] = False
+    f_s = Flow.from_transforms([['rotation', 0, 0, 45]], s7, 's')
+    f_sm = Flow.from_transforms([['rotation', 0, 0, 45]], s7, 's', m_s)
+    f_t = Flow.from_transforms([['rotation', 0, 0, 45]], s7, 't')
+    f_tm = Flow.from_transforms([['rotation', 0, 0, 45]], s7, 't', m_t)
+    put("k7/valid_target_s", f_s, f_s.valid_target())
+    put("k7/valid_target_s_masked", f_sm, f_sm.valid_target())
+    put("k7/valid_target_s_masked_nomask", f_sm, f_sm.valid_target(False))
+    put("k7/valid_source_t", f_t, f_t.valid_source())
+    put("k7/valid_source_t_masked", f_tm, f_tm.valid_source())
+    put("k7/valid_source_t_masked_nomask", f_tm, f_tm.valid_source(False))
+
+    path = os.path.join(HERE, "ref_scipy_paths.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

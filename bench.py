@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: Flow.combine_with(mode=3) at 2160 x 3840 float32 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic pair of flow fields that is already resident
+in HBM: one launch of the fused compose kernel (ofl_compose3_dev, with the reference's zero-flow
+predicates evaluated in the same launch).  Steps rotate over `--sets` distinct input/output sets so
+that consecutive steps cannot be served from the 256 MiB Infinity Cache.  With N > 1 every rank owns
+one GPU and its own pairs (independent units, "weak" scaling, no data-path collective); the only
+exchange is the one-off RCCL broadcast of the shared first flow field before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+H, W = 2160, 3840
+BYTES_PER_PX = 27            # 2 x (8 + 1) read + (8 + 1) written
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+
+
+def make_pair(of, h, w, ref, variant):
+    """Synthetic pair of SURVEY.md 8(d) config 2, scaled to the requested size; `variant` perturbs the
+    angle/scale slightly so that the rotating sets are not byte-identical."""
+    ang = -30.0 + 0.5 * variant
+    sc = 0.8 + 0.005 * variant
+    f1 = of.Flow.from_transforms([['rotation', w / 2.0, h / 2.0, ang]], [h, w], ref)
+    f2 = of.Flow.from_transforms([['scaling', w * 400.0 / 1920.0, h * 300.0 / 1080.0, sc]], [h, w], ref)
+    rng = np.random.default_rng(variant)
+    m1 = rng.random((h, w)) > 0.05
+    m2 = rng.random((h, w)) > 0.05
+    return of.Flow(f1.vecs, ref, m1), of.Flow(f2.vecs, ref, m2)
+
+
+def cpu_baseline(h, w, ref, budget_s=20.0):
+    """The oracle (CPU restatement: NumPy op sequence of the reference + C remap with OpenMP) timed on
+    this box's host cores on a bounded sample of the same workload."""
+    from oracle import np_oracle as O
+    O.build()
+    threads = O.set_threads(min(len(os.sched_getaffinity(0)), 16))    # one GPU's CPU share on this pool
+    import oflibnumpy_amd as of
+    f1, f2 = make_pair(of, h, w, ref, 0)
+    a, b = O.OFlow(f1.vecs, ref, f1.mask), O.OFlow(f2.vecs, ref, f2.mask)
+    a.combine_with(b, 3)                                   # warm-up (page faults, OpenMP pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        a.combine_with(b, 3)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 16:
+            break
+    return {"value": round(n / dt, 4), "unit": "flow-fields/s", "cores": threads, "kind": "port",
+            "sample": "{} x OFlow.combine_with(mode=3) at {}x{} '{}' (NumPy op sequence of the reference, "
+                      "single thread, + C restatement of cv2.remap on {} OpenMP threads)".format(n, h, w, ref, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--sets", type=int, default=6, help="distinct HBM-resident input/output sets rotated over")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--ref", default="t", choices=["t", "s"])
+    ap.add_argument("--no-stats", action="store_true", help="skip the fused zero-flow predicates (A/B only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    h, w = args.height, args.width
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+
+    # The engine (plain HIP runtime behind a C ABI) is loaded BEFORE torch so that it binds the system
+    # ROCm runtime; torch is used for the rendezvous / barrier / max-reduce only (gloo, CPU tensors).
+    os.environ.setdefault("OFL_DEVICE", str(local_rank))
+    import oflibnumpy_amd as of
+    from oflibnumpy_amd import device as dev
+    nat = of.native
+    nat.ensure_device()
+    lib = nat.load()
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def device_sync():
+        nat.check(lib.ofl_device_sync())
+
+    # ---------------------------------------------------------------- inputs resident in HBM
+    ref = args.ref
+    sets = []
+    for i in range(args.sets):
+        f1, f2 = make_pair(of, h, w, ref, i + 16 * rank)
+        d1, d2 = f1.to_device(), f2.to_device()
+        out = dev.DeviceFlow.empty((h, w), ref)
+        fa, fb, sign = (d1, d2, -1) if ref == 't' else (d2, d1, +1)
+        sets.append((fa, fb, sign, out))
+    if world > 1:
+        # the one exchange step of the workload: broadcast a shared source field over xGMI (RCCL)
+        import torch
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            nat.check(lib.ofl_comm_unique_id(uid.ctypes.data))
+        t = torch.from_numpy(uid)
+        dist.broadcast(t, 0)
+        nat.check(lib.ofl_comm_init(uid.ctypes.data, rank, world))
+        nat.check(lib.ofl_comm_broadcast(sets[0][0].vecs.ptr, h * w * 8, 0, None))
+        nat.check(lib.ofl_comm_broadcast(sets[0][0].mask.ptr, h * w, 0, None))
+        device_sync()
+    total = args.warmup + args.steps
+    stats = None if args.no_stats else dev.DeviceBuffer.zeros(32 * total)
+
+    import ctypes
+    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+    nat.check(lib.ofl_event_create(ctypes.byref(ev0)))
+    nat.check(lib.ofl_event_create(ctypes.byref(ev1)))
+
+    def step(i):
+        fa, fb, sign, out = sets[i % len(sets)]
+        dev.compose3_launch(fa, fb, sign, out, stats, 32 * i if stats is not None else 0)
+
+    for i in range(args.warmup):
+        step(i)
+    device_sync()
+    barrier()
+    t0 = time.perf_counter()
+    nat.check(lib.ofl_event_record(ev0, None))
+    for i in range(args.warmup, total):
+        step(i)
+    nat.check(lib.ofl_event_record(ev1, None))
+    device_sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = ctypes.c_float()
+    nat.check(lib.ofl_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)))
+    kernel_ms = ms.value / args.steps
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    # the predicates computed inside the timed launches: none of these synthetic flows is zero, so the
+    # reference would not have taken an early exit on any step
+    if stats is not None:
+        words = stats.to_host((total, 8), np.uint32)
+        assert words[:, [0, 3, 4, 7]].all(), "unexpected zero-flow predicate"
+
+    if rank == 0:
+        fields = args.steps * world
+        algo_bytes = BYTES_PER_PX * h * w
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "flow-fields/sec for combine_with mode=3 @{}x{} float32".format(h, w),
+            "value": round(fields / elapsed, 2), "unit": "flow-fields/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Flow.combine_with(mode=3), ref '{}', {}x{} float32 vecs + uint8 masks: "
+                                   "f1 = rotation(-30 deg about centre), f2 = scaling(0.8), 5% random invalid "
+                                   "pixels; 1 pair per step per GPU, {} rotating HBM-resident sets"
+                                   .format(ref, h, w, len(sets)),
+                       "fields_per_step_per_gpu": 1, "fused_zero_flow_predicates": stats is not None,
+                       "parallelism": "independent pairs per GPU x{}".format(world)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "compose3_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(h, w, ref)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        nat.check(lib.ofl_comm_destroy())
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

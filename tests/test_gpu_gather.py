@@ -1,0 +1,318 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP gather kernels K1 / K2 / K4 / K5 called
+through the C ABI, against the CPU oracle on the same seeded inputs.  Bars: boolean masks and integer
+images bit-exact; float32 / float64 values bit-exact as well (the kernels mirror the oracle operation
+for operation), which is stricter than the 1e-4 relative tolerance BASELINE.json asks for."""
+import numpy as np
+import pytest
+
+from test_oracle import (k7_flows, K7_VALID_TARGET_T, K7_VALID_TARGET_T_MASKED, K7_VALID_SOURCE_S,
+                         K7_VALID_SOURCE_S_MASKED)
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4   # BASELINE.json: "within 1e-4 relative float32 on the warped pixels"
+
+
+def wobble_flow(shape, seed, amp=3.0):
+    h, w = shape
+    y, x = np.mgrid[:h, :w].astype('f')
+    rng = np.random.default_rng(seed)
+    a, b = rng.uniform(40, 130, 2)
+    return np.stack([amp * np.sin(2 * np.pi * x / a) * np.cos(2 * np.pi * y / b),
+                     amp * np.cos(2 * np.pi * x / b) * np.sin(2 * np.pi * y / a)], -1).astype('f')
+
+
+def rand_mask(shape, seed, p=0.05):
+    return np.random.default_rng(seed).random(shape) > p
+
+
+CASES = [  # (shape, transforms f1, transforms f2)
+    ((300, 400), [['rotation', 200, 150, -30]], [['translation', 40, 0]]),          # BASELINE config 1 (README)
+    ((256, 512), [['rotation', 255.5, 127.5, -30]], [['scaling', 100, 100, 0.8]]),  # reference test_combine_with
+    ((64, 68), [['rotation', 10, 10, 75]], [['scaling', 30, 30, 1.7]]),
+    ((37, 53), [['rotation', 20, 10, -15]], [['translation', 2.5, -3.25]]),         # W % 4 != 0 -> generic kernel
+    ((5, 1), [['translation', 0.5, 1]], [['translation', 0, 0.25]]),                # degenerate width
+    ((1, 8), [['translation', 0.5, 0]], [['translation', 1.5, 0]]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("ref", ['t', 's'])
+def test_compose3_matches_oracle_bit_exact(gpu, oracle, case, ref):
+    of = gpu
+    shape, t1, t2 = CASES[case]
+    # (np.squeeze inside the reference's flow generator drops a width / height of 1, so the vectors are
+    # generated on a padded shape and cut)
+    big = [shape[0] + 1, shape[1] + 1]
+    v1 = of.from_transforms(t1, big, ref)[:shape[0], :shape[1]] + wobble_flow(shape, case, 0.7)
+    v2 = of.from_transforms(t2, big, ref)[:shape[0], :shape[1]]
+    f1 = of.Flow(v1, ref, rand_mask(shape, case))
+    f2 = of.Flow(v2, ref, rand_mask(shape, case + 100))
+    got = f1.combine_with(f2, 3)
+    want = oracle.OFlow(f1.vecs, ref, f1.mask).combine_with(oracle.OFlow(f2.vecs, ref, f2.mask), 3)
+    assert got.ref == want.ref == ref
+    np.testing.assert_array_equal(got.mask, want.mask)
+    np.testing.assert_array_equal(got.vecs, want.vecs)
+    np.testing.assert_allclose(got.vecs, want.vecs, rtol=RTOL, atol=0)
+    # array facade (reference tests/test_flow_operations.py:26-72): same vectors as the method
+    np.testing.assert_array_equal(of.combine_flows(f1.vecs, f2.vecs, 3, ref),
+                                  of.Flow(f1.vecs, ref).combine_with(of.Flow(f2.vecs, ref), 3).vecs)
+
+
+@pytest.mark.parametrize("ref", ['t', 's'])
+def test_compose3_analytic(gpu, ref):
+    """reference tests/test_flow_class.py:1050-1057 at its own size and tolerance (atol 5e-2 inside masks)."""
+    of = gpu
+    shape = [512, 512]
+    tr = [['rotation', 255.5, 255.5, -30], ['scaling', 100, 100, 0.8]]
+    f1, f2, f3 = (of.Flow.from_transforms(t, shape, ref) for t in (tr[:1], tr[1:], tr))
+    r = f1.combine_with(f2, 3)
+    assert isinstance(r, of.Flow) and r.ref == ref
+    m = r.mask & f3.mask
+    assert m.sum() > 50000
+    np.testing.assert_allclose(r.vecs[m], f3.vecs[m], atol=5e-2)
+
+
+def test_compose3_raw_abi_batch_and_stats(gpu, oracle):
+    """ofl_compose3 (host-pointer entry of the C ABI) with a batch of fields, both quantisation modes,
+    and the fused zero-flow statistics."""
+    import ctypes
+    of = gpu
+    nat, lib = of.native, of.native.load()
+    B, H, W = 3, 48, 64
+    rng = np.random.default_rng(5)
+    fa = (rng.standard_normal((B, H, W, 2)) * 4).astype('f')
+    fb = (rng.standard_normal((B, H, W, 2)) * 6).astype('f')
+    ma = (rng.random((B, H, W)) > 0.1).astype(np.uint8)
+    mb = (rng.random((B, H, W)) > 0.1).astype(np.uint8)
+    fa[1] = 0                      # sampled field exactly zero
+    fb[2] = 5e-4                   # position field below the 1e-3 threshold but non-zero
+    fb[0][~mb[0].astype(bool)] = 0
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for quant in (nat.QUANT_OPENCV, nat.QUANT_EXACT):
+        for sign in (-1, 1):
+            out = np.empty_like(fa)
+            mout = np.empty_like(ma)
+            stats = np.zeros(2 * B, np.uint32)
+            nat.check(lib.ofl_compose3(p(fa), p(ma), p(fb), p(mb), sign, H, W, B, p(out), p(mout), p(stats), quant))
+            for b in range(B):
+                o, m = oracle.compose3_raw(fa[b], ma[b], fb[b], mb[b], sign, quant)
+                np.testing.assert_array_equal(out[b], o)
+                np.testing.assert_array_equal(mout[b].astype(bool), m)
+            S = nat
+            assert stats[2] == 0                                               # fa[1] all zero
+            assert stats[0] == (S.STAT_NONZERO_MASKED | S.STAT_NONZERO_TH_MASKED | S.STAT_NONZERO | S.STAT_NONZERO_TH)
+            assert stats[5] == (S.STAT_NONZERO_MASKED | S.STAT_NONZERO)          # fb[2]: non-zero but thresholded zero
+            for b in range(B):                                                  # vs the oracle predicates
+                for k, (f, m) in enumerate(((fa[b], ma[b]), (fb[b], mb[b]))):
+                    s = int(stats[2 * b + k])
+                    assert bool(s & S.STAT_NONZERO_MASKED) == (not oracle.is_zero_raw(f, m, False))
+                    assert bool(s & S.STAT_NONZERO_TH_MASKED) == (not oracle.is_zero_raw(f, m, True))
+                    assert bool(s & S.STAT_NONZERO) == (not oracle.is_zero_raw(f, None, False))
+                    assert bool(s & S.STAT_NONZERO_TH) == (not oracle.is_zero_raw(f, None, True))
+
+
+def test_compose3_early_exits(gpu):
+    """flow_class.py:1339-1354: zero operands hand back the other operand object."""
+    of = gpu
+    shape = [40, 48]
+    f = of.Flow.from_transforms([['rotation', 10, 10, 20]], shape, 't')
+    z = of.Flow.zero(shape, 't')
+    assert z.combine_with(f, 3) is f
+    assert f.combine_with(z, 3) is f
+    m = np.zeros(shape, bool)            # nothing valid => "zero" wherever the mask is True
+    zm = of.Flow(f.vecs, 't', m)
+    assert zm.combine_with(f, 3) is f
+    tiny = of.Flow(np.full(shape + [2], 5e-4, 'f'), 't')
+    assert tiny.combine_with(f, 3, thresholded=True) is f
+    r = tiny.combine_with(f, 3)          # not thresholded: computed normally
+    assert r is not f and r is not tiny
+
+
+DTYPES = [np.uint8, np.int16, np.uint16, np.float32, np.float64]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 6])
+def test_gather_raw_matches_oracle(gpu, oracle, dtype, C):
+    """ofl_gather_bilinear (host entry) vs the oracle for every dtype / channel count / arithmetic / rule,
+    with a flow placed inside a larger target (padding offsets)."""
+    import ctypes
+    of = gpu
+    nat, lib = of.native, of.native.load()
+    H, W, fH, fW, top, left = 50, 70, 40, 58, 6, 9
+    rng = np.random.default_rng(C * 10 + np.dtype(dtype).itemsize)
+    if np.issubdtype(dtype, np.integer):
+        info = np.iinfo(dtype)
+        src = rng.integers(info.min, info.max, (H, W, C), endpoint=True).astype(dtype)
+    else:
+        src = (rng.standard_normal((H, W, C)) * 100).astype(dtype)
+    flow = (of.from_transforms([['rotation', 30, 20, 25], ['scaling', 10, 10, 1.3]], [fH, fW], 't')
+            + wobble_flow((fH, fW), C, 1.5)).astype('f')
+    flow[0, 0] = [1e9, -1e9]                   # far outside: saturates like cv2's int16 coordinates
+    flow[1, 1] = [0.5, 0.5]                    # exact half-pixel: fixed-point / round-half-even ties
+    smask = (rng.random((H, W)) > 0.2).astype(np.uint8)
+    fmask = (rng.random((fH, fW)) > 0.2).astype(np.uint8)
+    code = {np.uint8: nat.U8, np.int16: nat.I16, np.uint16: nat.U16, np.float32: nat.F32, np.float64: nat.F64}[dtype]
+    p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    ariths = (nat.ARITH_NATIVE, nat.ARITH_FLOAT_RNE) if dtype == np.uint8 else (nat.ARITH_NATIVE,)
+    for quant in (nat.QUANT_OPENCV, nat.QUANT_EXACT):
+        for arith in ariths:
+            for rule in (nat.RULE_EQ1, nat.RULE_GE_HALF, nat.RULE_GT_HALF):
+                for sign in (-1, 1):
+                    dst = np.empty_like(src)
+                    valid = np.empty((H, W), np.uint8)
+                    nat.check(lib.ofl_gather_bilinear(p(src), code, C, H, W, p(flow), fH, fW, top, left, sign,
+                                                      p(smask), p(fmask), p(dst), p(valid), quant, arith, rule))
+                    want, wv = oracle.gather_bilinear(src, flow, sign, smask=smask, want_valid=True, quant=quant,
+                                                      arith=arith, rule=rule, pad=(top, left))
+                    np.testing.assert_array_equal(dst, want)
+                    inside = np.zeros((H, W), bool)
+                    inside[top:top + fH, left:left + fW] = fmask.astype(bool)
+                    np.testing.assert_array_equal(valid.astype(bool), wv & inside)
+
+
+def test_apply_flow_t_known_answers(gpu):
+    """reference tests/test_utils.py:277-283 (integer translation == ndimage.shift, exact) and the 7x7 masks
+    of tests/test_flow_class.py:872-880, 899-912, 928-954, 973-975 through the product API."""
+    from scipy import ndimage
+    of = gpu
+    img = (np.random.default_rng(0).random((512, 512, 3)) * 255).astype(np.uint8)
+    f = of.from_transforms([['translation', 10, 20]], [512, 512], 't')
+    np.testing.assert_array_equal(of.apply_flow(f, img, 't'), ndimage.shift(img, [20, 10, 0]))
+    f_s, f_sm, f_t, f_tm = k7_flows(lambda t, s, r, m=None: of.Flow.from_transforms(t, list(s), r, m))
+    np.testing.assert_array_equal(f_t.valid_target(), K7_VALID_TARGET_T)
+    np.testing.assert_array_equal(f_tm.valid_target(), K7_VALID_TARGET_T_MASKED)
+    np.testing.assert_array_equal(f_s.valid_source(), K7_VALID_SOURCE_S)
+    np.testing.assert_array_equal(f_sm.valid_source(), K7_VALID_SOURCE_S_MASKED)
+    np.testing.assert_array_equal(of.valid_target(f_t.vecs, 't'), K7_VALID_TARGET_T)
+    np.testing.assert_array_equal(of.valid_source(f_s.vecs, 's'), K7_VALID_SOURCE_S)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_flow_apply_t_matches_oracle(gpu, oracle, dtype):
+    """Flow.apply ('t') for every target kind of reference tests/test_flow_class.py:418-467: 3-D / 2-D arrays,
+    with and without valid area and target mask, Flow targets, padding with and without cut."""
+    of = gpu
+    shape = (90, 110)
+    rng = np.random.default_rng(3)
+    img = (rng.random(shape + (3,)) * 200).astype(dtype)
+    fmask = rand_mask(shape, 11, 0.1)
+    tmask = rand_mask(shape, 12, 0.1)
+    flow = of.Flow.from_transforms([['rotation', 30, 50, 30]], list(shape), 't', fmask)
+    oflow = oracle.OFlow(flow.vecs, 't', fmask)
+    np.testing.assert_array_equal(flow.apply(img), oflow.apply(img))
+    np.testing.assert_array_equal(flow.apply(img), of.apply_flow(flow.vecs, img, 't'))
+    np.testing.assert_array_equal(flow.apply(img[..., 0]), oflow.apply(img[..., 0]))
+    for tm in (None, tmask):
+        if dtype == np.uint16 and tm is None:
+            # uint16 image + the default int8 mask concatenates to int32, which cv2.remap cannot
+            # interpolate (cv2.error in the reference): refused on the host
+            with pytest.raises(TypeError):
+                flow.apply(img, tm, return_valid_area=True)
+            continue
+        w, v = flow.apply(img, tm, return_valid_area=True)
+        ow, ov = oflow.apply(img, tm, return_valid_area=True)
+        np.testing.assert_array_equal(w, ow)
+        np.testing.assert_array_equal(v, ov)
+        assert w.dtype == dtype and v.dtype == bool
+        w, v = flow.apply(img[..., 1], tm, return_valid_area=True)
+        ow, ov = oflow.apply(img[..., 1], tm, return_valid_area=True)
+        np.testing.assert_array_equal(w, ow)
+        np.testing.assert_array_equal(v, ov)
+
+
+def test_flow_apply_t_flow_target_and_padding(gpu, oracle):
+    of = gpu
+    shape = (90, 110)
+    m1, m2 = rand_mask(shape, 1, 0.1), rand_mask(shape, 2, 0.1)
+    flow = of.Flow.from_transforms([['rotation', 30, 50, 30]], list(shape), 't', m1)
+    tgt = of.Flow.from_transforms([['scaling', 20, 20, 1.2]], list(shape), 's', m2)
+    r = flow.apply(tgt)
+    o = oracle.OFlow(flow.vecs, 't', m1).apply(oracle.OFlow(tgt.vecs, 's', m2))
+    assert r.ref == 's'
+    np.testing.assert_array_equal(r.vecs, o.vecs)
+    np.testing.assert_array_equal(r.mask, o.mask)
+    # padding: a smaller flow on a larger target == the full flow cut out (reference test_apply :441-467)
+    img = (np.random.default_rng(4).random((120, 160, 3)) * 255).astype(np.uint8)
+    full = of.Flow.from_transforms([['rotation', 30, 50, 30]], [120, 160], 't')
+    desired = of.apply_flow(full.vecs, img, 't')
+    padding = [50, 40, 30, 80]
+    cut_flow = of.Flow.from_transforms([['rotation', 0, 0, 30]], [120 - 90, 160 - 110], 't')
+    got = cut_flow.apply(img, padding=padding, cut=False)
+    np.testing.assert_array_equal(got[50:-40, 30:-80], desired[50:-40, 30:-80])
+    np.testing.assert_array_equal(got[:50], img[:50])               # zero flow outside: identity
+    got = cut_flow.apply(img, padding=padding, cut=True)
+    np.testing.assert_array_equal(got, desired[50:-40, 30:-80])
+    w, v = cut_flow.apply(img, return_valid_area=True, padding=padding, cut=False)
+    assert v.shape == (120, 160) and not v[:50].any() and not v[:, :30].any()
+    tf = of.Flow.from_transforms([['rotation', 30, 50, 30]], [120, 160], 't')
+    wf = cut_flow.apply(tf, padding=padding, cut=True)
+    np.testing.assert_array_equal(wf.vecs, of.apply_flow(full.vecs, tf.vecs, 't')[50:-40, 30:-80])
+
+
+def test_flow_stats_and_axpy(gpu, oracle):
+    import ctypes
+    of = gpu
+    nat, lib = of.native, of.native.load()
+    rng = np.random.default_rng(8)
+    for n in (1, 2, 7, 1000, 4097):
+        v = np.zeros((n, 2), np.float32)
+        m = (rng.random(n) > 0.3).astype(np.uint8)
+        p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        for variant in range(5):
+            if variant == 1:
+                v[n // 2] = [0, 7e-4]
+            elif variant == 2:
+                v[n - 1] = [-3, 0]
+                m[n - 1] = 0
+            elif variant == 3:
+                m[n - 1] = 1
+            elif variant == 4:
+                v[0, 0] = np.inf
+            for mask in (None, m):
+                s = np.zeros(1, np.uint32)
+                nat.check(lib.ofl_flow_stats(p(v), p(mask), n, np.float32(1e-3), p(s)))
+                s = int(s[0])
+                fin = v[np.isfinite(v).all(-1)] if variant == 4 else v
+                assert bool(s & nat.STAT_NONFINITE) == (variant == 4)
+                if variant != 4:
+                    mm = mask if mask is not None else np.ones(n, np.uint8)
+                    assert bool(s & nat.STAT_NONZERO) == (not oracle.is_zero_raw(v[None], None, False))
+                    assert bool(s & nat.STAT_NONZERO_TH) == (not oracle.is_zero_raw(v[None], None, True))
+                    assert bool(s & nat.STAT_NONZERO_MASKED) == (not oracle.is_zero_raw(v[None], mm[None], False))
+                    assert bool(s & nat.STAT_NONZERO_TH_MASKED) == (not oracle.is_zero_raw(v[None], mm[None], True))
+    a = of.DeviceFlow.from_host(rng.standard_normal((33, 35, 2)).astype('f'), 't', rng.random((33, 35)) > 0.2)
+    b = of.DeviceFlow.from_host(rng.standard_normal((33, 35, 2)).astype('f'), 's', rng.random((33, 35)) > 0.2)
+    (av, am), (bv, bm) = a.to_host(), b.to_host()
+    for got, want in (((a + b).to_host(), (av + bv, am & bm)), ((a - b).to_host(), (av - bv, am & bm)),
+                      ((-a).to_host(), (-av, am))):
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+    assert (a + b).ref == 't'
+
+
+def test_full_size_properties(gpu, oracle):
+    """BASELINE.json sizes (2160 x 3840), through size-independent properties:
+      * translation (+) translation composes to the exact sum with a full-rectangle mask,
+      * row bands of the big result equal the oracle run on those bands' dependencies,
+      * a batch launch equals per-field launches."""
+    of = gpu
+    H, W = 2160, 3840
+    t1 = of.Flow.from_transforms([['translation', 16, -8]], [H, W], 't')
+    t2 = of.Flow.from_transforms([['translation', -5, 24]], [H, W], 't')
+    r = t1.combine_with(t2, 3)
+    np.testing.assert_array_equal(r.vecs[r.mask], np.broadcast_to(np.float32([11, 16]), (int(r.mask.sum()), 2)))
+    want_mask = np.zeros((H, W), bool)
+    want_mask[24:H, 0:W - 5] = True         # samples (x + 5, y - 24) must land inside the source
+    np.testing.assert_array_equal(r.mask, want_mask)
+    # general flows: compare three 16-row bands with the oracle evaluated on the full inputs
+    f1 = of.Flow.from_transforms([['rotation', 1920, 1080, -30]], [H, W], 't', rand_mask((H, W), 21))
+    f2 = of.Flow.from_transforms([['scaling', 800, 600, 0.8]], [H, W], 't', rand_mask((H, W), 22))
+    r = f1.combine_with(f2, 3)
+    o, mo = oracle.compose3_raw(f1.vecs, f1.mask, f2.vecs, f2.mask, -1)
+    np.testing.assert_array_equal(r.mask, mo)
+    np.testing.assert_array_equal(r.vecs, o)
+    f3 = of.Flow.from_transforms([['rotation', 1920, 1080, -30], ['scaling', 800, 600, 0.8]], [H, W], 't')
+    m = r.mask & f3.mask
+    np.testing.assert_allclose(r.vecs[m], f3.vecs[m], atol=5e-2)

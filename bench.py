@@ -28,13 +28,23 @@ BYTES_PER_PX = 27            # 2 x (8 + 1) read + (8 + 1
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
 
+PATTERN = "scale"
+
+
 def make_pair(of, h, w, ref, variant):
     """Synthetic pair of SURVEY.md 8(d) config 2, scaled to the requested size; `variant` perturbs the
-    angle/scale slightly so that the rotating sets are not byte-identical."""
+    angle/scale slightly so that the rotating sets are not byte-identical.  PATTERN selects what the
+    SAMPLING field looks like: "scale" (the config: f2 = scaling 0.8, 36 % of the samples fall outside),
+    "shift" (f2 = 3.3 px translation: streaming-friendly gather) or "rot" (f1 and f2 swapped: samples lie
+    on a grid rotated by 30 degrees)."""
     ang = -30.0 + 0.5 * variant
     sc = 0.8 + 0.005 * variant
     f1 = of.Flow.from_transforms([['rotation', w / 2.0, h / 2.0, ang]], [h, w], ref)
     f2 = of.Flow.from_transforms([['scaling', w * 400.0 / 1920.0, h * 300.0 / 1080.0, sc]], [h, w], ref)
+    if PATTERN == "shift":
+        f2 = of.Flow.from_transforms([['translation', 3.3 + 0.1 * variant, -2.7]], [h, w], ref)
+    elif PATTERN == "rot":
+        f1, f2 = f2, f1
     rng = np.random.default_rng(variant)
     m1 = rng.random((h, w)) > 0.05
     m2 = rng.random((h, w)) > 0.05
@@ -68,14 +78,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--sets", type=int, default=6, help="distinct HBM-resident input/output sets rotated over")
+    ap.add_argument("--sets", type=int, default=0, help="distinct HBM-resident input/output sets rotated over "
+                                                      "(default: enough to exceed the 256 MiB Infinity Cache twice)")
+    ap.add_argument("--batch", type=int, default=8, help="independent flow-field pairs per step (one launch)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--ref", default="t", choices=["t", "s"])
     ap.add_argument("--no-stats", action="store_true", help="skip the fused zero-flow predicates (A/B only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pattern", default="scale", choices=["scale", "shift", "rot"],
+                    help="sampling pattern of the gather (default: the BASELINE config)")
     args = ap.parse_args()
     h, w = args.height, args.width
+    global PATTERN
+    PATTERN = args.pattern
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,12 +125,29 @@ def main():
 
     # ---------------------------------------------------------------- inputs resident in HBM
     ref = args.ref
+    B = max(1, args.batch)
+    set_bytes = BYTES_PER_PX * h * w * B
+    n_sets = args.sets if args.sets > 0 else max(2, -(-(3 * 256 << 20) // set_bytes))
+    n = h * w
+
+    class Batch:            # B fields stored back to back: vecs [B][H][W][2] f32, mask [B][H][W] u8
+        def __init__(self):
+            self.vecs, self.mask, self.shape = dev.DeviceBuffer(B * n * 8), dev.DeviceBuffer(B * n), (h, w)
+
+        def put(self, i, flow):
+            nat.check(lib.ofl_upload(self.vecs.ptr + i * n * 8, flow.vecs.ctypes.data, n * 8, None))
+            m = flow.mask.astype(np.uint8)
+            nat.check(lib.ofl_upload(self.mask.ptr + i * n, m.ctypes.data, n, None))
+            nat.check(lib.ofl_stream_sync(None))
+
     sets = []
-    for i in range(args.sets):
-        f1, f2 = make_pair(of, h, w, ref, i + 16 * rank)
-        d1, d2 = f1.to_device(), f2.to_device()
-        out = dev.DeviceFlow.empty((h, w), ref)
-        fa, fb, sign = (d1, d2, -1) if ref == 't' else (d2, d1, +1)
+    for i in range(n_sets):
+        b1, b2, out = Batch(), Batch(), Batch()
+        for j in range(B):
+            f1, f2 = make_pair(of, h, w, ref, (i * B + j) % 24 + 32 * rank)
+            b1.put(j, f1)
+            b2.put(j, f2)
+        fa, fb, sign = (b1, b2, -1) if ref == 't' else (b2, b1, +1)
         sets.append((fa, fb, sign, out))
     if world > 1:
         # the one exchange step of the workload: broadcast a shared source field over xGMI (RCCL)
@@ -125,11 +158,11 @@ def main():
         t = torch.from_numpy(uid)
         dist.broadcast(t, 0)
         nat.check(lib.ofl_comm_init(uid.ctypes.data, rank, world))
-        nat.check(lib.ofl_comm_broadcast(sets[0][0].vecs.ptr, h * w * 8, 0, None))
+        nat.check(lib.ofl_comm_broadcast(sets[0][0].vecs.ptr, h * w * 8, 0, None))     # first field of the first batch
         nat.check(lib.ofl_comm_broadcast(sets[0][0].mask.ptr, h * w, 0, None))
         device_sync()
     total = args.warmup + args.steps
-    stats = None if args.no_stats else dev.DeviceBuffer.zeros(32 * total)
+    stats = None if args.no_stats else dev.DeviceBuffer.zeros(32 * B * total)
 
     import ctypes
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -138,7 +171,7 @@ def main():
 
     def step(i):
         fa, fb, sign, out = sets[i % len(sets)]
-        dev.compose3_launch(fa, fb, sign, out, stats, 32 * i if stats is not None else 0)
+        dev.compose3_launch(fa, fb, sign, out, stats, 32 * B * i if stats is not None else 0, batch=B)
 
     for i in range(args.warmup):
         step(i)
@@ -165,12 +198,12 @@ def main():
     # the predicates computed inside the timed launches: none of these synthetic flows is zero, so the
     # reference would not have taken an early exit on any step
     if stats is not None:
-        words = stats.to_host((total, 8), np.uint32)
-        assert words[:, [0, 3, 4, 7]].all(), "unexpected zero-flow predicate"
+        words = stats.to_host((total * B, 8), np.uint32)
+        assert words[:, [0, 1, 4, 5, 6, 7]].all(), "unexpected zero-flow predicate"
 
     if rank == 0:
-        fields = args.steps * world
-        algo_bytes = BYTES_PER_PX * h * w
+        fields = args.steps * world * B
+        algo_bytes = BYTES_PER_PX * h * w * B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "flow-fields/sec for combine_with mode=3 @{}x{} float32".format(h, w),
@@ -181,15 +214,20 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Flow.combine_with(mode=3), ref '{}', {}x{} float32 vecs + uint8 masks: "
                                    "f1 = rotation(-30 deg about centre), f2 = scaling(0.8), 5% random invalid "
-                                   "pixels; 1 pair per step per GPU, {} rotating HBM-resident sets"
-                                   .format(ref, h, w, len(sets)),
-                       "fields_per_step_per_gpu": 1, "fused_zero_flow_predicates": stats is not None,
+                                   "pixels; {} independent pairs per step (one launch) per GPU, {} rotating HBM-resident "
+                                   "sets".format(ref, h, w, B, len(sets)),
+                       "fields_per_step_per_gpu": B, "fused_zero_flow_predicates": stats is not None, "sampling_pattern": PATTERN,
                        "parallelism": "independent pairs per GPU x{}".format(world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "compose3_kernel", "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
+        tpath = os.path.join(ROOT, "profiles", "r01_compose3_traffic.json")
+        if os.path.exists(tpath) and (h, w) == (H, W) and PATTERN == "scale":
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+            # correction + WRITE_SIZE), scaled from the profiled batch to this run's batch
+            line["roofline"]["traffic"] = round(json.load(open(tpath))["hbm_bytes_per_field"] * B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(h, w, ref)
         print(json.dumps(line), flush=True)

@@ -106,13 +106,16 @@ int         ofl_mem_info(size_t *free_bytes, size_t *total_bytes);
  *   ref 't': fa/ma = self (f1), fb/mb = flow (f2), sign = -1
  *   ref 's': fa/ma = flow (f2), fb/mb = self (f1), sign = +1
  * batch fields are stored back to back ([batch][H][W][..]).  `stats` (device, uint32[batch][8] or
- * NULL) receives zero-flow flag WORDS: stats[b][k] (k = 0..3, the OFL_STAT_* bit index) for fa/ma
- * and stats[b][4 + k] for fb/mb; a word is set to 1 when the condition holds and is never cleared,
- * so the caller zeroes the words beforehand (plain idempotent stores -- no atomics on the hot path).
- * With stats != NULL the kernel additionally streams fa/ma once so that the reference's early-exit
- * predicates (flow_class.py:1339-1354, utils.py:215) can be honoured without separate passes.
- * The host entry returns the same information folded into bit masks: stats_host[2*b] = OFL_STAT_*
- * bits of fa, stats_host[2*b+1] = bits of fb.
+ * NULL) receives zero-flow flag WORDS computed from data the launch reads anyway (no extra traffic):
+ * a word is set to 1 when its condition holds and is never cleared, so the caller zeroes the words
+ * beforehand (plain idempotent stores -- no atomics on the hot path).
+ *     stats[b][4 + k], k = 0..3 (the OFL_STAT_* bit index): EXACT predicates of fb/mb.
+ *     stats[b][0], stats[b][1]: CERTIFICATES for fa/ma -- set when a gathered, masked vector of fa is
+ *         non-zero / at or above the 1e-3 threshold, i.e. fa is certainly not (thresholded-)zero.  A clear
+ *         word means "not observed": the caller confirms with ofl_flow_stats_dev before taking one of the
+ *         reference's early exits (flow_class.py:1339-1354).  stats[b][2..3] are not written.
+ * The host entry returns exact OFL_STAT_* bit masks: stats_host[2*b] for fa, stats_host[2*b+1] for fb.
+ * out / mout must not alias the inputs.
  */
 int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const uint8_t *mb,
                      int sign, int H, int W, int batch, float *out, uint8_t *mout,

@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libofl_hip.so")
+LIB_PATH = os.environ.get("OFL_LIB") or os.path.join(_HERE, "libofl_hip.so")   # OFL_LIB: A/B builds only
 
 # enums of include/ofl.h
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_NOPOINTS, E_RCCL = 0, -1, -2, -3, -4, -5, -6

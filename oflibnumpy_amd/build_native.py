@@ -10,11 +10,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libofl_hip.so")
-OBJ_DIR = os.path.join(CSRC, "_obj")
+OUT = os.path.join(HERE, os.environ.get("OFL_BUILD_NAME", "libofl_hip.so"))
+OBJ_DIR = os.path.join(CSRC, "_obj" + os.environ.get("OFL_BUILD_TAG", ""))
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"] + os.environ.get("OFL_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

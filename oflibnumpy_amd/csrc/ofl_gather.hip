@@ -4,12 +4,13 @@
 // (coalesced, 16 B per lane), derives the cv2.remap sample position, and gathers the 2x2 source
 // neighbourhood.  The two horizontally adjacent taps of one source row are fetched with ONE
 // 8-byte-aligned 16-byte load; reuse between neighbouring pixels is served by the per-CU L1 and the
-// per-XCD L2, which is why workgroups own compact 2-D tiles (64 x 16 px) and consecutive tiles of
-// one XCD are neighbours (blocks b and b+8 share an XCD on MI355X).
+// per-XCD L2, which is why workgroups own 2-D tiles and consecutive tiles of one XCD are neighbours
+// (blocks b and b+8 share an XCD on MI355X).
 //
 // Numerics follow oracle/ofl_oracle.c operation for operation (contraction disabled) so that the
 // float results and the validity masks are bit-identical to the CPU restatement.
 #include "ofl_common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -17,9 +18,7 @@ using namespace ofl;
 
 namespace {
 
-constexpr int kTileW = 64;   // pixels per tile row  (16 lanes x 4 px)
-constexpr int kTileH = 16;   // tile rows            (256 threads / 16 lanes)
-constexpr int kPx    = 4;    // pixels per thread along x
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct __attribute__((aligned(8))) Pair2 { float lo_u, lo_v, hi_u, hi_v; };   // taps (ix, ix+1) of a float2 field
 
@@ -57,97 +56,310 @@ __device__ __forceinline__ void select_mask(uint32_t lo, uint32_t hi, int d, boo
 }
 
 // ------------------------------------------------------------------------------------ K2
-template <int QUANT, bool STATS>
-__global__ __launch_bounds__(256)
-void compose3_kernel(const float *__restrict__ fa, const uint8_t *__restrict__ ma,
-                     const float *__restrict__ fb, const uint8_t *__restrict__ mb,
-                     int sign, int H, int W, int tiles_x, int tiles_per_field, int nblocks,
-                     float *__restrict__ out, uint8_t *__restrict__ mout,
-                     uint32_t *__restrict__ stats, float th)
+// Workgroup tile: 128 px x 8 rows, 256 threads.  Lane (lx, ly) owns the two pixel PAIRS at
+// x = 2*lx and x = 64 + 2*lx of its tile row, so that every stream instruction of a wave covers
+// contiguous memory (32 lanes x 16 B = 512 B of vectors, 32 lanes x 2 B = 64 B of mask per row):
+// no half-filled 64-byte requests on either the read or the write side.
+#ifndef OFL_C3_LANES_X
+#define OFL_C3_LANES_X 32            // lanes along x per tile row (16 / 32 / 64): tile = 4*LX px x 256/LX rows
+#endif
+#ifndef OFL_C3_NT
+#define OFL_C3_NT 3                  // experiment knob: 1 = non-temporal stores, 2 = non-temporal stream loads
+#endif
+constexpr int kC3LanesX = OFL_C3_LANES_X;
+constexpr int kC3TileW = 4 * kC3LanesX, kC3TileH = 256 / kC3LanesX, kC3Px = 4;
+
+struct C3Pos {            // what must stay live while the gather is in flight
+    int   ix, iy;         // top-left tap
+    float fx, fy;         // fractional position (multiples of 1/32 with cv2's snapping)
+};
+
+struct C3Tap {
+    int   ax, ay;         // "fraction is non-zero" indicators for the validity test
+    float w0, w1, w2, w3;
+};
+
+// Sample position: utils.py:231-235 evaluates float32(float64(grid) -/+ float64(flow)).  For an integer
+// grid coordinate below 2^15 and any float32 flow value this equals the single float32 operation
+// (the float64 sum is exact unless |flow| < 2^-14, and then it cannot land on a float32 rounding
+// midpoint, whose distance from the integer is at least 2^-24 * 2^floor(log2 grid)), so one v_add_f32
+// / v_sub_f32 reproduces NumPy bit for bit; tests compare against the float64 oracle.
+template <int QUANT>
+__device__ __forceinline__ C3Pos c3_pos(int gx, int gy, float fu, float fv, int sign)
 {
-    const int tile = xcd_swizzle(blockIdx.x, nblocks);
-    const int b    = tile / tiles_per_field;
-    const int t    = tile - b * tiles_per_field;
-    const int ty   = t / tiles_x, tx = t - ty * tiles_x;
-    const int lx   = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x0   = tx * kTileW + lx * kPx;
-    const int y    = ty * kTileH + ly;
-
-    const size_t field = (size_t)b * H * W;
-    fa += field * 2; fb += field * 2; out += field * 2;
-    ma += field;     mb += field;     mout += field;
-
-    uint32_t bits_a = 0, bits_b = 0;
-    if (y < H && x0 < W) {
-        const size_t o = (size_t)y * W + x0;
-        const float4   b01 = *reinterpret_cast<const float4 *>(fb + 2 * o);
-        const float4   b23 = *reinterpret_cast<const float4 *>(fb + 2 * o + 4);
-        const uint32_t mb4 = *reinterpret_cast<const uint32_t *>(mb + o);
-        const float bu[kPx] = { b01.x, b01.z, b23.x, b23.z };
-        const float bv[kPx] = { b01.y, b01.w, b23.y, b23.w };
-
-        float    ou[kPx], ov[kPx];
-        uint32_t mo = 0;
-#pragma unroll
-        for (int j = 0; j < kPx; ++j) {
-            const Tap tp = make_tap<QUANT>(map_coord(x0 + j, bu[j], sign), map_coord(y, bv[j], sign));
-            const int  ixc = min(max(tp.ix, 0), W - 2);
-            const int  d   = tp.ix - ixc;
-            const bool r0  = (unsigned)tp.iy < (unsigned)H;
-            const bool r1  = (unsigned)(tp.iy + 1) < (unsigned)H;
-            const int  y0c = min(max(tp.iy, 0), H - 1);
-            const int  y1c = min(max(tp.iy + 1, 0), H - 1);
-            const size_t s0 = (size_t)y0c * W + ixc, s1 = (size_t)y1c * W + ixc;
-
-            const Pair2 p0 = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
-            const Pair2 p1 = *reinterpret_cast<const Pair2 *>(fa + 2 * s1);
-            const uint32_t m00 = ma[s0], m01 = ma[s0 + 1], m10 = ma[s1], m11 = ma[s1 + 1];
-
-            float u00, v00, u01, v01, u10, v10, u11, v11, a00, a01, a10, a11;
-            select_pair(p0, d, r0, u00, v00, u01, v01);
-            select_pair(p1, d, r1, u10, v10, u11, v11);
-            select_mask(m00, m01, d, r0, a00, a01);
-            select_mask(m10, m11, d, r1, a10, a11);
-
-            ou[j] = __fadd_rn(bu[j], blend4(u00, u01, u10, u11, tp));     // Flow.__add__, flow_class.py:332
-            ov[j] = __fadd_rn(bv[j], blend4(v00, v01, v10, v11, tp));
-            const bool mbit = ((mb4 >> (8 * j)) & 0xffu) != 0;
-            const bool ok   = (blend4(a00, a01, a10, a11, tp) == 1.0f) & mbit;   // flow_class.py:668,680,333
-            mo |= (ok ? 1u : 0u) << (8 * j);
-            if (STATS) bits_b |= stat_bits(bu[j], bv[j], mbit, th);
-        }
-        *reinterpret_cast<float4 *>(out + 2 * o)     = make_float4(ou[0], ov[0], ou[1], ov[1]);
-        *reinterpret_cast<float4 *>(out + 2 * o + 4) = make_float4(ou[2], ov[2], ou[3], ov[3]);
-        *reinterpret_cast<uint32_t *>(mout + o)      = mo;
-
-        if (STATS) {   // stream the sampled field once for its own early-exit predicate
-            const float4   a01 = *reinterpret_cast<const float4 *>(fa + 2 * o);
-            const float4   a23 = *reinterpret_cast<const float4 *>(fa + 2 * o + 4);
-            const uint32_t ma4 = *reinterpret_cast<const uint32_t *>(ma + o);
-            bits_a |= stat_bits(a01.x, a01.y, (ma4 & 0xffu) != 0, th);
-            bits_a |= stat_bits(a01.z, a01.w, (ma4 & 0xff00u) != 0, th);
-            bits_a |= stat_bits(a23.x, a23.y, (ma4 & 0xff0000u) != 0, th);
-            bits_a |= stat_bits(a23.z, a23.w, (ma4 & 0xff000000u) != 0, th);
-        }
+    const float px = sign >= 0 ? __fadd_rn((float)gx, fu) : __fsub_rn((float)gx, fu);
+    const float py = sign >= 0 ? __fadd_rn((float)gy, fv) : __fsub_rn((float)gy, fv);
+    C3Pos p;
+    if (QUANT == OFL_QUANT_OPENCV) {
+        const int sx = cv_round(__fmul_rn(px, 32.0f)), sy = cv_round(__fmul_rn(py, 32.0f));
+        p.ix = sx >> 5; p.iy = sy >> 5;      // unsaturated: beyond +-32767 every tap is outside anyway
+        p.fx = (float)(sx & 31) * (1.0f / 32.0f);
+        p.fy = (float)(sy & 31) * (1.0f / 32.0f);
+    } else {
+        float flx = floorf(px), fly = floorf(py);
+        p.fx = __fsub_rn(px, flx); p.fy = __fsub_rn(py, fly);
+        flx = fminf(fmaxf(flx, -32768.0f), 32767.0f);
+        fly = fminf(fmaxf(fly, -32768.0f), 32767.0f);
+        p.ix = (int)flx; p.iy = (int)fly;
     }
-    if (STATS) {
-        // wave-level OR, then idempotent plain stores of the flag words (no atomics: thousands of
-        // waves hitting one address with atomics would serialise at the memory side).
-        uint32_t wa = 0, wb = 0;
+    return p;
+}
+
+// Bilinear weights from the fractional position; evaluated AFTER the gather has been issued so that
+// they do not occupy registers while the loads are in flight.
+template <int QUANT>
+__device__ __forceinline__ C3Tap c3_weights(const C3Pos &p)
+{
+    C3Tap t;
+    t.ax = (QUANT == OFL_QUANT_OPENCV) ? (p.fx != 0.0f) : 1;
+    t.ay = (QUANT == OFL_QUANT_OPENCV) ? (p.fy != 0.0f) : 1;
+    const float x0 = __fsub_rn(1.0f, p.fx), y0 = __fsub_rn(1.0f, p.fy);
+    t.w0 = __fmul_rn(y0, x0); t.w1 = __fmul_rn(y0, p.fx);
+    t.w2 = __fmul_rn(p.fy, x0); t.w3 = __fmul_rn(p.fy, p.fx);
+    return t;
+}
+
+__device__ __forceinline__ float c3_blend(float v00, float v01, float v10, float v11, const C3Tap &t)
+{
+    float s = __fmul_rn(v00, t.w0);
+    s = __fadd_rn(s, __fmul_rn(v01, t.w1));
+    s = __fadd_rn(s, __fmul_rn(v10, t.w2));
+    s = __fadd_rn(s, __fmul_rn(v11, t.w3));
+    return s;
+}
+
+// "interpolated mask == 1" (flow_class.py:668).  With cv2's 1/32-px weights (multiples of 1/1024
+// that sum to exactly 1) the float sum equals 1 iff every tap with a non-zero weight carries mask 1,
+// which is pure integer logic; the un-snapped extension mode keeps the float comparison.
+template <int QUANT>
+__device__ __forceinline__ bool c3_valid(bool m00, bool m01, bool m10, bool m11, const C3Tap &t)
+{
+    if (QUANT == OFL_QUANT_OPENCV) {
+        const bool zx = t.ax == 0, zy = t.ay == 0;
+        return m00 & (m01 | zx) & (m10 | zy) & (m11 | zx | zy);
+    }
+    return c3_blend(m00 ? 1.0f : 0.0f, m01 ? 1.0f : 0.0f, m10 ? 1.0f : 0.0f, m11 ? 1.0f : 0.0f, t) == 1.0f;
+}
+
+struct C3Args {
+    const float *fa; const uint8_t *ma; const float *fb; const uint8_t *mb;
+    float *out; uint8_t *mout; uint32_t *stats;
+    int sign, H, W, tiles_x, tiles_per_field, ntiles;
+    float th;
+    int ablate;            // development knob (OFL_C3_ABLATE): 1 = skip the gather, 2 = skip the stores; 0 in production
+};
+
+struct C3Stream {          // one lane's share of a tile row of the streamed field fb/mb
+    float4   v[2];
+    uint32_t m[2];
+};
+
+struct C3Stat {            // running maxima for the zero-flow predicates of one field pair
+    float amax_m, bmax, bmax_m;
+};
+
+__device__ __forceinline__ void c3_tile_coords(const C3Args &a, int tile, int &b, int &y, int (&xg)[2])
+{
+    b = tile / a.tiles_per_field;
+    const int t  = tile - b * a.tiles_per_field;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    y = ty * kC3TileH + (threadIdx.x / kC3LanesX);
+    xg[0] = tx * kC3TileW + 2 * (threadIdx.x % kC3LanesX);
+    xg[1] = xg[0] + 2 * kC3LanesX;
+}
+
+__device__ __forceinline__ C3Stream c3_load_stream(const C3Args &a, int tile)
+{
+    int b, y, xg[2];
+    c3_tile_coords(a, tile, b, y, xg);
+    const size_t base = (size_t)b * a.H * a.W + (size_t)y * a.W;
+    C3Stream s;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wa |= (__ballot((bits_a >> k) & 1u) != 0ull) ? (1u << k) : 0u;
-            wb |= (__ballot((bits_b >> k) & 1u) != 0ull) ? (1u << k) : 0u;
-        }
-        if ((threadIdx.x & 63) == 0) {
-            uint32_t *s = stats + (size_t)b * 8;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (((wa >> k) & 1u) && __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) s[k] = 1u;
-                if (((wb >> k) & 1u) && __hip_atomic_load(s + 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) s[4 + k] = 1u;
+    for (int g = 0; g < 2; ++g) {
+        s.v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s.m[g] = 0;
+        if (y < a.H && xg[g] < a.W) {
+            if (OFL_C3_NT & 2) {
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.fb + 2 * (base + xg[g])));
+                s.v[g] = make_float4(t.x, t.y, t.z, t.w);
+                s.m[g] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(a.mb + base + xg[g]));
+            } else {
+                s.v[g] = *reinterpret_cast<const float4 *>(a.fb + 2 * (base + xg[g]));
+                s.m[g] = *reinterpret_cast<const uint16_t *>(a.mb + base + xg[g]);
             }
         }
     }
+    return s;
+}
+
+__device__ __forceinline__ void c3_flush_stats(const C3Args &a, int b, const C3Stat &st)
+{
+    // Flag words (set-only, plain idempotent stores; thousands of waves issuing atomics on one
+    // address would serialise at the memory side).  fb: all four predicates, exact.  fa: words 0/1
+    // are set when a GATHERED masked vector is non-zero / above threshold -- a certificate that fa
+    // is not zero; a clear word means "not observed" and is confirmed by ofl_flow_stats_dev.
+    const bool c[6] = { st.amax_m > 0.0f, st.amax_m >= a.th, st.bmax_m > 0.0f, st.bmax_m >= a.th,
+                        st.bmax > 0.0f, st.bmax >= a.th };
+    const int  slot[6] = { 0, 1, 4, 5, 6, 7 };
+    uint32_t *s = a.stats + (size_t)b * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const bool any = __ballot(c[k]) != 0ull;
+        if (any && (threadIdx.x & 63) == 0 &&
+            __hip_atomic_load(s + slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            s[slot[k]] = 1u;
+    }
+}
+
+// One tile: taps from the already loaded stream data, gather, blend, store.
+template <int QUANT, bool STATS>
+__device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Stream &in, C3Stat &st)
+{
+    int b, y, xg[2];
+    c3_tile_coords(a, tile, b, y, xg);
+    const int H = a.H, W = a.W, sign = a.sign;
+    const size_t field = (size_t)b * H * W;
+    const float   *fa = a.fa + field * 2;
+    const uint8_t *ma = a.ma + field;
+    const bool act[2] = { y < H && xg[0] < W, y < H && xg[1] < W };
+    const size_t row = field + (size_t)y * W;
+
+    const float bu[kC3Px] = { in.v[0].x, in.v[0].z, in.v[1].x, in.v[1].z };
+    const float bv[kC3Px] = { in.v[0].y, in.v[0].w, in.v[1].y, in.v[1].w };
+    const bool  bm[kC3Px] = { (in.m[0] & 0xffu) != 0, (in.m[0] & 0xff00u) != 0,
+                              (in.m[1] & 0xffu) != 0, (in.m[1] & 0xff00u) != 0 };
+
+    C3Pos tp[kC3Px];
+    bool inside = true, outside = true;
+#pragma unroll
+    for (int j = 0; j < kC3Px; ++j) {
+        tp[j] = c3_pos<QUANT>(xg[j >> 1] + (j & 1), y, bu[j], bv[j], sign);
+        const bool in_j  = (unsigned)tp[j].ix <= (unsigned)(W - 2) && (unsigned)tp[j].iy <= (unsigned)(H - 2);
+        const bool out_j = tp[j].ix < -1 || tp[j].ix >= W || tp[j].iy < -1 || tp[j].iy >= H;
+        inside  = inside && (in_j || !act[j >> 1]);
+        outside = outside && (out_j || !act[j >> 1]);
+    }
+    if (H < 2) inside = false;
+    if (a.ablate & 1) outside = true;
+
+    float su[kC3Px], sv[kC3Px];
+    bool  ok[kC3Px];
+#pragma unroll
+    for (int j = 0; j < kC3Px; ++j) { su[j] = 0.0f; sv[j] = 0.0f; ok[j] = false; }
+
+    if (__all(outside)) {
+        // every tap of every pixel of this wave lies outside the source: B(.) = 0, nothing to fetch
+    } else if (__all(inside)) {
+        // interior fast path: all four taps in bounds, no clamping and no selects
+        Pair2    p0[kC3Px], p1[kC3Px];
+        uint32_t m0[kC3Px], m1[kC3Px];
+#pragma unroll
+        for (int j = 0; j < kC3Px; ++j) {
+            const size_t s0 = act[j >> 1] ? (size_t)tp[j].iy * W + tp[j].ix : 0;
+            p0[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
+            p1[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * (s0 + W));
+            m0[j] = (uint32_t)ma[s0] | ((uint32_t)ma[s0 + 1] << 8);
+            m1[j] = (uint32_t)ma[s0 + W] | ((uint32_t)ma[s0 + W + 1] << 8);
+        }
+#pragma unroll
+        for (int j = 0; j < kC3Px; ++j) {
+            const C3Tap w = c3_weights<QUANT>(tp[j]);
+            su[j] = c3_blend(p0[j].lo_u, p0[j].hi_u, p1[j].lo_u, p1[j].hi_u, w);
+            sv[j] = c3_blend(p0[j].lo_v, p0[j].hi_v, p1[j].lo_v, p1[j].hi_v, w);
+            const bool m00 = (m0[j] & 0xffu) != 0, m01 = (m0[j] & 0xff00u) != 0;
+            const bool m10 = (m1[j] & 0xffu) != 0, m11 = (m1[j] & 0xff00u) != 0;
+            ok[j] = c3_valid<QUANT>(m00, m01, m10, m11, w);
+            if (STATS) st.amax_m = fmaxf(st.amax_m, (m00 && act[j >> 1]) ? fmaxf(fabsf(p0[j].lo_u), fabsf(p0[j].lo_v)) : 0.0f);
+        }
+    } else {
+        // border path: clamp the addresses, zero the taps that fall outside (cv2 BORDER_CONSTANT 0)
+#pragma unroll
+        for (int j = 0; j < kC3Px; ++j) {
+            const int  ixc = min(max(tp[j].ix, 0), max(W - 2, 0));
+            const int  d   = tp[j].ix - ixc;
+            const bool r0  = (unsigned)tp[j].iy < (unsigned)H;
+            const bool r1  = (unsigned)(tp[j].iy + 1) < (unsigned)H;
+            const int  y0c = min(max(tp[j].iy, 0), H - 1);
+            const int  y1c = min(max(tp[j].iy + 1, 0), H - 1);
+            const size_t s0 = (size_t)y0c * W + ixc, s1 = (size_t)y1c * W + ixc;
+            const Pair2 p0 = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
+            const Pair2 p1 = *reinterpret_cast<const Pair2 *>(fa + 2 * s1);
+            const uint32_t q00 = ma[s0], q01 = ma[s0 + 1], q10 = ma[s1], q11 = ma[s1 + 1];
+            float u00, v00, u01, v01, u10, v10, u11, v11, a00, a01, a10, a11;
+            select_pair(p0, d, r0, u00, v00, u01, v01);
+            select_pair(p1, d, r1, u10, v10, u11, v11);
+            select_mask(q00, q01, d, r0, a00, a01);
+            select_mask(q10, q11, d, r1, a10, a11);
+            const C3Tap w = c3_weights<QUANT>(tp[j]);
+            su[j] = c3_blend(u00, u01, u10, u11, w);
+            sv[j] = c3_blend(v00, v01, v10, v11, w);
+            ok[j] = c3_valid<QUANT>(a00 != 0.0f, a01 != 0.0f, a10 != 0.0f, a11 != 0.0f, w);
+            if (STATS) st.amax_m = fmaxf(st.amax_m, (a00 != 0.0f && act[j >> 1]) ? fmaxf(fabsf(u00), fabsf(v00)) : 0.0f);
+        }
+    }
+
+    // ---- stream out: out = fb + B(fa), mout = mb & valid   (flow_class.py:332-334, 668, 680)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (act[g] && !((a.ablate & 2) && su[2 * g] != 12345.0f)) {
+            const int j = 2 * g;
+            const float4 o4 = make_float4(__fadd_rn(bu[j], su[j]), __fadd_rn(bv[j], sv[j]),
+                                          __fadd_rn(bu[j + 1], su[j + 1]), __fadd_rn(bv[j + 1], sv[j + 1]));
+            const uint16_t mo = (uint16_t)(((ok[j] && bm[j]) ? 1u : 0u) | ((ok[j + 1] && bm[j + 1]) ? 0x100u : 0u));
+            if (OFL_C3_NT & 1) {
+                const v4f t = { o4.x, o4.y, o4.z, o4.w };
+                __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(a.out + 2 * (row + xg[g])));
+                __builtin_nontemporal_store(mo, reinterpret_cast<uint16_t *>(a.mout + row + xg[g]));
+            } else {
+                *reinterpret_cast<float4 *>(a.out + 2 * (row + xg[g])) = o4;
+                *reinterpret_cast<uint16_t *>(a.mout + row + xg[g]) = mo;
+            }
+            if (STATS) {
+                const float a0 = fmaxf(fabsf(bu[j]), fabsf(bv[j])), a1 = fmaxf(fabsf(bu[j + 1]), fabsf(bv[j + 1]));
+                st.bmax   = fmaxf(st.bmax, fmaxf(a0, a1));
+                st.bmax_m = fmaxf(st.bmax_m, fmaxf(bm[j] ? a0 : 0.0f, bm[j + 1] ? a1 : 0.0f));
+            }
+        }
+    }
+}
+
+// Persistent form: gridDim.x workgroups (a multiple of 8, sized to the chip's residency) walk the tile
+// list with stride gridDim.x.  The stream loads of the NEXT tile are issued before the gathers of the
+// current one are consumed, which takes the fb round trip out of every tile's dependency chain
+// (load fb -> addresses -> gather -> store), and the launch pays one ramp-up / tail instead of one per
+// resident-set of workgroups.  At every step the workgroups of one XCD (blockIdx % 8) own a contiguous
+// run of tiles, so neighbouring tiles share gather halos in that XCD's L2.
+template <int QUANT, bool STATS>
+__global__ __launch_bounds__(256)
+void compose3_kernel(const C3Args a)
+{
+    const int nb  = gridDim.x;
+    const int per = nb >> 3;
+    const int lane_tile = (nb & 7) == 0 ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    int tile = lane_tile;
+    if (tile >= a.ntiles) return;
+    C3Stat st = { 0.0f, 0.0f, 0.0f };
+    int cur_b = tile / a.tiles_per_field;
+    C3Stream in = c3_load_stream(a, tile);
+    while (true) {
+        const int next = tile + nb;
+        const bool more = next < a.ntiles;
+        C3Stream nxt;
+        if (more) nxt = c3_load_stream(a, next);          // prefetch: in flight during this tile's gather
+        c3_tile<QUANT, STATS>(a, tile, in, st);
+        if (!more) break;
+        if (STATS) {
+            const int nb_ = next / a.tiles_per_field;
+            if (nb_ != cur_b) {
+                c3_flush_stats(a, cur_b, st);
+                st.amax_m = st.bmax = st.bmax_m = 0.0f;
+                cur_b = nb_;
+            }
+        }
+        in = nxt;
+        tile = next;
+    }
+    if (STATS) c3_flush_stats(a, cur_b, st);
 }
 
 // Generic-shape fallback (any W >= 1, one pixel per thread, no vector accesses).
@@ -312,6 +524,28 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
     return OFL_OK;
 }
 
+// resident workgroups per CU of each compose3 instantiation (queried once per process)
+int c3_blocks_per_cu(int quant, bool with_stats)
+{
+    static int cache[2][2] = { { 0, 0 }, { 0, 0 } };
+    int &v = cache[quant == OFL_QUANT_OPENCV ? 0 : 1][with_stats ? 1 : 0];
+    if (v == 0) {
+        int n = 0;
+        hipError_t e;
+        if (quant == OFL_QUANT_OPENCV)
+            e = with_stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_OPENCV, true>, 256, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_OPENCV, false>, 256, 0);
+        else
+            e = with_stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_EXACT, true>, 256, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_EXACT, false>, 256, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); n = 4; }
+        const char *env = getenv("OFL_C3_BLOCKS_PER_CU");      // tuning knob
+        if (env && atoi(env) > 0) n = atoi(env);
+        v = n < 1 ? 1 : (n > 8 ? 8 : n);
+    }
+    return v;
+}
+
 size_t dtype_size(int dtype)
 {
     switch (dtype) {
@@ -359,14 +593,18 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
     hipStream_t s = stream_of(stream);
     const float th = 1e-3f;   // DEFAULT_THRESHOLD, utils.py:22 (compared in float32)
 
-    if (W % kPx == 0 && W >= 2) {
-        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
-        const long long nb = (long long)tiles_x * tiles_y * batch;
-        if (nb > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
-        const int nblocks = (int)nb, tpf = tiles_x * tiles_y;
-#define OFL_C3(Q, S)                                                                                    \
-        hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(nblocks), dim3(256), 0, s, fa, ma, fb, mb, sign, \
-                           H, W, tiles_x, tpf, nblocks, out, mout, stats, th)
+    if (W % 2 == 0) {
+        const int tiles_x = (W + kC3TileW - 1) / kC3TileW, tiles_y = (H + kC3TileH - 1) / kC3TileH;
+        const long long nt = (long long)tiles_x * tiles_y * batch;
+        if (nt > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
+        static const int ablate = getenv("OFL_C3_ABLATE") ? atoi(getenv("OFL_C3_ABLATE")) : 0;
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, ablate };
+        // persistent grid: what the chip keeps resident (a multiple of 8 = one share per XCD), or one
+        // workgroup per tile when the problem is smaller than that
+        int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr);
+        if (grid > (int)nt) grid = (int)nt;
+        if (grid >= 8) grid &= ~7;
+#define OFL_C3(Q, S) hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a)
         if (quant == OFL_QUANT_OPENCV) { if (stats) OFL_C3(OFL_QUANT_OPENCV, true); else OFL_C3(OFL_QUANT_OPENCV, false); }
         else                           { if (stats) OFL_C3(OFL_QUANT_EXACT, true);  else OFL_C3(OFL_QUANT_EXACT, false); }
 #undef OFL_C3
@@ -404,16 +642,22 @@ int ofl_compose3(const float *fa, const uint8_t *ma, const float *fb, const uint
     OFL_HIP(hipMemsetAsync(dst.p, 0, (size_t)batch * 8 * 4, s));
     OFL_TRY(ofl_compose3_dev((const float *)dfa.p, (const uint8_t *)dma.p, (const float *)dfb.p,
                              (const uint8_t *)dmb.p, sign, H, W, batch, (float *)dout.p, (uint8_t *)dmout.p,
-                             stats_host ? (uint32_t *)dst.p : nullptr, quant, s));
+                             nullptr, quant, s));
     OFL_HIP(hipMemcpyAsync(out, dout.p, n * 8, hipMemcpyDeviceToHost, s));
     OFL_HIP(hipMemcpyAsync(mout, dmout.p, n, hipMemcpyDeviceToHost, s));
-    uint32_t words[8];
+    // exact predicates for the host caller: one pass of the statistics kernel per field (the fused
+    // launch above only certifies "fa is not zero" from the vectors it happened to gather)
     for (int b = 0; stats_host && b < batch; ++b) {
-        OFL_HIP(hipMemcpyAsync(words, (uint32_t *)dst.p + (size_t)b * 8, sizeof(words), hipMemcpyDeviceToHost, s));
-        OFL_HIP(hipStreamSynchronize(s));
-        uint32_t a = 0, bb = 0;
-        for (int k = 0; k < 4; ++k) { a |= words[k] ? (1u << k) : 0u; bb |= words[4 + k] ? (1u << k) : 0u; }
-        stats_host[2 * b] = a; stats_host[2 * b + 1] = bb;
+        const size_t hw = (size_t)H * W;
+        uint32_t bits[2] = { 0, 0 };
+        for (int k = 0; k < 2; ++k) {
+            const float *f = (const float *)(k == 0 ? dfa.p : dfb.p) + (size_t)b * hw * 2;
+            const uint8_t *m = (const uint8_t *)(k == 0 ? dma.p : dmb.p) + (size_t)b * hw;
+            OFL_TRY(ofl_flow_stats_dev(f, m, hw, 1e-3f, (uint32_t *)dst.p, s));
+            OFL_HIP(hipMemcpyAsync(&bits[k], dst.p, 4, hipMemcpyDeviceToHost, s));
+            OFL_HIP(hipStreamSynchronize(s));
+        }
+        stats_host[2 * b] = bits[0] & 15u; stats_host[2 * b + 1] = bits[1] & 15u;
     }
     OFL_HIP(hipStreamSynchronize(s));
     return OFL_OK;

@@ -340,18 +340,25 @@ class DeviceFlow:
         need = fa._stats is None or fb._stats is None
         words = DeviceBuffer.zeros(32) if need else None
         compose3_launch(fa, fb, sign, out, words, quant=quant)
+        cert_a = 0
         if need:
-            sa, sb = _fold_stat_words(words.to_host((8,), np.uint32))
-            # the fused launch does not look for NaN/Inf: flows are validated finite at upload
-            fa._stats = sa if fa._stats is None else fa._stats
-            fb._stats = sb if fb._stats is None else fb._stats
-        if self.is_zero(thresholded=thresholded):
+            w = words.to_host((8,), np.uint32)
+            if fb._stats is None:                       # exact predicates of the streamed field
+                fb._stats = sum((1 << k) for k in range(4) if w[4 + k])
+            cert_a = (1 if w[0] else 0) | (2 if w[1] else 0)   # certificates "fa is not zero"
+        bit = nat.STAT_NONZERO_TH_MASKED if thresholded else nat.STAT_NONZERO_MASKED
+        if fa._stats is None and not (cert_a & bit):
+            fa.stats()                                  # not certified by the gather: exact pass (K4)
+        a_zero = fa.is_zero(thresholded=thresholded) if fa._stats is not None else False
+        b_zero = fb.is_zero(thresholded=thresholded)
+        self_zero, flow_zero = (b_zero, a_zero) if self.ref == 's' else (a_zero, b_zero)
+        if self_zero:
             return flow
-        if flow.is_zero(thresholded=thresholded):
+        if flow_zero:
             return self
         if fb.is_zero(thresholded=True, masked=False):
             # apply_flow returned the target untouched (utils.py:215-216): plain vector sum
-            return fb + fa if self.ref == 't' else fb + fa
+            return fb + fa
         return out
 
     def _resample_to(self, flow3):

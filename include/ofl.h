@@ -163,23 +163,40 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
                  size_t n_px, float *out, uint8_t *mout, void *stream);
 
 /* ------------------------------------------------------------------ K3: scattered -> regular grid
- * Replaces apply_flow(flow, target, 's', mask) utils.py:237-258 (scipy.interpolate.griddata
- * 'linear', NaN -> 0) and the inline griddata of mode 2 / ref 't' flow_class.py:1398-1410.
- * Source point i sits at (x, y) + sign*flow[i] and carries vals[i][0..C) (float32); points with
- * pmask[i] == 0 are dropped (pmask NULL = keep all).  Output: out[H][W][C] float32 interpolated
- * piecewise-linearly on the triangulated warped grid, 0 where no triangle covers the pixel and
- * the pixel is outside the convex hull of the kept points; `covered` (uint8 [H][W] or NULL) is 1
- * where a value was produced.  query == NULL evaluates at the regular grid nodes; otherwise
- * query [H][W][2] holds absolute (x, y) positions (mode 2 't').
+ * Replaces apply_flow(flow, target, 's', mask) utils.py:237-258 (scipy.interpolate.griddata 'linear',
+ * NaN -> 0) and the inline griddata of mode 2 / ref 't' flow_class.py:1398-1410.
+ * Source point i sits at (x, y) + sign*flow[i] -- evaluated in float64 (point_precision 0, utils.py:242)
+ * or rounded to float32 first (point_precision 1, flow_class.py:1398-1400) -- and carries
+ * vals[i][0..C) (float32) plus, optionally, a mask value vmask[i]; points with pmask[i] == 0 are
+ * dropped (pmask NULL = keep all, utils.py:249-251).  The warped grid cells are split into triangles
+ * along their Delaunay diagonal and scan-converted:
+ *     out[H][W][C]  piecewise-linear interpolation (float64 barycentric, stored as float32),
+ *                   0 where no triangle covers the node;
+ *     valid[H][W]   valid_rule 0: float32(interpolated vmask) == 1   (flow_class.py:668)
+ *                   valid_rule 1: interpolated vmask > 0.99           (flow_class.py:1410)
+ *                   (vmask NULL = all ones, i.e. valid == "covered by a triangle").
+ * query == NULL evaluates at the regular grid nodes; otherwise query [H][W][2] holds absolute (x, y)
+ * positions (mode 2 't').  C may be 0 (validity only).  `workspace` (device) must hold
+ * ofl_scatter_workspace_bytes() bytes.  info_host (host uint64[3] or NULL): [0] kept points, [1] number
+ * of large triangles, [2] their bounding-box nodes; passing it synchronises and enables the checks
+ * that need the counts: OFL_E_NOPOINTS when no point is kept (qhull's "No points given").
+ * Known deviation from SciPy: holes left by dropped points are not re-triangulated.
  */
-int ofl_scatter_linear_dev(const float *flow, int sign, const uint8_t *pmask,
-                           const float *vals, int C, int H, int W,
-                           const float *query, float *out, uint8_t *covered,
-                           void *workspace, size_t workspace_bytes, void *stream);
+int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                           const float *vals, int C, const uint8_t *vmask, int H, int W,
+                           const float *query, float *out, uint8_t *valid, int valid_rule,
+                           void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
 int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes);
-int ofl_scatter_linear(const float *flow, int sign, const uint8_t *pmask,
-                       const float *vals, int C, int H, int W,
-                       const float *query, float *out, uint8_t *covered);
+int ofl_scatter_linear(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                       const float *vals, int C, const uint8_t *vmask, int H, int W,
+                       const float *query, float *out, uint8_t *valid, int valid_rule);
+
+/* small device helpers of the flow algebra:
+ *   ofl_mask_and_dev     out = a & b                      (flow_class.py:643)
+ *   ofl_grid_offset_dev  out[y][x] = float32((x, y) + sign * vecs[y][x])   (flow_class.py:1398-1406)
+ */
+int ofl_mask_and_dev(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, void *stream);
+int ofl_grid_offset_dev(const float *vecs, int sign, int H, int W, float *out, void *stream);
 
 /* ------------------------------------------------------------------ C1: shared-source broadcast (RCCL)
  * The only exchange step of the sharded workload: one broadcast of a shared source image / flow

@@ -66,9 +66,11 @@ SIGNATURES = {
     "ofl_flow_stats_dev": (_ci, [_vp, _vp, _cs, _cf, _vp, _vp]),
     "ofl_flow_stats": (_ci, [_vp, _vp, _cs, _cf, _vp]),
     "ofl_axpy_dev": (_ci, [_vp, _vp, _vp, _vp, _cf, _cs, _vp, _vp, _vp]),
-    "ofl_scatter_linear_dev": (_ci, [_vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _cs, _vp]),
+    "ofl_scatter_linear_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_workspace_bytes": (_ci, [_ci, _ci, _ci, ctypes.POINTER(_cs)]),
-    "ofl_scatter_linear": (_ci, [_vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _vp, _vp]),
+    "ofl_scatter_linear": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci]),
+    "ofl_mask_and_dev": (_ci, [_vp, _vp, _vp, _cs, _vp]),
+    "ofl_grid_offset_dev": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
     "ofl_comm_unique_id": (_ci, [_vp]),
     "ofl_comm_init": (_ci, [_vp, _ci, _ci]),
     "ofl_comm_broadcast": (_ci, [_vp, _cs, _ci, _vp]),

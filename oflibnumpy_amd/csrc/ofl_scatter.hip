@@ -1,21 +1,568 @@
-// ofl_scatter.hip -- K3 scattered -> regular grid interpolation (placeholder until the kernel lands).
+// ofl_scatter.hip -- K3: scattered -> regular-grid linear interpolation for gfx950.
+//
+// Replaces scipy.interpolate.griddata(points, values, grid, 'linear') as the reference uses it
+// (src/oflibnumpy/utils.py:237-258; flow_class.py:1398-1410): the scattered points are the regular
+// grid displaced by a flow, so their connectivity is known -- every source cell (x, y)-(x+1, y+1)
+// becomes two triangles, split along the diagonal the Delaunay criterion picks for that cell
+// (in-circle test in float64 on exactly the positions SciPy sees).  For flows whose cells stay close
+// to similar (rotation / uniform scaling / translation + small deformation) this IS the Delaunay
+// triangulation SciPy builds, without Qhull's O(N log N) serial construction.
+//
+//   pass 1 (raster)   one thread per source cell: both triangles are scan-converted over the integer
+//                     nodes of their bounding boxes; a node inside (barycentric >= -eps, eps as in
+//                     SciPy's _barycentric_inside) records the triangle id with atomicMin -> a
+//                     deterministic owner per output node, no value races.  Triangles whose bounding
+//                     box is large go to a list that pass 1b scans with one wave per triangle.
+//   pass 2 (resolve)  one thread per output node (or per query point): barycentric coordinates in
+//                     float64 from the owner triangle, values and mask interpolated, 0 where no
+//                     triangle covers the node (NaN -> 0 of utils.py:254).
+//
+// Memory traffic: flow 8 B + point mask 1 B per cell corner (neighbouring cells share lines), one
+// 4-byte atomic per covered node, then 4 + 3 * (8 + 4 C) gathered bytes and 4 C + 1 written bytes per
+// node -- all L2-friendly because owner triangles of neighbouring nodes are neighbours in memory.
 #include "ofl_common.h"
+#include <algorithm>
+#include <vector>
+
 using namespace ofl;
+
+namespace {
+
+constexpr uint32_t kNoOwner   = 0xFFFFFFFFu;
+constexpr double   kEps       = 100.0 * 2.220446049250313e-16;   // scipy _qhull: eps = 100 * DBL_EPSILON
+constexpr int      kSmallArea = 1024;                             // bbox nodes a single thread scans itself
+constexpr int      kBigCap    = 1 << 20;                          // capacity of the big-triangle list
+constexpr int      kCandCap   = 1 << 22;                          // hull candidates kept on the device
+constexpr int      kHullCap   = 1 << 16;                          // vertices per hull chain
+constexpr int      kFillRadius = 16;                              // how far an uncovered node looks for a covered one
+constexpr double   kHullTol   = 1e-12;                            // distance (px) a node may lie outside a hull edge
+
+struct D2 { double x, y; };
+
+struct ScatterWs {          // layout of the caller-provided workspace
+    uint32_t *owner;        // [H][W]
+    uint32_t *big;          // [kBigCap] triangle ids
+    D2       *cand;         // [cand_cap] positions of mesh-boundary points (convex-hull candidates)
+    D2       *lower;        // [kHullCap] lower hull chain, x ascending
+    D2       *upper;        // [kHullCap] upper hull chain, x ascending
+    unsigned long long *counters;   // [0] kept points, [1] big-list length, [2] big-list work, [3] candidates
+    int       cand_cap;
+};
+
+struct HullRef { const D2 *lower, *upper; int n_lower, n_upper; };
+
+// `sign` carries the point precision in bit 1 of its magnitude: +-1 = float64 positions (utils.py:242),
+// +-2 = positions rounded to float32 first (flow_class.py:1398-1400 builds them in a float32 array).
+__device__ __forceinline__ D2 point_of(const float *flow, int sign, int W, int x, int y)
+{
+    const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)y * W + x) * 2);
+    D2 p;
+    p.x = sign >= 0 ? (double)x + (double)f.x : (double)x - (double)f.x;
+    p.y = sign >= 0 ? (double)y + (double)f.y : (double)y - (double)f.y;
+    if (sign == 2 || sign == -2) { p.x = (double)(float)p.x; p.y = (double)(float)p.y; }
+    return p;
+}
+
+__device__ __forceinline__ double cross2(const D2 &o, const D2 &a, const D2 &b)
+{
+    return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x);
+}
+
+// > 0 when d lies inside the circumcircle of the counter-clockwise triangle (a, b, c)
+__device__ __forceinline__ double incircle(const D2 &a, const D2 &b, const D2 &c, const D2 &d)
+{
+    const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    const double a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+    return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx);
+}
+
+// Which diagonal splits the warped cell a=P(x,y), b=P(x+1,y), c=P(x+1,y+1), d=P(x,y+1):
+// returns 0 for a-c, 1 for b-d.
+__device__ __forceinline__ int pick_diagonal(const D2 &a, const D2 &b, const D2 &c, const D2 &d)
+{
+    const double o_abc = cross2(a, b, c), o_acd = cross2(a, c, d);
+    const double o_bcd = cross2(b, c, d), o_bda = cross2(b, d, a);
+    const bool ac_ok = (o_abc > 0) == (o_acd > 0) && o_abc != 0 && o_acd != 0;   // both halves same orientation
+    const bool bd_ok = (o_bcd > 0) == (o_bda > 0) && o_bcd != 0 && o_bda != 0;
+    if (ac_ok && !bd_ok) return 0;
+    if (bd_ok && !ac_ok) return 1;
+    if (!ac_ok && !bd_ok) return 0;                 // folded cell: the reference is arbitrary here too
+    double ic = incircle(a, b, c, d);               // convex cell: Delaunay criterion
+    if (o_abc < 0) ic = -ic;
+    return ic > 0 ? 1 : 0;                          // d inside circle(a, b, c) -> a-c is illegal
+}
+
+// vertices of triangle t (0/1) of a cell split along `diag`; indices into {a, b, c, d}
+__device__ __forceinline__ void tri_corners(int diag, int t, int &i0, int &i1, int &i2)
+{
+    if (diag == 0) { if (t == 0) { i0 = 0; i1 = 1; i2 = 2; } else { i0 = 0; i1 = 2; i2 = 3; } }
+    else           { if (t == 0) { i0 = 1; i1 = 2; i2 = 3; } else { i0 = 1; i1 = 3; i2 = 0; } }
+}
+
+__device__ __forceinline__ bool bary(const D2 &p0, const D2 &p1, const D2 &p2, double gx, double gy,
+                                     double &c0, double &c1, double &c2)
+{
+    const double e1x = p1.x - p0.x, e1y = p1.y - p0.y, e2x = p2.x - p0.x, e2y = p2.y - p0.y;
+    const double det = e1x * e2y - e1y * e2x;
+    if (det == 0.0) return false;
+    const double dx = gx - p0.x, dy = gy - p0.y;
+    c1 = (dx * e2y - dy * e2x) / det;
+    c2 = (e1x * dy - e1y * dx) / det;
+    c0 = 1.0 - c1 - c2;
+    return c0 >= -kEps && c0 <= 1.0 + kEps && c1 >= -kEps && c1 <= 1.0 + kEps && c2 >= -kEps && c2 <= 1.0 + kEps;
+}
+
+struct TriBox { int x0, x1, y0, y1; };
+
+__device__ __forceinline__ TriBox tri_box(const D2 &p0, const D2 &p1, const D2 &p2, int W, int H)
+{
+    const double xmin = fmin(p0.x, fmin(p1.x, p2.x)), xmax = fmax(p0.x, fmax(p1.x, p2.x));
+    const double ymin = fmin(p0.y, fmin(p1.y, p2.y)), ymax = fmax(p0.y, fmax(p1.y, p2.y));
+    TriBox b;
+    // clamp in double first: positions may be astronomically large
+    b.x0 = (int)fmax(ceil(xmin - 1e-9), 0.0);
+    b.y0 = (int)fmax(ceil(ymin - 1e-9), 0.0);
+    b.x1 = (int)fmin(floor(xmax + 1e-9), (double)(W - 1));
+    b.y1 = (int)fmin(floor(ymax + 1e-9), (double)(H - 1));
+    if (!(xmax >= -1.0) || !(ymax >= -1.0)) { b.x1 = -1; b.y1 = -1; }
+    return b;
+}
+
+__device__ __forceinline__ uint32_t tri_id(uint32_t cell, int diag, int t) { return (cell << 2) | ((uint32_t)diag << 1) | (uint32_t)t; }
+
+__global__ __launch_bounds__(256)
+void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
+                           int H, int W, ScatterWs ws)
+{
+    const int cw = W - 1, ch = H - 1;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (pmask) {   // count the points SciPy would receive (utils.py:249-251): one thread per point
+        unsigned long long kept = 0;
+        // cells cover (W-1) x (H-1); points on the last row / column are counted by the edge threads
+        if (x < W && y < H) {
+            kept += pmask[(size_t)y * W + x] != 0;
+        }
+        const unsigned long long wave_sum = __popcll(__ballot(kept != 0));
+        if ((threadIdx.x & 63) == 0 && wave_sum) atomicAdd(&ws.counters[0], wave_sum);
+    }
+    if (x >= cw || y >= ch) return;
+    const size_t i00 = (size_t)y * W + x;
+    bool keep[4] = { true, true, true, true };
+    if (pmask) {
+        keep[0] = pmask[i00] != 0; keep[1] = pmask[i00 + 1] != 0;
+        keep[2] = pmask[i00 + W + 1] != 0; keep[3] = pmask[i00 + W] != 0;
+    }
+    const int n_keep = keep[0] + keep[1] + keep[2] + keep[3];
+    if (n_keep < 3) return;
+    D2 p[4] = { point_of(flow, sign, W, x, y), point_of(flow, sign, W, x + 1, y),
+                point_of(flow, sign, W, x + 1, y + 1), point_of(flow, sign, W, x, y + 1) };
+    int diag;
+    if (n_keep == 4) diag = pick_diagonal(p[0], p[1], p[2], p[3]);
+    else diag = (!keep[0] || !keep[2]) ? 1 : 0;     // the only diagonal that leaves a fully kept triangle
+    const uint32_t cell = (uint32_t)(y * cw + x);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int i0, i1, i2;
+        tri_corners(diag, t, i0, i1, i2);
+        if (!(keep[i0] && keep[i1] && keep[i2])) continue;
+        const TriBox b = tri_box(p[i0], p[i1], p[i2], W, H);
+        if (b.x1 < b.x0 || b.y1 < b.y0) continue;
+        const uint32_t id = tri_id(cell, diag, t);
+        const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
+        if (area > kSmallArea) {
+            const unsigned long long slot = atomicAdd(&ws.counters[1], 1ull);
+            atomicAdd(&ws.counters[2], (unsigned long long)area);
+            if (slot < (unsigned long long)kBigCap) ws.big[slot] = id;
+            continue;
+        }
+        for (int gy = b.y0; gy <= b.y1; ++gy)
+            for (int gx = b.x0; gx <= b.x1; ++gx) {
+                double c0, c1, c2;
+                if (bary(p[i0], p[i1], p[i2], (double)gx, (double)gy, c0, c1, c2))
+                    atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+            }
+    }
+}
+
+// Convex-hull candidates: kept points that sit on the border of the kept mesh (a neighbour is missing)
+// or next to a cell that is not properly oriented (folded mesh).  Every vertex of the convex hull of
+// the kept points is among them; interior points of a properly embedded mesh never are.
+__global__ __launch_bounds__(256)
+void scatter_boundary_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
+                             int H, int W, ScatterWs ws)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    if (pmask && !pmask[(size_t)y * W + x]) return;
+    bool cand = (x == 0 || y == 0 || x == W - 1 || y == H - 1);
+    if (!cand && pmask) {
+        for (int dy = -1; dy <= 1 && !cand; ++dy)
+            for (int dx = -1; dx <= 1 && !cand; ++dx)
+                cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
+    }
+    if (!cand) {    // all eight neighbours exist: look for folded incident cells
+        for (int cy = y - 1; cy <= y && !cand; ++cy)
+            for (int cx = x - 1; cx <= x && !cand; ++cx) {
+                const D2 a = point_of(flow, sign, W, cx, cy), b = point_of(flow, sign, W, cx + 1, cy);
+                const D2 c = point_of(flow, sign, W, cx + 1, cy + 1), d = point_of(flow, sign, W, cx, cy + 1);
+                cand = !(cross2(a, b, c) > 0 && cross2(a, c, d) > 0 && cross2(b, c, d) > 0 && cross2(b, d, a) > 0);
+            }
+    }
+    if (cand) {
+        const unsigned long long slot = atomicAdd(&ws.counters[3], 1ull);
+        if (slot < (unsigned long long)ws.cand_cap) ws.cand[slot] = point_of(flow, sign, W, x, y);
+    }
+}
+
+// y-range of a convex polygon at abscissa qx from one of its x-monotone chains (binary search)
+__device__ __forceinline__ bool chain_y(const D2 *ch, int n, double qx, double &yq, double &slack)
+{
+    if (n <= 0 || qx < ch[0].x || qx > ch[n - 1].x) return false;
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ch[mid].x <= qx) lo = mid; else hi = mid;
+    }
+    const D2 a = ch[lo], b = ch[hi];
+    const double dx = b.x - a.x, dy = b.y - a.y;
+    if (dx <= 0.0) { yq = a.y; slack = kHullTol; return true; }
+    yq = a.y + dy * ((qx - a.x) / dx);
+    slack = kHullTol * sqrt(1.0 + (dy / dx) * (dy / dx));     // tolerance measured perpendicular to the edge
+    return true;
+}
+
+__device__ __forceinline__ bool inside_hull(const HullRef &h, double qx, double qy)
+{
+    double ylo, yhi, s0, s1;
+    if (!chain_y(h.lower, h.n_lower, qx, ylo, s0) || !chain_y(h.upper, h.n_upper, qx, yhi, s1)) return false;
+    // at the extreme abscissae the chains end in vertical hull edges
+    if (qx == h.lower[0].x) { ylo = fmin(ylo, h.lower[0].y); yhi = fmax(yhi, h.upper[0].y); }
+    if (qx == h.lower[h.n_lower - 1].x) { ylo = fmin(ylo, h.lower[h.n_lower - 1].y); yhi = fmax(yhi, h.upper[h.n_upper - 1].y); }
+    return qy >= ylo - s0 && qy <= yhi + s1;
+}
+
+// nearest covered grid node around (cx, cy): rings of growing Chebyshev radius, ties to the smallest
+// Euclidean distance then the smallest owner id (deterministic)
+__device__ __forceinline__ uint32_t nearest_owner(const uint32_t *owner, int H, int W, int cx, int cy, double qx, double qy)
+{
+    for (int r = 0; r <= kFillRadius; ++r) {
+        uint32_t best = kNoOwner;
+        double bestd = 1e300;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= H) continue;
+            const int step = (dy == -r || dy == r) ? 1 : 2 * r;
+            for (int dx = -r; dx <= r; dx += (step > 0 ? step : 1)) {
+                const int xx = cx + dx;
+                if (xx < 0 || xx >= W) continue;
+                const uint32_t id = owner[(size_t)yy * W + xx];
+                if (id == kNoOwner) continue;
+                const double d = (xx - qx) * (xx - qx) + (yy - qy) * (yy - qy);
+                if (d < bestd || (d == bestd && id < best)) { bestd = d; best = id; }
+            }
+        }
+        if (best != kNoOwner) return best;
+    }
+    return kNoOwner;
+}
+
+// decode a triangle id into its three source vertices (linear pixel indices) and positions
+__device__ __forceinline__ void tri_decode(uint32_t id, const float *flow, int sign, int W,
+                                           size_t (&vi)[3], D2 (&vp)[3])
+{
+    const int cw = W - 1;
+    const uint32_t cell = id >> 2;
+    const int diag = (id >> 1) & 1, t = id & 1;
+    const int y = (int)(cell / (uint32_t)cw), x = (int)(cell - (uint32_t)y * (uint32_t)cw);
+    const int cx[4] = { x, x + 1, x + 1, x }, cy[4] = { y, y, y + 1, y + 1 };
+    int i[3];
+    tri_corners(diag, t, i[0], i[1], i[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vi[k] = (size_t)cy[i[k]] * W + cx[i[k]];
+        vp[k] = point_of(flow, sign, W, cx[i[k]], cy[i[k]]);
+    }
+}
+
+// pass 1b: one wave per large triangle, 64 nodes of the bounding box per step
+__global__ __launch_bounds__(256)
+void scatter_big_kernel(const float *__restrict__ flow, int sign, int H, int W, ScatterWs ws)
+{
+    unsigned long long n = ws.counters[1];
+    if (n > (unsigned long long)kBigCap) n = kBigCap;
+    const int lane = threadIdx.x & 63;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6); k < n;
+         k += (unsigned long long)gridDim.x * 4) {
+        const uint32_t id = ws.big[k];
+        size_t vi[3];
+        D2 vp[3];
+        tri_decode(id, flow, sign, W, vi, vp);
+        const TriBox b = tri_box(vp[0], vp[1], vp[2], W, H);
+        const long long bw = b.x1 - b.x0 + 1, area = bw * (b.y1 - b.y0 + 1);
+        for (long long j = lane; j < area; j += 64) {
+            const int gy = b.y0 + (int)(j / bw), gx = b.x0 + (int)(j % bw);
+            double c0, c1, c2;
+            if (bary(vp[0], vp[1], vp[2], (double)gx, (double)gy, c0, c1, c2))
+                atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+        }
+    }
+}
+
+// pass 2: interpolate.  query == NULL: node (x, y) itself; otherwise the triangle containing the
+// query point is searched in the 3 x 3 cells around the owner of the nearest node.
+__global__ __launch_bounds__(256)
+void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
+                            const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                            int H, int W, const float *__restrict__ query,
+                            float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, ScatterWs ws,
+                            HullRef hull)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const size_t o = (size_t)y * W + x;
+    double qx = x, qy = y;
+    uint32_t id = kNoOwner;
+    size_t vi[3];
+    D2 vp[3];
+    double c0 = 0, c1 = 0, c2 = 0;
+    bool found = false;
+    if (!query) {
+        id = ws.owner[o];
+        if (id != kNoOwner) {
+            tri_decode(id, flow, sign, W, vi, vp);
+            found = bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
+        }
+    } else {
+        const float2 q = *reinterpret_cast<const float2 *>(query + o * 2);
+        qx = (double)q.x; qy = (double)q.y;
+        // seed: owner of the nearest grid node (or one of its neighbours)
+        const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
+        uint32_t seed = kNoOwner;
+        if (qx >= -1.0 && qx <= (double)W && qy >= -1.0 && qy <= (double)H) {
+            for (int dy = 0; dy <= 1 && seed == kNoOwner; ++dy)
+                for (int dx = 0; dx <= 1 && seed == kNoOwner; ++dx) {
+                    const int sx = min(max(nx + (dx ? (qx < nx ? -1 : 1) : 0), 0), W - 1);
+                    const int sy = min(max(ny + (dy ? (qy < ny ? -1 : 1) : 0), 0), H - 1);
+                    seed = ws.owner[(size_t)sy * W + sx];
+                }
+        }
+        if (seed != kNoOwner) {
+            const int cw = W - 1, chh = H - 1;
+            const uint32_t cell = seed >> 2;
+            const int sy = (int)(cell / (uint32_t)cw), sx = (int)(cell - (uint32_t)sy * (uint32_t)cw);
+            for (int dy = -1; dy <= 1 && !found; ++dy)
+                for (int dx = -1; dx <= 1 && !found; ++dx) {
+                    const int cx = sx + dx, cy = sy + dy;
+                    if (cx < 0 || cy < 0 || cx >= cw || cy >= chh) continue;
+                    const size_t i00 = (size_t)cy * W + cx;
+                    bool keep[4] = { true, true, true, true };
+                    if (pmask) {
+                        keep[0] = pmask[i00] != 0; keep[1] = pmask[i00 + 1] != 0;
+                        keep[2] = pmask[i00 + W + 1] != 0; keep[3] = pmask[i00 + W] != 0;
+                    }
+                    const int n_keep = keep[0] + keep[1] + keep[2] + keep[3];
+                    if (n_keep < 3) continue;
+                    const D2 p[4] = { point_of(flow, sign, W, cx, cy), point_of(flow, sign, W, cx + 1, cy),
+                                      point_of(flow, sign, W, cx + 1, cy + 1), point_of(flow, sign, W, cx, cy + 1) };
+                    const int diag = n_keep == 4 ? pick_diagonal(p[0], p[1], p[2], p[3]) : ((!keep[0] || !keep[2]) ? 1 : 0);
+                    for (int t = 0; t < 2 && !found; ++t) {
+                        int i0, i1, i2;
+                        tri_corners(diag, t, i0, i1, i2);
+                        if (!(keep[i0] && keep[i1] && keep[i2])) continue;
+                        if (bary(p[i0], p[i1], p[i2], qx, qy, c0, c1, c2)) {
+                            found = true;
+                            id = tri_id((uint32_t)(cy * cw + cx), diag, t);
+                            tri_decode(id, flow, sign, W, vi, vp);
+                        }
+                    }
+                }
+        }
+    }
+    if (!found && hull.n_lower > 0 && inside_hull(hull, qx, qy)) {
+        // Inside the convex hull of the kept points but not covered by a cell triangle: SciPy's Delaunay
+        // triangulation spans such gaps (ragged / curved mesh borders, holes left by dropped points) with
+        // triangles between border vertices.  The linear function of the nearest cell triangle is
+        // continued instead -- identical for data that is affine across the gap.
+        const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
+        id = nearest_owner(ws.owner, H, W, nx, ny, qx, qy);
+        if (id != kNoOwner) {
+            tri_decode(id, flow, sign, W, vi, vp);
+            (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
+            const double e1x = vp[1].x - vp[0].x, e1y = vp[1].y - vp[0].y, e2x = vp[2].x - vp[0].x, e2y = vp[2].y - vp[0].y;
+            found = (e1x * e2y - e1y * e2x) != 0.0;
+        }
+    }
+    if (!found) {
+        for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;          // NaN -> 0, utils.py:254 / fill_value=0
+        if (valid) valid[o] = 0;
+        return;
+    }
+    for (int c = 0; c < C; ++c) {
+        const double v = c0 * (double)vals[vi[0] * C + c] + c1 * (double)vals[vi[1] * C + c] + c2 * (double)vals[vi[2] * C + c];
+        out[o * C + c] = (float)v;
+    }
+    if (valid) {
+        double m = 1.0;
+        if (vmask) m = c0 * (double)(vmask[vi[0]] != 0) + c1 * (double)(vmask[vi[1]] != 0) + c2 * (double)(vmask[vi[2]] != 0);
+        else       m = c0 + c1 + c2;
+        const float mf = (float)m;                                   // result.astype(target.dtype), utils.py:258
+        valid[o] = valid_rule == 0 ? (mf == 1.0f) : (m > 0.99);     // flow_class.py:668 / :1410
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int cand_cap_for(int H, int W)
+{
+    const long long n = (long long)H * W;
+    return (int)(n < kCandCap ? n : kCandCap);
+}
+
+ScatterWs carve(void *workspace, int H, int W)
+{
+    ScatterWs ws;
+    char *p = (char *)workspace;
+    ws.cand_cap = cand_cap_for(H, W);
+    ws.owner = (uint32_t *)p;            p += align_up((size_t)H * W * 4, 256);
+    ws.big = (uint32_t *)p;              p += align_up((size_t)kBigCap * 4, 256);
+    ws.cand = (D2 *)p;                   p += align_up((size_t)ws.cand_cap * sizeof(D2), 256);
+    ws.lower = (D2 *)p;                  p += align_up((size_t)kHullCap * sizeof(D2), 256);
+    ws.upper = (D2 *)p;                  p += align_up((size_t)kHullCap * sizeof(D2), 256);
+    ws.counters = (unsigned long long *)p;
+    return ws;
+}
+
+// Andrew's monotone chain on the host: lower and upper chains, both with x ascending and both
+// containing the two extreme-x end points.
+void convex_chains(std::vector<D2> &pts, std::vector<D2> &lower, std::vector<D2> &upper)
+{
+    std::sort(pts.begin(), pts.end(), [](const D2 &a, const D2 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+    auto cross = [](const D2 &o, const D2 &a, const D2 &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
+    lower.clear(); upper.clear();
+    for (const D2 &p : pts) {          // smallest y at every x
+        while (lower.size() >= 2 && cross(lower[lower.size() - 2], lower.back(), p) <= 0) lower.pop_back();
+        lower.push_back(p);
+    }
+    for (const D2 &p : pts) {          // largest y at every x
+        while (upper.size() >= 2 && cross(upper[upper.size() - 2], upper.back(), p) >= 0) upper.pop_back();
+        upper.push_back(p);
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
 int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
 {
-    (void)H; (void)W; (void)C;
-    if (bytes) *bytes = 0;
-    return fail(OFL_E_INVALID, "ofl_scatter_linear: not implemented in this build");
+    (void)C;
+    if (!bytes) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: NULL");
+    if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: bad shape");
+    *bytes = align_up((size_t)H * W * 4, 256) + align_up((size_t)kBigCap * 4, 256) +
+             align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * align_up((size_t)kHullCap * sizeof(D2), 256) + 256;
+    return OFL_OK;
 }
-int ofl_scatter_linear_dev(const float *, int, const uint8_t *, const float *, int, int, int,
-                           const float *, float *, uint8_t *, void *, size_t, void *)
+
+int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                           const float *vals, int C, const uint8_t *vmask, int H, int W,
+                           const float *query, float *out, uint8_t *valid, int valid_rule,
+                           void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
 {
-    return fail(OFL_E_INVALID, "ofl_scatter_linear: not implemented in this build");
+    OFL_TRY(need_device());
+    if (!flow || !workspace) return fail(OFL_E_INVALID, "ofl_scatter_linear: NULL pointer");
+    if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 29))
+        return fail(OFL_E_INVALID, "ofl_scatter_linear: H*W must be in [1, 2^29)");
+    if (C < 0 || (C > 0 && (!vals || !out))) return fail(OFL_E_INVALID, "ofl_scatter_linear: C > 0 needs vals and out");
+    if (C == 0 && !valid) return fail(OFL_E_INVALID, "ofl_scatter_linear: nothing to compute");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_linear: sign must be +1 or -1");
+    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad point_precision");
+    if (point_precision == 1) sign *= 2;
+    if (valid_rule != 0 && valid_rule != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
+    size_t need = 0;
+    OFL_TRY(ofl_scatter_workspace_bytes(H, W, C, &need));
+    if (workspace_bytes < need) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small (%zu < %zu)", workspace_bytes, need);
+    hipStream_t s = stream_of(stream);
+    ScatterWs ws = carve(workspace, H, W);
+    OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)H * W * 4, s));
+    OFL_HIP(hipMemsetAsync(ws.counters, 0, 64, s));
+    const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
+    hipLaunchKernelGGL(scatter_raster_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
+    OFL_HIP(hipGetLastError());
+    // the big-triangle list is usually empty; its length lives on the device, so the sweep kernel is
+    // always enqueued with a modest grid and returns immediately when there is nothing to do
+    hipLaunchKernelGGL(scatter_big_kernel, dim3(rt().n_cu * 4), block, 0, s, flow, sign, H, W, ws);
+    OFL_HIP(hipGetLastError());
+    // convex hull of the kept points: candidates from the device, monotone chain on the host.  This is
+    // the one place where the scatter path synchronises the stream (a few thousand points).
+    hipLaunchKernelGGL(scatter_boundary_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
+    OFL_HIP(hipGetLastError());
+    unsigned long long c[4];
+    OFL_HIP(hipMemcpyAsync(c, ws.counters, sizeof(c), hipMemcpyDeviceToHost, s));
+    OFL_HIP(hipStreamSynchronize(s));
+    if (info_host) {
+        info_host[0] = pmask ? c[0] : (uint64_t)H * W;
+        info_host[1] = c[1];
+        info_host[2] = c[2];
+    }
+    if (pmask && c[0] == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
+    if (c[1] > (unsigned long long)kBigCap)
+        return fail(OFL_E_INVALID, "ofl_scatter_linear: %llu triangles exceed the large-triangle list (%d): flow too irregular", c[1], kBigCap);
+    HullRef hull = { ws.lower, ws.upper, 0, 0 };
+    if (c[3] >= 3 && c[3] <= (unsigned long long)ws.cand_cap) {
+        std::vector<D2> pts((size_t)c[3]), lower, upper;
+        OFL_HIP(hipMemcpy(pts.data(), ws.cand, pts.size() * sizeof(D2), hipMemcpyDeviceToHost));
+        convex_chains(pts, lower, upper);
+        if (lower.size() >= 2 && upper.size() >= 2 && lower.size() <= (size_t)kHullCap && upper.size() <= (size_t)kHullCap) {
+            OFL_HIP(hipMemcpy(ws.lower, lower.data(), lower.size() * sizeof(D2), hipMemcpyHostToDevice));
+            OFL_HIP(hipMemcpy(ws.upper, upper.data(), upper.size() * sizeof(D2), hipMemcpyHostToDevice));
+            hull.n_lower = (int)lower.size();
+            hull.n_upper = (int)upper.size();
+        }
+    }
+    hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
+                       out, valid, valid_rule, ws, hull);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
 }
-int ofl_scatter_linear(const float *, int, const uint8_t *, const float *, int, int, int,
-                       const float *, float *, uint8_t *)
+
+int ofl_scatter_linear(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                       const float *vals, int C, const uint8_t *vmask, int H, int W,
+                       const float *query, float *out, uint8_t *valid, int valid_rule)
 {
-    return fail(OFL_E_INVALID, "ofl_scatter_linear: not implemented in this build");
+    OFL_TRY(need_device());
+    if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad shape");
+    const size_t n = (size_t)H * W;
+    hipStream_t s = rt().stream;
+    size_t wsb = 0;
+    OFL_TRY(ofl_scatter_workspace_bytes(H, W, C, &wsb));
+    void *bufs[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    const void *src[6] = { flow, pmask, vals, vmask, query, nullptr };
+    const size_t sz[8] = { n * 8, pmask ? n : 0, (size_t)C * n * 4, vmask ? n : 0, query ? n * 8 : 0,
+                           (size_t)C * n * 4, valid ? n : 0, wsb };
+    int rc = OFL_OK;
+    uint64_t info[3];
+    do {
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 8 && e == hipSuccess; ++k)
+            if (sz[k]) e = hipMalloc(&bufs[k], sz[k]);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
+        for (int k = 0; k < 5 && e == hipSuccess; ++k)
+            if (sz[k] && src[k]) e = hipMemcpyAsync(bufs[k], src[k], sz[k], hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { rc = hip_fail(e, "H2D"); break; }
+        rc = ofl_scatter_linear_dev((const float *)bufs[0], sign, point_precision, (const uint8_t *)bufs[1], (const float *)bufs[2], C,
+                                    (const uint8_t *)bufs[3], H, W, (const float *)bufs[4], (float *)bufs[5],
+                                    (uint8_t *)bufs[6], valid_rule, bufs[7], wsb, info, s);
+        if (rc != OFL_OK) break;
+        if (sz[5] && (e = hipMemcpyAsync(out, bufs[5], sz[5], hipMemcpyDeviceToHost, s)) != hipSuccess) { rc = hip_fail(e, "D2H"); break; }
+        if (sz[6] && (e = hipMemcpyAsync(valid, bufs[6], sz[6], hipMemcpyDeviceToHost, s)) != hipSuccess) { rc = hip_fail(e, "D2H"); break; }
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) { rc = hip_fail(e, "sync"); break; }
+    } while (0);
+    (void)hipStreamSynchronize(s);
+    for (int k = 0; k < 8; ++k) if (bufs[k]) (void)hipFree(bufs[k]);
+    return rc;
 }
-}
+
+}  // extern "C"

@@ -87,6 +87,30 @@ void axpy_kernel(const float *__restrict__ a, const uint8_t *__restrict__ ma,
     }
 }
 
+__global__ __launch_bounds__(256)
+void mask_and_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<uint32_t *>(out)[i] = reinterpret_cast<const uint32_t *>(a)[i] & reinterpret_cast<const uint32_t *>(b)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        out[i] = a[i] & b[i];
+    }
+}
+
+// out = float32(grid +- vecs): NumPy adds the int64 grid to the float32 array in float64 and rounds once
+__global__ __launch_bounds__(256)
+void grid_offset_kernel(const float *__restrict__ vecs, int sign, int H, int W, float *__restrict__ out)
+{
+    const size_t n = (size_t)H * W, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        const float2 f = reinterpret_cast<const float2 *>(vecs)[i];
+        reinterpret_cast<float2 *>(out)[i] = make_float2(map_coord(x, f.x, sign), map_coord(y, f.y, sign));
+    }
+}
+
 int stream_grid(size_t n_items)
 {
     size_t nb = (n_items + 255) / 256;
@@ -143,6 +167,26 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
     if (n_px == 0) return OFL_OK;
     hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n_px / 2)), dim3(256), 0, stream_of(stream),
                        a, ma, b, mb, alpha, n_px, out, mout);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_mask_and_dev(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!a || !b || !out) return fail(OFL_E_INVALID, "ofl_mask_and: NULL pointer");
+    if (n == 0) return OFL_OK;
+    hipLaunchKernelGGL(mask_and_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, stream_of(stream), a, b, out, n);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_grid_offset_dev(const float *vecs, int sign, int H, int W, float *out, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!vecs || !out || H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_grid_offset: bad arguments");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_grid_offset: sign must be +1 or -1");
+    hipLaunchKernelGGL(grid_offset_kernel, dim3(stream_grid((size_t)H * W)), dim3(256), 0, stream_of(stream), vecs, sign, H, W, out);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

@@ -362,13 +362,14 @@ class DeviceFlow:
         return out
 
     def _resample_to(self, flow3):
-        """Mode 2 / ref 't' (flow_class.py:1398-1410): self sampled from the points x - self onto the
-        points x - flow3; mask = interpolated mask > 0.99."""
+        """Mode 2 / ref 't' (flow_class.py:1398-1410): self sampled from the float32 points x - self onto
+        the points x - flow3 (no mask filtering); mask = interpolated mask > 0.99."""
         h, w = self.shape
         out = DeviceFlow.empty(self.shape, 't')
         query = DeviceBuffer(self.n_px * 8)
         grid_minus(flow3.vecs, query, h, w)
-        scatter_linear(self.vecs, -1, None, self.vecs, 2, self.mask, h, w, query, out.vecs, out.mask, 1)
+        scatter_linear(self.vecs, -1, None, self.vecs, 2, self.mask, h, w, query, out.vecs, out.mask, 1,
+                       point_precision=1)
         return out
 
     def valid_target(self, consider_mask=True, quant=nat.QUANT_OPENCV):
@@ -402,14 +403,58 @@ class DeviceFlow:
 
 # ------------------------------------------------------------------------------ small helpers
 def _mask_and(a, b, out, n):
-    """out = a & b for uint8 masks, via the axpy kernel's mask lane (vector lane discarded)."""
-    raise NotImplementedError
+    """out = a & b for uint8 masks (flow_class.py:643)."""
+    nat.check(_lib().ofl_mask_and_dev(a.ptr, b.ptr, out.ptr, n, None))
 
 
 def grid_minus(vecs, out, h, w):
-    raise NotImplementedError
+    """out = float32(grid - vecs): the query positions of mode 2 / ref 't' (flow_class.py:1404-1406)."""
+    nat.check(_lib().ofl_grid_offset_dev(vecs.ptr, -1, h, w, out.ptr, None))
 
 
-def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, valid_rule, stream=None):
-    """K3: scattered -> regular-grid linear interpolation.  Replaces utils.py:237-258."""
-    raise NotImplementedError
+_ws_cache = {}
+
+
+def _workspace(h, w, C):
+    key = (h, w)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        n = ctypes.c_size_t(0)
+        nat.check(_lib().ofl_scatter_workspace_bytes(h, w, C, ctypes.byref(n)))
+        if len(_ws_cache) > 4:
+            _ws_cache.clear()
+        ws = _ws_cache[key] = DeviceBuffer(n.value)
+    return ws
+
+
+def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, valid_rule, point_precision=0,
+                   stream=None):
+    """K3: scattered -> regular-grid linear interpolation.  Replaces utils.py:237-258 (and, with `query`,
+    flow_class.py:1398-1410).  Raises ValueError("No points given") like qhull when nothing is kept."""
+    ws = _workspace(h, w, C)
+    info = (ctypes.c_uint64 * 3)()
+    ptr = lambda b: b.ptr if b is not None else None
+    nat.check(_lib().ofl_scatter_linear_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),
+                                            h, w, ptr(query), ptr(out), ptr(valid), valid_rule, ws.ptr, ws.nbytes,
+                                            info, stream))
+    return tuple(info)
+
+
+def scatter_host(flow, target, pmask, vmask=None):
+    """apply_flow(flow, target, 's', mask) for host arrays (utils.py:237-258): target (H, W, C) of any numeric
+    dtype is interpolated in float32/float64 on the device, then rounded / cast back like the reference.
+    Returns (warped, valid or None); valid = float32(interpolated vmask) == 1 (flow_class.py:668)."""
+    h, w, C = target.shape
+    fbuf = DeviceBuffer.from_host(np.ascontiguousarray(flow, np.float32))
+    vals = DeviceBuffer.from_host(np.ascontiguousarray(target, np.float32))
+    pm = DeviceBuffer.from_host(np.ascontiguousarray(pmask).astype(np.uint8)) if pmask is not None else None
+    vm = DeviceBuffer.from_host(np.ascontiguousarray(vmask).astype(np.uint8)) if vmask is not None else None
+    out = DeviceBuffer(h * w * C * 4)
+    valid = DeviceBuffer(h * w) if vmask is not None else None
+    scatter_linear(fbuf, +1, pm, vals, C, vm, h, w, None, out, valid, 0)
+    res = out.to_host((h, w, C), np.float32)
+    if np.issubdtype(target.dtype, np.integer):
+        res = np.round(res)
+    res = res.astype(target.dtype)
+    v = valid.to_host((h, w), np.uint8).astype(bool) if valid is not None else None
+    return res, v

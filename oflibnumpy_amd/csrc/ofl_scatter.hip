@@ -22,6 +22,7 @@
 // node -- all L2-friendly because owner triangles of neighbouring nodes are neighbours in memory.
 #include "ofl_common.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <vector>
 
 using namespace ofl;
@@ -45,7 +46,8 @@ struct ScatterWs {          // layout of the caller-provided workspace
     D2       *cand;         // [cand_cap] positions of mesh-boundary points (convex-hull candidates)
     D2       *lower;        // [kHullCap] lower hull chain, x ascending
     D2       *upper;        // [kHullCap] upper hull chain, x ascending
-    unsigned long long *counters;   // [0] kept points, [1] big-list length, [2] big-list work, [3] candidates
+    unsigned long long *counters;   // [1] big-list length, [2] big-list work, [3] candidates
+    unsigned long long *kept_slots; // [256] partial counts of kept points
     int       cand_cap;
 };
 
@@ -92,11 +94,29 @@ __device__ __forceinline__ int pick_diagonal(const D2 &a, const D2 &b, const D2 
     return ic > 0 ? 1 : 0;                          // d inside circle(a, b, c) -> a-c is illegal
 }
 
-// vertices of triangle t (0/1) of a cell split along `diag`; indices into {a, b, c, d}
+// vertices of triangle t (0/1) of a cell split along `diag`; corner numbers a=0, b=1, c=2, d=3:
+//   diag 0: (a, b, c), (a, c, d)        diag 1: (b, c, d), (b, d, a)
 __device__ __forceinline__ void tri_corners(int diag, int t, int &i0, int &i1, int &i2)
 {
-    if (diag == 0) { if (t == 0) { i0 = 0; i1 = 1; i2 = 2; } else { i0 = 0; i1 = 2; i2 = 3; } }
-    else           { if (t == 0) { i0 = 1; i1 = 2; i2 = 3; } else { i0 = 1; i1 = 3; i2 = 0; } }
+    i0 = diag;
+    i1 = diag + 1 + t;
+    i2 = (diag + 2 + t) & 3;
+}
+
+// Value selection by corner number WITHOUT indexing a register array at run time (hipcc would place
+// such an array in scratch memory).
+template <typename T>
+__device__ __forceinline__ T pick4(int i, const T &a, const T &b, const T &c, const T &d)
+{
+    return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d));
+}
+
+__device__ __forceinline__ D2 pick4(int i, const D2 &a, const D2 &b, const D2 &c, const D2 &d)
+{
+    D2 r;
+    r.x = i == 0 ? a.x : (i == 1 ? b.x : (i == 2 ? c.x : d.x));
+    r.y = i == 0 ? a.y : (i == 1 ? b.y : (i == 2 ? c.y : d.y));
+    return r;
 }
 
 __device__ __forceinline__ bool bary(const D2 &p0, const D2 &p1, const D2 &p2, double gx, double gy,
@@ -110,6 +130,29 @@ __device__ __forceinline__ bool bary(const D2 &p0, const D2 &p1, const D2 &p2, d
     c2 = (e1x * dy - e1y * dx) / det;
     c0 = 1.0 - c1 - c2;
     return c0 >= -kEps && c0 <= 1.0 + kEps && c1 >= -kEps && c1 <= 1.0 + kEps && c2 >= -kEps && c2 <= 1.0 + kEps;
+}
+
+// Inside test of the raster passes, division-free: c_i >= -eps  <=>  w_i * sign(det) >= -eps * |det| with the
+// three edge functions w_i of the barycentric numerators (c_i <= 1 + eps follows from the other two
+// being >= -eps up to O(eps)).  The resolve pass evaluates the coordinates themselves.
+struct TriEdge { D2 p0; double e1x, e1y, e2x, e2y, det, tol; };
+
+__device__ __forceinline__ bool tri_setup(const D2 &p0, const D2 &p1, const D2 &p2, TriEdge &t)
+{
+    t.p0 = p0;
+    t.e1x = p1.x - p0.x; t.e1y = p1.y - p0.y; t.e2x = p2.x - p0.x; t.e2y = p2.y - p0.y;
+    t.det = t.e1x * t.e2y - t.e1y * t.e2x;
+    t.tol = kEps * fabs(t.det);
+    return t.det != 0.0;
+}
+
+__device__ __forceinline__ bool tri_inside(const TriEdge &t, double gx, double gy)
+{
+    const double dx = gx - t.p0.x, dy = gy - t.p0.y;
+    double w1 = dx * t.e2y - dy * t.e2x, w2 = t.e1x * dy - t.e1y * dx;
+    double w0 = t.det - w1 - w2;
+    if (t.det < 0) { w0 = -w0; w1 = -w1; w2 = -w2; }
+    return w0 >= -t.tol && w1 >= -t.tol && w2 >= -t.tol;
 }
 
 struct TriBox { int x0, x1, y0, y1; };
@@ -137,36 +180,47 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
     const int cw = W - 1, ch = H - 1;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (pmask) {   // count the points SciPy would receive (utils.py:249-251): one thread per point
-        unsigned long long kept = 0;
-        // cells cover (W-1) x (H-1); points on the last row / column are counted by the edge threads
-        if (x < W && y < H) {
-            kept += pmask[(size_t)y * W + x] != 0;
-        }
-        const unsigned long long wave_sum = __popcll(__ballot(kept != 0));
-        if ((threadIdx.x & 63) == 0 && wave_sum) atomicAdd(&ws.counters[0], wave_sum);
+    if (pmask) {
+        // Count the points SciPy would receive (utils.py:249-251).  One atomic per WORKGROUP, spread over
+        // 256 slots: a single counter word would serialise ~1e5 atomics at ~12 ns each (1.5 ms at 4K --
+        // measured, it dominated the first version of this kernel).
+        const int kept = (x < W && y < H) ? (pmask[(size_t)y * W + x] != 0) : 0;
+        const int block_sum = __syncthreads_count(kept);
+        if (threadIdx.x == 0 && block_sum)
+            atomicAdd(&ws.kept_slots[(blockIdx.y * gridDim.x + blockIdx.x) & 255], (unsigned long long)block_sum);
     }
     if (x >= cw || y >= ch) return;
     const size_t i00 = (size_t)y * W + x;
-    bool keep[4] = { true, true, true, true };
+    bool k0 = true, k1 = true, k2 = true, k3 = true;
     if (pmask) {
-        keep[0] = pmask[i00] != 0; keep[1] = pmask[i00 + 1] != 0;
-        keep[2] = pmask[i00 + W + 1] != 0; keep[3] = pmask[i00 + W] != 0;
+        k0 = pmask[i00] != 0; k1 = pmask[i00 + 1] != 0;
+        k2 = pmask[i00 + W + 1] != 0; k3 = pmask[i00 + W] != 0;
     }
-    const int n_keep = keep[0] + keep[1] + keep[2] + keep[3];
+    const int n_keep = (int)k0 + (int)k1 + (int)k2 + (int)k3;
     if (n_keep < 3) return;
-    D2 p[4] = { point_of(flow, sign, W, x, y), point_of(flow, sign, W, x + 1, y),
-                point_of(flow, sign, W, x + 1, y + 1), point_of(flow, sign, W, x, y + 1) };
+    const D2 pa = point_of(flow, sign, W, x, y), pb = point_of(flow, sign, W, x + 1, y);
+    const D2 pc = point_of(flow, sign, W, x + 1, y + 1), pd = point_of(flow, sign, W, x, y + 1);
     int diag;
-    if (n_keep == 4) diag = pick_diagonal(p[0], p[1], p[2], p[3]);
-    else diag = (!keep[0] || !keep[2]) ? 1 : 0;     // the only diagonal that leaves a fully kept triangle
+    if (n_keep == 4) diag = pick_diagonal(pa, pb, pc, pd);
+    else diag = (!k0 || !k2) ? 1 : 0;     // the only diagonal that leaves a fully kept triangle
+    // a cell that is not properly oriented (folded mesh) can push interior points onto the convex hull
+    // of the point set: its corners become hull candidates (duplicates are harmless)
+    if (!(cross2(pa, pb, pc) > 0 && cross2(pa, pc, pd) > 0 && cross2(pb, pc, pd) > 0 && cross2(pb, pd, pa) > 0)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (pick4(k, k0, k1, k2, k3)) {
+                const unsigned long long slot = atomicAdd(&ws.counters[3], 1ull);
+                if (slot < (unsigned long long)ws.cand_cap) ws.cand[slot] = pick4(k, pa, pb, pc, pd);
+            }
+    }
     const uint32_t cell = (uint32_t)(y * cw + x);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         int i0, i1, i2;
         tri_corners(diag, t, i0, i1, i2);
-        if (!(keep[i0] && keep[i1] && keep[i2])) continue;
-        const TriBox b = tri_box(p[i0], p[i1], p[i2], W, H);
+        if (!(pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3))) continue;
+        const D2 q0 = pick4(i0, pa, pb, pc, pd), q1 = pick4(i1, pa, pb, pc, pd), q2 = pick4(i2, pa, pb, pc, pd);
+        const TriBox b = tri_box(q0, q1, q2, W, H);
         if (b.x1 < b.x0 || b.y1 < b.y0) continue;
         const uint32_t id = tri_id(cell, diag, t);
         const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
@@ -176,18 +230,19 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
             if (slot < (unsigned long long)kBigCap) ws.big[slot] = id;
             continue;
         }
+        TriEdge te;
+        if (!tri_setup(q0, q1, q2, te)) continue;
         for (int gy = b.y0; gy <= b.y1; ++gy)
-            for (int gx = b.x0; gx <= b.x1; ++gx) {
-                double c0, c1, c2;
-                if (bary(p[i0], p[i1], p[i2], (double)gx, (double)gy, c0, c1, c2))
+            for (int gx = b.x0; gx <= b.x1; ++gx)
+                if (tri_inside(te, (double)gx, (double)gy))
                     atomicMin(&ws.owner[(size_t)gy * W + gx], id);
-            }
     }
 }
 
-// Convex-hull candidates: kept points that sit on the border of the kept mesh (a neighbour is missing)
-// or next to a cell that is not properly oriented (folded mesh).  Every vertex of the convex hull of
-// the kept points is among them; interior points of a properly embedded mesh never are.
+// Convex-hull candidates: kept points that sit on the border of the kept mesh (a neighbour is missing);
+// corners of cells that are not properly oriented (folded mesh) are added by the raster pass.  Every
+// vertex of the convex hull of the kept points is among them; interior points of a properly embedded
+// mesh never are.
 __global__ __launch_bounds__(256)
 void scatter_boundary_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
                              int H, int W, ScatterWs ws)
@@ -201,14 +256,6 @@ void scatter_boundary_kernel(const float *__restrict__ flow, int sign, const uin
         for (int dy = -1; dy <= 1 && !cand; ++dy)
             for (int dx = -1; dx <= 1 && !cand; ++dx)
                 cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
-    }
-    if (!cand) {    // all eight neighbours exist: look for folded incident cells
-        for (int cy = y - 1; cy <= y && !cand; ++cy)
-            for (int cx = x - 1; cx <= x && !cand; ++cx) {
-                const D2 a = point_of(flow, sign, W, cx, cy), b = point_of(flow, sign, W, cx + 1, cy);
-                const D2 c = point_of(flow, sign, W, cx + 1, cy + 1), d = point_of(flow, sign, W, cx, cy + 1);
-                cand = !(cross2(a, b, c) > 0 && cross2(a, c, d) > 0 && cross2(b, c, d) > 0 && cross2(b, d, a) > 0);
-            }
     }
     if (cand) {
         const unsigned long long slot = atomicAdd(&ws.counters[3], 1ull);
@@ -276,13 +323,14 @@ __device__ __forceinline__ void tri_decode(uint32_t id, const float *flow, int s
     const uint32_t cell = id >> 2;
     const int diag = (id >> 1) & 1, t = id & 1;
     const int y = (int)(cell / (uint32_t)cw), x = (int)(cell - (uint32_t)y * (uint32_t)cw);
-    const int cx[4] = { x, x + 1, x + 1, x }, cy[4] = { y, y, y + 1, y + 1 };
-    int i[3];
-    tri_corners(diag, t, i[0], i[1], i[2]);
+    int i0, i1, i2;
+    tri_corners(diag, t, i0, i1, i2);
+    const int ci[3] = { i0, i1, i2 };
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        vi[k] = (size_t)cy[i[k]] * W + cx[i[k]];
-        vp[k] = point_of(flow, sign, W, cx[i[k]], cy[i[k]]);
+        const int px = x + (((ci[k] + 1) >> 1) & 1), py = y + (ci[k] >> 1);     // corner a,b,c,d -> (0,0),(1,0),(1,1),(0,1)
+        vi[k] = (size_t)py * W + px;
+        vp[k] = point_of(flow, sign, W, px, py);
     }
 }
 
@@ -301,10 +349,11 @@ void scatter_big_kernel(const float *__restrict__ flow, int sign, int H, int W, 
         tri_decode(id, flow, sign, W, vi, vp);
         const TriBox b = tri_box(vp[0], vp[1], vp[2], W, H);
         const long long bw = b.x1 - b.x0 + 1, area = bw * (b.y1 - b.y0 + 1);
+        TriEdge te;
+        if (!tri_setup(vp[0], vp[1], vp[2], te)) continue;
         for (long long j = lane; j < area; j += 64) {
             const int gy = b.y0 + (int)(j / bw), gx = b.x0 + (int)(j % bw);
-            double c0, c1, c2;
-            if (bary(vp[0], vp[1], vp[2], (double)gx, (double)gy, c0, c1, c2))
+            if (tri_inside(te, (double)gx, (double)gy))
                 atomicMin(&ws.owner[(size_t)gy * W + gx], id);
         }
     }
@@ -331,9 +380,10 @@ void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint
     bool found = false;
     if (!query) {
         id = ws.owner[o];
-        if (id != kNoOwner) {
+        if (id != kNoOwner) {      // the raster pass decided containment; only the coordinates are needed
             tri_decode(id, flow, sign, W, vi, vp);
-            found = bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
+            (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
+            found = true;
         }
     } else {
         const float2 q = *reinterpret_cast<const float2 *>(query + o * 2);
@@ -358,21 +408,21 @@ void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint
                     const int cx = sx + dx, cy = sy + dy;
                     if (cx < 0 || cy < 0 || cx >= cw || cy >= chh) continue;
                     const size_t i00 = (size_t)cy * W + cx;
-                    bool keep[4] = { true, true, true, true };
+                    bool k0 = true, k1 = true, k2 = true, k3 = true;
                     if (pmask) {
-                        keep[0] = pmask[i00] != 0; keep[1] = pmask[i00 + 1] != 0;
-                        keep[2] = pmask[i00 + W + 1] != 0; keep[3] = pmask[i00 + W] != 0;
+                        k0 = pmask[i00] != 0; k1 = pmask[i00 + 1] != 0;
+                        k2 = pmask[i00 + W + 1] != 0; k3 = pmask[i00 + W] != 0;
                     }
-                    const int n_keep = keep[0] + keep[1] + keep[2] + keep[3];
+                    const int n_keep = (int)k0 + (int)k1 + (int)k2 + (int)k3;
                     if (n_keep < 3) continue;
-                    const D2 p[4] = { point_of(flow, sign, W, cx, cy), point_of(flow, sign, W, cx + 1, cy),
-                                      point_of(flow, sign, W, cx + 1, cy + 1), point_of(flow, sign, W, cx, cy + 1) };
-                    const int diag = n_keep == 4 ? pick_diagonal(p[0], p[1], p[2], p[3]) : ((!keep[0] || !keep[2]) ? 1 : 0);
+                    const D2 pa = point_of(flow, sign, W, cx, cy), pb = point_of(flow, sign, W, cx + 1, cy);
+                    const D2 pc = point_of(flow, sign, W, cx + 1, cy + 1), pd = point_of(flow, sign, W, cx, cy + 1);
+                    const int diag = n_keep == 4 ? pick_diagonal(pa, pb, pc, pd) : ((!k0 || !k2) ? 1 : 0);
                     for (int t = 0; t < 2 && !found; ++t) {
                         int i0, i1, i2;
                         tri_corners(diag, t, i0, i1, i2);
-                        if (!(keep[i0] && keep[i1] && keep[i2])) continue;
-                        if (bary(p[i0], p[i1], p[i2], qx, qy, c0, c1, c2)) {
+                        if (!(pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3))) continue;
+                        if (bary(pick4(i0, pa, pb, pc, pd), pick4(i1, pa, pb, pc, pd), pick4(i2, pa, pb, pc, pd), qx, qy, c0, c1, c2)) {
                             found = true;
                             id = tri_id((uint32_t)(cy * cw + cx), diag, t);
                             tri_decode(id, flow, sign, W, vi, vp);
@@ -431,7 +481,8 @@ ScatterWs carve(void *workspace, int H, int W)
     ws.cand = (D2 *)p;                   p += align_up((size_t)ws.cand_cap * sizeof(D2), 256);
     ws.lower = (D2 *)p;                  p += align_up((size_t)kHullCap * sizeof(D2), 256);
     ws.upper = (D2 *)p;                  p += align_up((size_t)kHullCap * sizeof(D2), 256);
-    ws.counters = (unsigned long long *)p;
+    ws.counters = (unsigned long long *)p;   p += 256;
+    ws.kept_slots = (unsigned long long *)p;
     return ws;
 }
 
@@ -462,7 +513,8 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
     if (!bytes) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: NULL");
     if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: bad shape");
     *bytes = align_up((size_t)H * W * 4, 256) + align_up((size_t)kBigCap * 4, 256) +
-             align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * align_up((size_t)kHullCap * sizeof(D2), 256) + 256;
+             align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * align_up((size_t)kHullCap * sizeof(D2), 256) +
+             256 + 256 * sizeof(unsigned long long);
     return OFL_OK;
 }
 
@@ -487,7 +539,7 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     hipStream_t s = stream_of(stream);
     ScatterWs ws = carve(workspace, H, W);
     OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)H * W * 4, s));
-    OFL_HIP(hipMemsetAsync(ws.counters, 0, 64, s));
+    OFL_HIP(hipMemsetAsync(ws.counters, 0, 256 + 256 * sizeof(unsigned long long), s));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_raster_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
     OFL_HIP(hipGetLastError());
@@ -499,9 +551,11 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     // the one place where the scatter path synchronises the stream (a few thousand points).
     hipLaunchKernelGGL(scatter_boundary_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
     OFL_HIP(hipGetLastError());
-    unsigned long long c[4];
-    OFL_HIP(hipMemcpyAsync(c, ws.counters, sizeof(c), hipMemcpyDeviceToHost, s));
+    unsigned long long cbuf[32 + 256];
+    OFL_HIP(hipMemcpyAsync(cbuf, ws.counters, sizeof(cbuf), hipMemcpyDeviceToHost, s));
     OFL_HIP(hipStreamSynchronize(s));
+    unsigned long long c[4] = { 0, cbuf[1], cbuf[2], cbuf[3] };
+    for (int k = 0; k < 256; ++k) c[0] += cbuf[32 + k];
     if (info_host) {
         info_host[0] = pmask ? c[0] : (uint64_t)H * W;
         info_host[1] = c[1];

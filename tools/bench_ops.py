@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Secondary measurements (not the driver's bench.py): the other BASELINE.json configs, device-resident,
+HIP-event timed.  Prints one JSON object per operation with the algorithmic bytes of SURVEY.md 8(d).
+
+    python tools/bench_ops.py [--iters 20]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oflibnumpy_amd as of
+from oflibnumpy_amd import device as dev
+
+nat = of.native
+
+
+def timed(fn, iters, warm=3):
+    lib = nat.load()
+    for _ in range(warm):
+        fn()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    nat.check(lib.ofl_event_create(ctypes.byref(e0)))
+    nat.check(lib.ofl_event_create(ctypes.byref(e1)))
+    nat.check(lib.ofl_device_sync())
+    t0 = time.perf_counter()
+    nat.check(lib.ofl_event_record(e0, None))
+    for _ in range(iters):
+        fn()
+    nat.check(lib.ofl_event_record(e1, None))
+    nat.check(lib.ofl_device_sync())
+    wall = (time.perf_counter() - t0) / iters
+    ms = ctypes.c_float()
+    nat.check(lib.ofl_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    return ms.value / iters * 1e-3, wall
+
+
+def report(name, shape, bytes_per_px, dev_s, wall_s, note=""):
+    n = shape[0] * shape[1]
+    print(json.dumps({"op": name, "shape": list(shape), "algorithmic_bytes": bytes_per_px * n,
+                      "device_ms": round(dev_s * 1e3, 4), "wall_ms": round(wall_s * 1e3, 4),
+                      "GBps_algorithmic": round(bytes_per_px * n / dev_s / 1e9, 1),
+                      "frac_of_8TBps": round(bytes_per_px * n / dev_s / 8e12, 4), "note": note}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    nat.ensure_device()
+    it = args.iters
+
+    # config 2: 1080 x 1920 't' flow applied to an RGB float32 image with valid area (34 B/px)
+    h, w = 1080, 1920
+    f1 = of.Flow.from_transforms([['rotation', 960, 540, -30]], [h, w], 't')
+    img = np.random.default_rng(1).random((h, w, 3), dtype=np.float32)
+    d1 = f1.to_device()
+    dimg = dev.DeviceImage.from_host(img)
+    t = timed(lambda: dev.gather_bilinear(dimg, d1.vecs, (h, w), -1, fmask=d1.mask, want_valid=True), it)
+    report("apply 't' RGB f32 + valid (K1)", (h, w), 34, *t, note="BASELINE config 2; rotated sampling pattern")
+
+    # config 3: 2160 x 3840 's': invert (1 scatter, 18 B/px) and combine mode 1 (72 B/px stage sum)
+    h, w = 2160, 3840
+    f2 = of.Flow.from_transforms([['scaling', 1000, 800, 0.9]], [h, w], 's')
+    f3 = of.Flow.from_transforms([['rotation', 1920, 1080, -20], ['scaling', 1000, 800, 0.9]], [h, w], 's')
+    d2, d3 = f2.to_device(), f3.to_device()
+    d2.stats(); d3.stats()
+    t = timed(lambda: d2.invert(), it)
+    report("invert s->s (K3)", (h, w), 18, *t, note="BASELINE config 3; includes the host convex-hull step")
+    t = timed(lambda: d2.combine_with(d3, 1), max(3, it // 4))
+    report("combine_with mode 1 's' (K3 + 2 x K1 + epilogues)", (h, w), 72, *t, note="BASELINE config 3")
+    t = timed(lambda: d2.switch_ref(), it)
+    report("switch_ref s->t (K3)", (h, w), 18, *t)
+
+    # config 5: Sintel .flo tiled to 4320 x 7680, apply to an RGB f32 image: 't' (gather) and 's' (scatter)
+    flo = of.load_sintel(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sintel.flo"))
+    big = np.tile(flo, (432, 384, 1))
+    h, w = big.shape[:2]
+    img = np.random.default_rng(2).random((h, w, 3), dtype=np.float32)
+    dimg = dev.DeviceImage.from_host(img)
+    dt = dev.DeviceFlow.from_host(big, 't')
+    t = timed(lambda: dev.gather_bilinear(dimg, dt.vecs, (h, w), -1, fmask=dt.mask, want_valid=True), max(3, it // 2))
+    report("apply 't' RGB f32 + valid, tiled Sintel 4320x7680 (K1)", (h, w), 34, *t, note="BASELINE config 5, wrapped as 't'")
+    vals = dimg.buf
+    out = dev.DeviceBuffer(h * w * 12)
+    valid = dev.DeviceBuffer(h * w)
+    info = []
+    t = timed(lambda: info.append(dev.scatter_linear(dt.vecs, +1, None, vals, 3, None, h, w, None, out, valid, 0)), 3, warm=1)
+    report("apply 's' RGB f32 + valid, tiled Sintel 4320x7680 (K3)", (h, w), 34, *t,
+           note="BASELINE config 5 as loaded ('s'); large triangles: {}".format(info[-1][1:]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""CPU suite, part 3: the N > 1 plumbing with world_size 2 over gloo (no GPU): shards partition the work
+disjointly and completely, the unique-id broadcast delivers rank 0's bytes, timings reduce to the maximum."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from oflibnumpy_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_partitions():
+    for n in (0, 1, 7, 8, 256, 1000):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in sharding.shard(n, r, world)]
+            assert got == list(range(n))
+            sizes = [len(sharding.shard(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert list(sharding.shard(256, 3, 8)) == list(range(96, 128))      # BASELINE config 4: 32 pairs per GPU
+    with pytest.raises(ValueError):
+        sharding.shard(4, 2, 2)
+
+
+def test_row_bands_cover_field():
+    for h in (7, 8, 2160, 4320, 1001):
+        for world in (1, 2, 8):
+            bands = [sharding.row_band(h, r, world) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == h
+            for (a0, a1), (b0, b1) in zip(bands, bands[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert all(b[0] % 8 == 0 or b[0] == h for b in bands)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch.distributed as dist
+    from oflibnumpy_amd import sharding
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    uid = np.arange(128, dtype=np.uint8) * (3 if rank == 0 else 0) + (7 if rank == 0 else 0)
+    got = sharding.broadcast_bytes(dist, uid, 0)
+    mine = list(sharding.shard(10, rank, world))
+    t = sharding.max_over_ranks(dist, [1.0 + rank, 5.0 - rank])
+    dist.barrier()
+    print(json.dumps({{"rank": rank, "uid_sum": int(got.astype(int).sum()), "items": mine, "t": t}}), flush=True)
+    dist.destroy_process_group()
+""")
+
+
+def test_two_ranks_over_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+        assert p.returncode == 0, err[-2000:]
+        outs.append(__import__("json").loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    want_sum = int((np.arange(128, dtype=np.uint8) * 3 + 7).astype(int).sum())
+    assert [d["uid_sum"] for d in outs] == [want_sum, want_sum]
+    assert outs[0]["items"] + outs[1]["items"] == list(range(10))
+    assert outs[0]["t"] == outs[1]["t"] == [2.0, 5.0]

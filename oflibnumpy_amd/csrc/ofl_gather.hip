@@ -158,20 +158,24 @@ struct C3Stat {            // running maxima for the zero-flow predicates of one
     float amax_m, bmax, bmax_m;
 };
 
+// LX = lanes along x per tile row: tile = 4*LX px wide, 256/LX rows high; lane (lx, ly) owns the pixel
+// pairs at x = 2*lx and x = 2*LX + 2*lx.
+template <int LX>
 __device__ __forceinline__ void c3_tile_coords(const C3Args &a, int tile, int &b, int &y, int (&xg)[2])
 {
     b = tile / a.tiles_per_field;
     const int t  = tile - b * a.tiles_per_field;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    y = ty * kC3TileH + (threadIdx.x / kC3LanesX);
-    xg[0] = tx * kC3TileW + 2 * (threadIdx.x % kC3LanesX);
-    xg[1] = xg[0] + 2 * kC3LanesX;
+    y = ty * (256 / LX) + (threadIdx.x / LX);
+    xg[0] = tx * (4 * LX) + 2 * (threadIdx.x % LX);
+    xg[1] = xg[0] + 2 * LX;
 }
 
+template <int LX>
 __device__ __forceinline__ C3Stream c3_load_stream(const C3Args &a, int tile)
 {
     int b, y, xg[2];
-    c3_tile_coords(a, tile, b, y, xg);
+    c3_tile_coords<LX>(a, tile, b, y, xg);
     const size_t base = (size_t)b * a.H * a.W + (size_t)y * a.W;
     C3Stream s;
 #pragma unroll
@@ -211,12 +215,43 @@ __device__ __forceinline__ void c3_flush_stats(const C3Args &a, int b, const C3S
     }
 }
 
+// stream out: out = fb + B(fa), mout = mb & valid   (flow_class.py:332-334, 668, 680)
+template <bool STATS>
+__device__ __forceinline__ void c3_finish(const C3Args &a, size_t row, const int (&xg)[2], const bool (&act)[2],
+                                          const float (&bu)[kC3Px], const float (&bv)[kC3Px], const bool (&bm)[kC3Px],
+                                          const float (&su)[kC3Px], const float (&sv)[kC3Px], const bool (&ok)[kC3Px],
+                                          C3Stat &st)
+{
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (act[g] && !((a.ablate & 2) && su[2 * g] != 12345.0f)) {
+            const int j = 2 * g;
+            const float4 o4 = make_float4(__fadd_rn(bu[j], su[j]), __fadd_rn(bv[j], sv[j]),
+                                          __fadd_rn(bu[j + 1], su[j + 1]), __fadd_rn(bv[j + 1], sv[j + 1]));
+            const uint16_t mo = (uint16_t)(((ok[j] && bm[j]) ? 1u : 0u) | ((ok[j + 1] && bm[j + 1]) ? 0x100u : 0u));
+            if (OFL_C3_NT & 1) {
+                const v4f t = { o4.x, o4.y, o4.z, o4.w };
+                __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(a.out + 2 * (row + xg[g])));
+                __builtin_nontemporal_store(mo, reinterpret_cast<uint16_t *>(a.mout + row + xg[g]));
+            } else {
+                *reinterpret_cast<float4 *>(a.out + 2 * (row + xg[g])) = o4;
+                *reinterpret_cast<uint16_t *>(a.mout + row + xg[g]) = mo;
+            }
+            if (STATS) {
+                const float a0 = fmaxf(fabsf(bu[j]), fabsf(bv[j])), a1 = fmaxf(fabsf(bu[j + 1]), fabsf(bv[j + 1]));
+                st.bmax   = fmaxf(st.bmax, fmaxf(a0, a1));
+                st.bmax_m = fmaxf(st.bmax_m, fmaxf(bm[j] ? a0 : 0.0f, bm[j + 1] ? a1 : 0.0f));
+            }
+        }
+    }
+}
+
 // One tile: taps from the already loaded stream data, gather, blend, store.
 template <int QUANT, bool STATS>
 __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Stream &in, C3Stat &st)
 {
     int b, y, xg[2];
-    c3_tile_coords(a, tile, b, y, xg);
+    c3_tile_coords<kC3LanesX>(a, tile, b, y, xg);
     const int H = a.H, W = a.W, sign = a.sign;
     const size_t field = (size_t)b * H * W;
     const float   *fa = a.fa + field * 2;
@@ -258,6 +293,7 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
             const size_t s0 = act[j >> 1] ? (size_t)tp[j].iy * W + tp[j].ix : 0;
             p0[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
             p1[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * (s0 + W));
+            if (a.ablate & 16) { m0[j] = 0x0101u; m1[j] = 0x0101u; continue; }       // TA-cost probe: no mask gathers
             m0[j] = (uint32_t)ma[s0] | ((uint32_t)ma[s0 + 1] << 8);
             m1[j] = (uint32_t)ma[s0 + W] | ((uint32_t)ma[s0 + W + 1] << 8);
         }
@@ -298,29 +334,7 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
         }
     }
 
-    // ---- stream out: out = fb + B(fa), mout = mb & valid   (flow_class.py:332-334, 668, 680)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        if (act[g] && !((a.ablate & 2) && su[2 * g] != 12345.0f)) {
-            const int j = 2 * g;
-            const float4 o4 = make_float4(__fadd_rn(bu[j], su[j]), __fadd_rn(bv[j], sv[j]),
-                                          __fadd_rn(bu[j + 1], su[j + 1]), __fadd_rn(bv[j + 1], sv[j + 1]));
-            const uint16_t mo = (uint16_t)(((ok[j] && bm[j]) ? 1u : 0u) | ((ok[j + 1] && bm[j + 1]) ? 0x100u : 0u));
-            if (OFL_C3_NT & 1) {
-                const v4f t = { o4.x, o4.y, o4.z, o4.w };
-                __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(a.out + 2 * (row + xg[g])));
-                __builtin_nontemporal_store(mo, reinterpret_cast<uint16_t *>(a.mout + row + xg[g]));
-            } else {
-                *reinterpret_cast<float4 *>(a.out + 2 * (row + xg[g])) = o4;
-                *reinterpret_cast<uint16_t *>(a.mout + row + xg[g]) = mo;
-            }
-            if (STATS) {
-                const float a0 = fmaxf(fabsf(bu[j]), fabsf(bv[j])), a1 = fmaxf(fabsf(bu[j + 1]), fabsf(bv[j + 1]));
-                st.bmax   = fmaxf(st.bmax, fmaxf(a0, a1));
-                st.bmax_m = fmaxf(st.bmax_m, fmaxf(bm[j] ? a0 : 0.0f, bm[j + 1] ? a1 : 0.0f));
-            }
-        }
-    }
+    c3_finish<STATS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
 }
 
 // Persistent form: gridDim.x workgroups (a multiple of 8, sized to the chip's residency) walk the tile
@@ -329,6 +343,10 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
 // (load fb -> addresses -> gather -> store), and the launch pays one ramp-up / tail instead of one per
 // resident-set of workgroups.  At every step the workgroups of one XCD (blockIdx % 8) own a contiguous
 // run of tiles, so neighbouring tiles share gather halos in that XCD's L2.
+#ifndef OFL_C3_PREFETCH
+#define OFL_C3_PREFETCH 1            // tiles of stream data kept in flight ahead of the one being gathered (1 or 2)
+#endif
+
 template <int QUANT, bool STATS>
 __global__ __launch_bounds__(256)
 void compose3_kernel(const C3Args a)
@@ -340,13 +358,212 @@ void compose3_kernel(const C3Args a)
     if (tile >= a.ntiles) return;
     C3Stat st = { 0.0f, 0.0f, 0.0f };
     int cur_b = tile / a.tiles_per_field;
-    C3Stream in = c3_load_stream(a, tile);
+    C3Stream in = c3_load_stream<kC3LanesX>(a, tile);
+#if OFL_C3_PREFETCH == 2
+    C3Stream in2;
+    if (tile + nb < a.ntiles) in2 = c3_load_stream<kC3LanesX>(a, tile + nb);
+#endif
     while (true) {
         const int next = tile + nb;
         const bool more = next < a.ntiles;
         C3Stream nxt;
-        if (more) nxt = c3_load_stream(a, next);          // prefetch: in flight during this tile's gather
+#if OFL_C3_PREFETCH == 2
+        if (next + nb < a.ntiles) nxt = c3_load_stream<kC3LanesX>(a, next + nb);   // two tiles ahead
+#else
+        if (more) nxt = c3_load_stream<kC3LanesX>(a, next);          // prefetch: in flight during this tile's gather
+#endif
         c3_tile<QUANT, STATS>(a, tile, in, st);
+        if (!more) break;
+        if (STATS) {
+            const int nb_ = next / a.tiles_per_field;
+            if (nb_ != cur_b) {
+                c3_flush_stats(a, cur_b, st);
+                st.amax_m = st.bmax = st.bmax_m = 0.0f;
+                cur_b = nb_;
+            }
+        }
+#if OFL_C3_PREFETCH == 2
+        in = in2;
+        in2 = nxt;
+#else
+        in = nxt;
+#endif
+        tile = next;
+    }
+    if (STATS) c3_flush_stats(a, cur_b, st);
+}
+
+// ------------------------------------------------------------------------------------ K2, LDS-staged form
+// The direct form above fetches 36 B per output pixel through the texture path (two unaligned 16-byte
+// gathers + two 2-byte mask gathers) and its row-strip tiles lose L1 locality when the sampling grid is
+// rotated.  Here a workgroup owns a compact 32 x 32 output tile, finds the bounding box of its sample
+// positions (wave shuffles + 4 LDS atomics per wave), stages that source rectangle ONCE with coalesced,
+// aligned 16-byte row loads into LDS as {u, v, mask, -} quads, and reads the taps with ds_read_b128.
+// Texture-path bytes per pixel drop to 9 (stream) + ~9 x (source px per output px), independent of the
+// rotation of the sampling grid.  Tiles whose footprint does not fit the LDS budget use the direct path.
+constexpr int kLdsLX  = 8;            // 8 lanes x 4 px = 32 px wide, 32 rows
+constexpr int kLdsCap = 2400;         // staged source pixels per workgroup (16 B each = 37.5 KB -> 4 workgroups / CU)
+
+// Wave-wide min / max on the VALU with DPP row shifts and row broadcasts (gfx9 reduction idiom): four
+// row_shr steps leave each 16-lane row's result in its last lane, row_bcast:15 / row_bcast:31 carry it
+// across rows; lane 63 ends up with the wave's result.  No LDS traffic, no dependent ds_bpermute chain.
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_minmax(int v)
+{
+#define OFL_DPP_STEP(CTRL, ROWMASK)                                                        \
+    {                                                                                      \
+        const int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false);        \
+        v = IS_MIN ? min(v, t) : max(v, t);                                                \
+    }
+    OFL_DPP_STEP(0x111, 0xf)    // row_shr:1
+    OFL_DPP_STEP(0x112, 0xf)    // row_shr:2
+    OFL_DPP_STEP(0x114, 0xf)    // row_shr:4
+    OFL_DPP_STEP(0x118, 0xf)    // row_shr:8
+    OFL_DPP_STEP(0x142, 0xa)    // row_bcast:15 into rows 1 and 3
+    OFL_DPP_STEP(0x143, 0xc)    // row_bcast:31 into rows 2 and 3
+#undef OFL_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int QUANT, bool STATS>
+__device__ __forceinline__ void c3_tile_lds(const C3Args &a, int tile, const C3Stream &in, C3Stat &st,
+                                            float4 *lds, int *box_now, int *box_next)
+{
+    int b, y, xg[2];
+    c3_tile_coords<kLdsLX>(a, tile, b, y, xg);
+    const int H = a.H, W = a.W, sign = a.sign;
+    const size_t field = (size_t)b * H * W;
+    const float   *fa = a.fa + field * 2;
+    const uint8_t *ma = a.ma + field;
+    const bool act[2] = { y < H && xg[0] < W, y < H && xg[1] < W };
+    const size_t row = field + (size_t)y * W;
+
+    const float bu[kC3Px] = { in.v[0].x, in.v[0].z, in.v[1].x, in.v[1].z };
+    const float bv[kC3Px] = { in.v[0].y, in.v[0].w, in.v[1].y, in.v[1].w };
+    const bool  bm[kC3Px] = { (in.m[0] & 0xffu) != 0, (in.m[0] & 0xff00u) != 0,
+                              (in.m[1] & 0xffu) != 0, (in.m[1] & 0xff00u) != 0 };
+
+    // ---- sample positions and this lane's share of the footprint
+    C3Pos tp[kC3Px];
+    bool  use[kC3Px];
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -0x7fffffff, by1 = -0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < kC3Px; ++j) {
+        tp[j] = c3_pos<QUANT>(xg[j >> 1] + (j & 1), y, bu[j], bv[j], sign);
+        const bool out_j = tp[j].ix < -1 || tp[j].ix >= W || tp[j].iy < -1 || tp[j].iy >= H;
+        use[j] = act[j >> 1] && !out_j && !(a.ablate & 1);
+        if (use[j]) {
+            bx0 = min(bx0, max(tp[j].ix, 0));     bx1 = max(bx1, min(tp[j].ix + 1, W - 1));
+            by0 = min(by0, max(tp[j].iy, 0));     by1 = max(by1, min(tp[j].iy + 1, H - 1));
+        }
+    }
+    bx0 = wave_minmax<true>(bx0);  by0 = wave_minmax<true>(by0);
+    bx1 = wave_minmax<false>(bx1); by1 = wave_minmax<false>(by1);
+    if ((threadIdx.x & 63) == 0 && bx1 >= bx0) {
+        atomicMin(&box_now[0], bx0); atomicMin(&box_now[1], by0);
+        atomicMax(&box_now[2], bx1); atomicMax(&box_now[3], by1);
+    }
+    __syncthreads();                                                   // A: footprint complete
+    const int X0 = box_now[0] & ~1, Y0 = box_now[1], X1 = box_now[2], Y1 = box_now[3];
+    if (threadIdx.x == 0) {                                            // re-arm the other box for the next tile
+        box_next[0] = 0x7fffffff; box_next[1] = 0x7fffffff; box_next[2] = -0x7fffffff; box_next[3] = -0x7fffffff;
+    }
+    const bool any    = X1 >= X0 && Y1 >= Y0;
+    const int  bw     = any ? ((X1 - X0 + 2) & ~1) : 0;                // even number of columns covering X0..X1
+    const int  bh     = any ? (Y1 - Y0 + 1) : 0;
+    const bool staged = any && bw * bh <= kLdsCap && !(a.ablate & 4);
+
+    if (staged) {
+        const int pairs = bw >> 1, total = pairs * bh;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int r = idx / pairs, cp = idx - r * pairs;
+            const size_t g = (size_t)(Y0 + r) * W + (X0 + 2 * cp);
+            const float4   v = *reinterpret_cast<const float4 *>(fa + 2 * g);
+            const uint32_t m = *reinterpret_cast<const uint16_t *>(ma + g);
+            lds[r * bw + 2 * cp]     = make_float4(v.x, v.y, (m & 0xffu) ? 1.0f : 0.0f, 0.0f);
+            lds[r * bw + 2 * cp + 1] = make_float4(v.z, v.w, (m & 0xff00u) ? 1.0f : 0.0f, 0.0f);
+        }
+    }
+    __syncthreads();                                                   // B: tile staged (and box_next re-armed)
+
+    float su[kC3Px], sv[kC3Px];
+    bool  ok[kC3Px];
+#pragma unroll
+    for (int j = 0; j < kC3Px; ++j) { su[j] = 0.0f; sv[j] = 0.0f; ok[j] = false; }
+
+    if (staged && !(a.ablate & 8)) {
+#pragma unroll
+        for (int j = 0; j < kC3Px; ++j) {
+            if (!use[j]) continue;
+            const int ix = tp[j].ix, iy = tp[j].iy;
+            const bool cx0 = ix >= 0, cx1 = ix + 1 <= W - 1, cy0 = iy >= 0, cy1 = iy + 1 <= H - 1;
+            const int lx0 = max(ix, 0) - X0, lx1 = min(ix + 1, W - 1) - X0;
+            const int ly0 = max(iy, 0) - Y0, ly1 = min(iy + 1, H - 1) - Y0;
+            float4 t00 = lds[ly0 * bw + lx0], t01 = lds[ly0 * bw + lx1];
+            float4 t10 = lds[ly1 * bw + lx0], t11 = lds[ly1 * bw + lx1];
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(cx0 && cy0)) t00 = z;                                // taps outside the image: BORDER_CONSTANT 0
+            if (!(cx1 && cy0)) t01 = z;
+            if (!(cx0 && cy1)) t10 = z;
+            if (!(cx1 && cy1)) t11 = z;
+            const C3Tap w = c3_weights<QUANT>(tp[j]);
+            su[j] = c3_blend(t00.x, t01.x, t10.x, t11.x, w);
+            sv[j] = c3_blend(t00.y, t01.y, t10.y, t11.y, w);
+            ok[j] = c3_valid<QUANT>(t00.z != 0.0f, t01.z != 0.0f, t10.z != 0.0f, t11.z != 0.0f, w);
+            if (STATS) st.amax_m = fmaxf(st.amax_m, t00.z != 0.0f ? fmaxf(fabsf(t00.x), fabsf(t00.y)) : 0.0f);
+        }
+    } else if (any) {
+        // footprint too large for the LDS budget: per-pixel gathers straight from global memory
+#pragma unroll
+        for (int j = 0; j < kC3Px; ++j) {
+            if (!use[j]) continue;
+            const int  ixc = min(max(tp[j].ix, 0), max(W - 2, 0));
+            const int  d   = tp[j].ix - ixc;
+            const bool r0  = (unsigned)tp[j].iy < (unsigned)H;
+            const bool r1  = (unsigned)(tp[j].iy + 1) < (unsigned)H;
+            const int  y0c = min(max(tp[j].iy, 0), H - 1);
+            const int  y1c = min(max(tp[j].iy + 1, 0), H - 1);
+            const size_t s0 = (size_t)y0c * W + ixc, s1 = (size_t)y1c * W + ixc;
+            const Pair2 p0 = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
+            const Pair2 p1 = *reinterpret_cast<const Pair2 *>(fa + 2 * s1);
+            const uint32_t q00 = ma[s0], q01 = ma[s0 + 1], q10 = ma[s1], q11 = ma[s1 + 1];
+            float u00, v00, u01, v01, u10, v10, u11, v11, a00, a01, a10, a11;
+            select_pair(p0, d, r0, u00, v00, u01, v01);
+            select_pair(p1, d, r1, u10, v10, u11, v11);
+            select_mask(q00, q01, d, r0, a00, a01);
+            select_mask(q10, q11, d, r1, a10, a11);
+            const C3Tap w = c3_weights<QUANT>(tp[j]);
+            su[j] = c3_blend(u00, u01, u10, u11, w);
+            sv[j] = c3_blend(v00, v01, v10, v11, w);
+            ok[j] = c3_valid<QUANT>(a00 != 0.0f, a01 != 0.0f, a10 != 0.0f, a11 != 0.0f, w);
+            if (STATS) st.amax_m = fmaxf(st.amax_m, a00 != 0.0f ? fmaxf(fabsf(u00), fabsf(v00)) : 0.0f);
+        }
+    }
+    c3_finish<STATS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
+}
+
+template <int QUANT, bool STATS>
+__global__ __launch_bounds__(256)
+void compose3_lds_kernel(const C3Args a)
+{
+    __shared__ float4 lds[kLdsCap];
+    __shared__ int    box[2][4];
+    if (threadIdx.x < 8) box[threadIdx.x >> 2][threadIdx.x & 3] = (threadIdx.x & 2) ? -0x7fffffff : 0x7fffffff;
+    __syncthreads();
+    const int nb  = gridDim.x;
+    const int per = nb >> 3;
+    int tile = (nb & 7) == 0 ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= a.ntiles) return;
+    C3Stat st = { 0.0f, 0.0f, 0.0f };
+    int cur_b = tile / a.tiles_per_field;
+    int parity = 0;
+    C3Stream in = c3_load_stream<kLdsLX>(a, tile);
+    while (true) {
+        const int next = tile + nb;
+        const bool more = next < a.ntiles;
+        C3Stream nxt;
+        if (more) nxt = c3_load_stream<kLdsLX>(a, next);     // prefetch across this tile's two barriers
+        c3_tile_lds<QUANT, STATS>(a, tile, in, st, lds, box[parity], box[parity ^ 1]);
         if (!more) break;
         if (STATS) {
             const int nb_ = next / a.tiles_per_field;
@@ -358,6 +575,7 @@ void compose3_kernel(const C3Args a)
         }
         in = nxt;
         tile = next;
+        parity ^= 1;
     }
     if (STATS) c3_flush_stats(a, cur_b, st);
 }
@@ -525,20 +743,29 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
 }
 
 // resident workgroups per CU of each compose3 instantiation (queried once per process)
-int c3_blocks_per_cu(int quant, bool with_stats)
+template <typename K>
+int c3_query_blocks(K kernel)
 {
-    static int cache[2][2] = { { 0, 0 }, { 0, 0 } };
-    int &v = cache[quant == OFL_QUANT_OPENCV ? 0 : 1][with_stats ? 1 : 0];
+    int n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 4; }
+    return n;
+}
+
+int c3_blocks_per_cu(int quant, bool with_stats, bool lds)
+{
+    static int cache[2][2][2] = { { { 0, 0 }, { 0, 0 } }, { { 0, 0 }, { 0, 0 } } };
+    const int q = quant == OFL_QUANT_OPENCV ? 0 : 1;
+    int &v = cache[q][with_stats ? 1 : 0][lds ? 1 : 0];
     if (v == 0) {
-        int n = 0;
-        hipError_t e;
-        if (quant == OFL_QUANT_OPENCV)
-            e = with_stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_OPENCV, true>, 256, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_OPENCV, false>, 256, 0);
-        else
-            e = with_stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_EXACT, true>, 256, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, compose3_kernel<OFL_QUANT_EXACT, false>, 256, 0);
-        if (e != hipSuccess) { (void)hipGetLastError(); n = 4; }
+        int n;
+        if (lds) {
+            if (q == 0) n = with_stats ? c3_query_blocks(compose3_lds_kernel<OFL_QUANT_OPENCV, true>) : c3_query_blocks(compose3_lds_kernel<OFL_QUANT_OPENCV, false>);
+            else        n = with_stats ? c3_query_blocks(compose3_lds_kernel<OFL_QUANT_EXACT, true>) : c3_query_blocks(compose3_lds_kernel<OFL_QUANT_EXACT, false>);
+        } else {
+            if (q == 0) n = with_stats ? c3_query_blocks(compose3_kernel<OFL_QUANT_OPENCV, true>) : c3_query_blocks(compose3_kernel<OFL_QUANT_OPENCV, false>);
+            else        n = with_stats ? c3_query_blocks(compose3_kernel<OFL_QUANT_EXACT, true>) : c3_query_blocks(compose3_kernel<OFL_QUANT_EXACT, false>);
+        }
         const char *env = getenv("OFL_C3_BLOCKS_PER_CU");      // tuning knob
         if (env && atoi(env) > 0) n = atoi(env);
         v = n < 1 ? 1 : (n > 8 ? 8 : n);
@@ -594,17 +821,21 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
     const float th = 1e-3f;   // DEFAULT_THRESHOLD, utils.py:22 (compared in float32)
 
     if (W % 2 == 0) {
-        const int tiles_x = (W + kC3TileW - 1) / kC3TileW, tiles_y = (H + kC3TileH - 1) / kC3TileH;
+        static const int ablate = getenv("OFL_C3_ABLATE") ? atoi(getenv("OFL_C3_ABLATE")) : 0;
+        static const int variant = getenv("OFL_C3_VARIANT") ? atoi(getenv("OFL_C3_VARIANT")) : 1;   // 0 direct, 1 LDS-staged
+        const bool use_lds = variant == 1;
+        const int tw = use_lds ? 4 * kLdsLX : kC3TileW, thh = use_lds ? 256 / kLdsLX : kC3TileH;
+        const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + thh - 1) / thh;
         const long long nt = (long long)tiles_x * tiles_y * batch;
         if (nt > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
-        static const int ablate = getenv("OFL_C3_ABLATE") ? atoi(getenv("OFL_C3_ABLATE")) : 0;
         C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, ablate };
         // persistent grid: what the chip keeps resident (a multiple of 8 = one share per XCD), or one
         // workgroup per tile when the problem is smaller than that
-        int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr);
+        int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr, use_lds);
         if (grid > (int)nt) grid = (int)nt;
         if (grid >= 8) grid &= ~7;
-#define OFL_C3(Q, S) hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a)
+#define OFL_C3(Q, S) do { if (use_lds) hipLaunchKernelGGL((compose3_lds_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
+                          else hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); } while (0)
         if (quant == OFL_QUANT_OPENCV) { if (stats) OFL_C3(OFL_QUANT_OPENCV, true); else OFL_C3(OFL_QUANT_OPENCV, false); }
         else                           { if (stats) OFL_C3(OFL_QUANT_EXACT, true);  else OFL_C3(OFL_QUANT_EXACT, false); }
 #undef OFL_C3

@@ -719,11 +719,183 @@ void gather_kernel(const T *__restrict__ src, int Crt, int H, int W,
     }
 }
 
+// K1, paired form (W even, C = 1..4): same lane mapping as K2 -- 128 x 8 tiles, each lane owns the pixel
+// pairs at x = 2*lx and x = 64 + 2*lx, so flow loads (16 B), image stores (2*C elements) and validity stores
+// (2 B) of a wave are contiguous -- and the same three wave-uniform paths (all samples outside / all
+// inside / border).  Numerics are those of gather_kernel (and of the oracle), element for element.
+template <typename T, int CT, bool INSIDE>
+__device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8_t *__restrict__ smask, int H, int W,
+                                          const Tap &tp, const int (&wi)[4], bool fixed_u8, int arith, int rule,
+                                          bool want_valid, T (&res)[CT], bool &ok)
+{
+    bool   in[4];
+    size_t off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yy = tp.iy + (k >> 1), xx = tp.ix + (k & 1);
+        in[k]  = INSIDE ? true : ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W);
+        off[k] = in[k] ? (size_t)yy * W + xx : 0;
+    }
+    typedef typename Acc<T>::type A;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        A v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = in[k] ? (A)src[off[k] * CT + c] : (A)0;
+        if constexpr (sizeof(T) == 8) {
+            res[c] = (T)blend4d(v[0], v[1], v[2], v[3], tp);
+        } else {
+            if (fixed_u8) {
+                const int acc = (int)v[0] * wi[0] + (int)v[1] * wi[1] + (int)v[2] * wi[2] + (int)v[3] * wi[3];
+                res[c] = (T)min(max((acc + (1 << 14)) >> 15, 0), 255);
+            } else {
+                res[c] = finish<T>(blend4((float)v[0], (float)v[1], (float)v[2], (float)v[3], tp), arith);
+            }
+        }
+    }
+    ok = false;
+    if (want_valid) {
+        int m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = in[k] ? (smask ? (smask[off[k]] != 0) : 1) : 0;
+        if (rule == OFL_RULE_GE_HALF) {
+            const int acc = m[0] * wi[0] + m[1] * wi[1] + m[2] * wi[2] + m[3] * wi[3];
+            ok = ((acc + (1 << 14)) >> 15) == 1;
+        } else {
+            const float sm = blend4((float)m[0], (float)m[1], (float)m[2], (float)m[3], tp);
+            ok = (rule == OFL_RULE_EQ1) ? (sm == 1.0f) : (cv_round(sm) == 1);
+        }
+    }
+}
+
+template <typename T, int CT>
+__global__ __launch_bounds__(256)
+void gather2_kernel(const T *__restrict__ src, int H, int W,
+                    const float *__restrict__ flow, int fH, int fW, int pad_top, int pad_left, int sign,
+                    const uint8_t *__restrict__ smask, const uint8_t *__restrict__ fmask,
+                    T *__restrict__ dst, uint8_t *__restrict__ valid,
+                    int quant, int arith, int rule, int tiles_x, int nblocks)
+{
+    const int tile = xcd_swizzle(blockIdx.x, nblocks);
+    const int ty   = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int lx   = threadIdx.x & 31, y = ty * 8 + (threadIdx.x >> 5);
+    const int xg[2] = { tx * 128 + 2 * lx, tx * 128 + 64 + 2 * lx };
+    const bool act[2] = { y < H && xg[0] < W, y < H && xg[1] < W };
+    const int  fy = y - pad_top;
+    const bool row_in_flow = (unsigned)fy < (unsigned)fH;
+    const bool aligned = ((pad_left | fW) & 1) == 0;          // 16-byte aligned flow pairs
+
+    float fu[4], fv[4];
+    bool  inf[4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int fx = xg[g] - pad_left;
+        inf[2 * g]     = act[g] && row_in_flow && (unsigned)fx < (unsigned)fW;
+        inf[2 * g + 1] = act[g] && row_in_flow && (unsigned)(fx + 1) < (unsigned)fW;
+        fu[2 * g] = fv[2 * g] = fu[2 * g + 1] = fv[2 * g + 1] = 0.0f;
+        if (aligned && inf[2 * g] && inf[2 * g + 1]) {
+            const float4 f = *reinterpret_cast<const float4 *>(flow + ((size_t)fy * fW + fx) * 2);
+            fu[2 * g] = f.x; fv[2 * g] = f.y; fu[2 * g + 1] = f.z; fv[2 * g + 1] = f.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (inf[2 * g + e]) {
+                    const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)fy * fW + fx + e) * 2);
+                    fu[2 * g + e] = f.x; fv[2 * g + e] = f.y;
+                }
+        }
+    }
+
+    Tap  tp[4];
+    int  wi[4][4];
+    bool inside = true, outside = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float px = map_coord(xg[j >> 1] + (j & 1), fu[j], sign), py = map_coord(y, fv[j], sign);
+        tp[j] = (quant == OFL_QUANT_OPENCV) ? make_tap<OFL_QUANT_OPENCV>(px, py) : make_tap<OFL_QUANT_EXACT>(px, py);
+        if (quant == OFL_QUANT_OPENCV) {
+            wi[j][0] = (32 - tp[j].ay) * (32 - tp[j].ax) * 32; wi[j][1] = (32 - tp[j].ay) * tp[j].ax * 32;
+            wi[j][2] = tp[j].ay * (32 - tp[j].ax) * 32;        wi[j][3] = tp[j].ay * tp[j].ax * 32;
+        } else {
+            wi[j][0] = __float2int_rn(tp[j].w0 * 32768.0f); wi[j][1] = __float2int_rn(tp[j].w1 * 32768.0f);
+            wi[j][2] = __float2int_rn(tp[j].w2 * 32768.0f); wi[j][3] = __float2int_rn(tp[j].w3 * 32768.0f);
+        }
+        const bool in_j  = (unsigned)tp[j].ix <= (unsigned)(W - 2) && (unsigned)tp[j].iy <= (unsigned)(H - 2);
+        const bool out_j = tp[j].ix < -1 || tp[j].ix >= W || tp[j].iy < -1 || tp[j].iy >= H;
+        inside  = inside && (in_j || !act[j >> 1]);
+        outside = outside && (out_j || !act[j >> 1]);
+    }
+    if (H < 2) inside = false;
+    const bool fixed_u8 = (sizeof(T) == 1) && arith == OFL_ARITH_NATIVE;
+    const bool want_valid = valid != nullptr;
+
+    T    res[4][CT];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ok[j] = false;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) res[j][c] = (T)0;
+    }
+    if (__all(outside)) {
+        // nothing to fetch: every tap of every pixel of this wave is outside the source
+    } else if (__all(inside)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (act[j >> 1]) gather_px<T, CT, true>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (act[j >> 1]) gather_px<T, CT, false>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
+    }
+
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!act[g]) continue;
+        const size_t o = (size_t)y * W + xg[g];
+        T *d = dst + o * CT;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) d[e * CT + c] = res[2 * g + e][c];
+        if (want_valid) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                bool v = ok[2 * g + e];
+                if (fmask) {
+                    const int fx = xg[g] + e - pad_left;
+                    v = v && inf[2 * g + e] && fmask[(size_t)fy * fW + fx] != 0;
+                }
+                m |= (v ? 1u : 0u) << (8 * e);
+            }
+            *reinterpret_cast<uint16_t *>(valid + o) = (uint16_t)m;
+        }
+    }
+}
+
 template <typename T>
 int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int fH, int fW, int pad_top,
                     int pad_left, int sign, const uint8_t *smask, const uint8_t *fmask, void *dst,
                     uint8_t *valid, int quant, int arith, int rule, hipStream_t s)
 {
+    if (W % 2 == 0 && C >= 1 && C <= 4) {
+        const int tiles_x = (W + 127) / 128, tiles_y = (H + 7) / 8;
+        const int nblocks = tiles_x * tiles_y;
+#define OFL_GATHER2_LAUNCH(CT)                                                                           \
+        hipLaunchKernelGGL((gather2_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, H, W, \
+                           flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,   \
+                           arith, rule, tiles_x, nblocks)
+        switch (C) {
+        case 1: OFL_GATHER2_LAUNCH(1); break;
+        case 2: OFL_GATHER2_LAUNCH(2); break;
+        case 3: OFL_GATHER2_LAUNCH(3); break;
+        default: OFL_GATHER2_LAUNCH(4); break;
+        }
+#undef OFL_GATHER2_LAUNCH
+        OFL_HIP(hipGetLastError());
+        return OFL_OK;
+    }
     const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
     const int nblocks = tiles_x * tiles_y;
 #define OFL_GATHER_LAUNCH(CT)                                                                          \
@@ -822,7 +994,7 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
 
     if (W % 2 == 0) {
         static const int ablate = getenv("OFL_C3_ABLATE") ? atoi(getenv("OFL_C3_ABLATE")) : 0;
-        static const int variant = getenv("OFL_C3_VARIANT") ? atoi(getenv("OFL_C3_VARIANT")) : 1;   // 0 direct, 1 LDS-staged
+        static const int variant = getenv("OFL_C3_VARIANT") ? atoi(getenv("OFL_C3_VARIANT")) : 0;   // 0 direct (default), 1 LDS-staged (rotated sampling grids)
         const bool use_lds = variant == 1;
         const int tw = use_lds ? 4 * kLdsLX : kC3TileW, thh = use_lds ? 256 / kLdsLX : kC3TileH;
         const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + thh - 1) / thh;

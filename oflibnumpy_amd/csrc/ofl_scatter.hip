@@ -22,6 +22,7 @@
 // node -- all L2-friendly because owner triangles of neighbouring nodes are neighbours in memory.
 #include "ofl_common.h"
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 #include <vector>
 
@@ -189,6 +190,21 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
         if (threadIdx.x == 0 && block_sum)
             atomicAdd(&ws.kept_slots[(blockIdx.y * gridDim.x + blockIdx.x) & 255], (unsigned long long)block_sum);
     }
+    // Convex-hull candidates: kept points on the border of the kept mesh (image border, or a dropped
+    // neighbour); corners of folded cells are added further down.  Every vertex of the convex hull of the
+    // kept points is among them; interior points of a properly embedded mesh never are.
+    if (x < W && y < H && (!pmask || pmask[(size_t)y * W + x])) {
+        bool cand = (x == 0 || y == 0 || x == W - 1 || y == H - 1);
+        if (!cand && pmask) {
+            for (int dy = -1; dy <= 1 && !cand; ++dy)
+                for (int dx = -1; dx <= 1 && !cand; ++dx)
+                    cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
+        }
+        if (cand) {
+            const unsigned long long slot = atomicAdd(&ws.counters[3], 1ull);
+            if (slot < (unsigned long long)ws.cand_cap) ws.cand[slot] = point_of(flow, sign, W, x, y);
+        }
+    }
     if (x >= cw || y >= ch) return;
     const size_t i00 = (size_t)y * W + x;
     bool k0 = true, k1 = true, k2 = true, k3 = true;
@@ -236,30 +252,6 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
             for (int gx = b.x0; gx <= b.x1; ++gx)
                 if (tri_inside(te, (double)gx, (double)gy))
                     atomicMin(&ws.owner[(size_t)gy * W + gx], id);
-    }
-}
-
-// Convex-hull candidates: kept points that sit on the border of the kept mesh (a neighbour is missing);
-// corners of cells that are not properly oriented (folded mesh) are added by the raster pass.  Every
-// vertex of the convex hull of the kept points is among them; interior points of a properly embedded
-// mesh never are.
-__global__ __launch_bounds__(256)
-void scatter_boundary_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
-                             int H, int W, ScatterWs ws)
-{
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    if (pmask && !pmask[(size_t)y * W + x]) return;
-    bool cand = (x == 0 || y == 0 || x == W - 1 || y == H - 1);
-    if (!cand && pmask) {
-        for (int dy = -1; dy <= 1 && !cand; ++dy)
-            for (int dx = -1; dx <= 1 && !cand; ++dx)
-                cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
-    }
-    if (cand) {
-        const unsigned long long slot = atomicAdd(&ws.counters[3], 1ull);
-        if (slot < (unsigned long long)ws.cand_cap) ws.cand[slot] = point_of(flow, sign, W, x, y);
     }
 }
 
@@ -471,18 +463,21 @@ int cand_cap_for(int H, int W)
     return (int)(n < kCandCap ? n : kCandCap);
 }
 
+constexpr size_t kHeadBytes  = 256 + 256 * sizeof(unsigned long long);   // counters + kept-point slots
+constexpr int    kFirstCand  = 16384;                                     // candidates fetched with the header
+
 ScatterWs carve(void *workspace, int H, int W)
 {
     ScatterWs ws;
     char *p = (char *)workspace;
     ws.cand_cap = cand_cap_for(H, W);
-    ws.owner = (uint32_t *)p;            p += align_up((size_t)H * W * 4, 256);
-    ws.big = (uint32_t *)p;              p += align_up((size_t)kBigCap * 4, 256);
-    ws.cand = (D2 *)p;                   p += align_up((size_t)ws.cand_cap * sizeof(D2), 256);
-    ws.lower = (D2 *)p;                  p += align_up((size_t)kHullCap * sizeof(D2), 256);
-    ws.upper = (D2 *)p;                  p += align_up((size_t)kHullCap * sizeof(D2), 256);
-    ws.counters = (unsigned long long *)p;   p += 256;
-    ws.kept_slots = (unsigned long long *)p;
+    ws.counters = (unsigned long long *)p;   p += 256;                 // header, slots and candidates are
+    ws.kept_slots = (unsigned long long *)p; p += 256 * sizeof(unsigned long long);   // contiguous: ONE read-back
+    ws.cand = (D2 *)p;                       p += align_up((size_t)ws.cand_cap * sizeof(D2), 256);
+    ws.lower = (D2 *)p;                      p += (size_t)kHullCap * sizeof(D2);      // lower | upper contiguous:
+    ws.upper = (D2 *)p;                      p += (size_t)kHullCap * sizeof(D2);      // ONE upload
+    ws.big = (uint32_t *)p;                  p += align_up((size_t)kBigCap * 4, 256);
+    ws.owner = (uint32_t *)p;
     return ws;
 }
 
@@ -490,17 +485,53 @@ ScatterWs carve(void *workspace, int H, int W)
 // containing the two extreme-x end points.
 void convex_chains(std::vector<D2> &pts, std::vector<D2> &lower, std::vector<D2> &upper)
 {
-    std::sort(pts.begin(), pts.end(), [](const D2 &a, const D2 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+    // sort by (x, y): counting sort into ~n/4 x-buckets, then tiny std::sorts -- the candidates are a few
+    // thousand points spread evenly along the mesh border, a comparison sort of all of them costs ~0.5 ms
+    const size_t n = pts.size();
+    double xmin = pts[0].x, xmax = pts[0].x;
+    for (const D2 &p : pts) { xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x); }
+    const size_t nb = std::max<size_t>(1, n / 4);
+    const double scale = xmax > xmin ? (double)(nb - 1) / (xmax - xmin) : 0.0;
+    std::vector<uint32_t> start(nb + 1, 0);
+    std::vector<uint32_t> key(n);
+    for (size_t i = 0; i < n; ++i) {
+        size_t b = (size_t)((pts[i].x - xmin) * scale);
+        if (b >= nb) b = nb - 1;
+        key[i] = (uint32_t)b;
+        ++start[b + 1];
+    }
+    for (size_t b = 0; b < nb; ++b) start[b + 1] += start[b];
+    std::vector<D2> sorted(n);
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < n; ++i) sorted[fill[key[i]]++] = pts[i];
+    auto less = [](const D2 &a, const D2 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); };
+    for (size_t b = 0; b < nb; ++b)
+        if (start[b + 1] - start[b] > 1) std::sort(sorted.begin() + start[b], sorted.begin() + start[b + 1], less);
     auto cross = [](const D2 &o, const D2 &a, const D2 &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
     lower.clear(); upper.clear();
-    for (const D2 &p : pts) {          // smallest y at every x
+    for (const D2 &p : sorted) {       // smallest y at every x
         while (lower.size() >= 2 && cross(lower[lower.size() - 2], lower.back(), p) <= 0) lower.pop_back();
         lower.push_back(p);
     }
-    for (const D2 &p : pts) {          // largest y at every x
+    for (const D2 &p : sorted) {       // largest y at every x
         while (upper.size() >= 2 && cross(upper[upper.size() - 2], upper.back(), p) >= 0) upper.pop_back();
         upper.push_back(p);
     }
+}
+
+// pinned host staging shared by the scatter calls of this process (guarded by a mutex; the event marks
+// the completion of the last upload that read from it)
+struct HostStage {
+    std::mutex lock;
+    char      *buf = nullptr;
+    hipEvent_t done = nullptr;
+    size_t     bytes = 0;
+};
+
+HostStage &host_stage()
+{
+    static HostStage h;
+    return h;
 }
 
 }  // namespace
@@ -512,9 +543,8 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
     (void)C;
     if (!bytes) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: NULL");
     if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: bad shape");
-    *bytes = align_up((size_t)H * W * 4, 256) + align_up((size_t)kBigCap * 4, 256) +
-             align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * align_up((size_t)kHullCap * sizeof(D2), 256) +
-             256 + 256 * sizeof(unsigned long long);
+    *bytes = kHeadBytes + align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * (size_t)kHullCap * sizeof(D2) +
+             align_up((size_t)kBigCap * 4, 256) + align_up((size_t)H * W * 4, 256);
     return OFL_OK;
 }
 
@@ -539,7 +569,7 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     hipStream_t s = stream_of(stream);
     ScatterWs ws = carve(workspace, H, W);
     OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)H * W * 4, s));
-    OFL_HIP(hipMemsetAsync(ws.counters, 0, 256 + 256 * sizeof(unsigned long long), s));
+    OFL_HIP(hipMemsetAsync(ws.counters, 0, kHeadBytes, s));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_raster_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
     OFL_HIP(hipGetLastError());
@@ -547,13 +577,24 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     // always enqueued with a modest grid and returns immediately when there is nothing to do
     hipLaunchKernelGGL(scatter_big_kernel, dim3(rt().n_cu * 4), block, 0, s, flow, sign, H, W, ws);
     OFL_HIP(hipGetLastError());
-    // convex hull of the kept points: candidates from the device, monotone chain on the host.  This is
-    // the one place where the scatter path synchronises the stream (a few thousand points).
-    hipLaunchKernelGGL(scatter_boundary_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
-    OFL_HIP(hipGetLastError());
-    unsigned long long cbuf[32 + 256];
-    OFL_HIP(hipMemcpyAsync(cbuf, ws.counters, sizeof(cbuf), hipMemcpyDeviceToHost, s));
+    // Convex hull of the kept points: candidates from the device, monotone chain on the host.  This is the
+    // one place where the scatter path synchronises the stream: ONE read-back (header + first candidates)
+    // into pinned memory, asynchronous uploads of the two chains.
+    HostStage &hs = host_stage();
+    std::lock_guard<std::mutex> guard(hs.lock);
+    const size_t first_bytes = kHeadBytes + (size_t)kFirstCand * sizeof(D2);
+    const size_t stage_bytes = first_bytes + 2 * (size_t)kHullCap * sizeof(D2);
+    if (!hs.buf) {
+        OFL_HIP(hipHostMalloc((void **)&hs.buf, stage_bytes, hipHostMallocDefault));
+        OFL_HIP(hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+        hs.bytes = stage_bytes;
+    } else {
+        OFL_HIP(hipEventSynchronize(hs.done));          // the previous call's upload has left the buffer
+    }
+    const size_t avail = kHeadBytes + (size_t)std::min(ws.cand_cap, kFirstCand) * sizeof(D2);
+    OFL_HIP(hipMemcpyAsync(hs.buf, ws.counters, avail, hipMemcpyDeviceToHost, s));
     OFL_HIP(hipStreamSynchronize(s));
+    const unsigned long long *cbuf = (const unsigned long long *)hs.buf;
     unsigned long long c[4] = { 0, cbuf[1], cbuf[2], cbuf[3] };
     for (int k = 0; k < 256; ++k) c[0] += cbuf[32 + k];
     if (info_host) {
@@ -567,15 +608,22 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     HullRef hull = { ws.lower, ws.upper, 0, 0 };
     if (c[3] >= 3 && c[3] <= (unsigned long long)ws.cand_cap) {
         std::vector<D2> pts((size_t)c[3]), lower, upper;
-        OFL_HIP(hipMemcpy(pts.data(), ws.cand, pts.size() * sizeof(D2), hipMemcpyDeviceToHost));
+        const size_t have = std::min<size_t>(pts.size(), (size_t)kFirstCand);
+        memcpy(pts.data(), hs.buf + kHeadBytes, have * sizeof(D2));
+        if (pts.size() > have)      // rare: more candidates than came with the header
+            OFL_HIP(hipMemcpy(pts.data() + have, ws.cand + have, (pts.size() - have) * sizeof(D2), hipMemcpyDeviceToHost));
         convex_chains(pts, lower, upper);
         if (lower.size() >= 2 && upper.size() >= 2 && lower.size() <= (size_t)kHullCap && upper.size() <= (size_t)kHullCap) {
-            OFL_HIP(hipMemcpy(ws.lower, lower.data(), lower.size() * sizeof(D2), hipMemcpyHostToDevice));
-            OFL_HIP(hipMemcpy(ws.upper, upper.data(), upper.size() * sizeof(D2), hipMemcpyHostToDevice));
+            char *up = hs.buf + first_bytes;
+            memcpy(up, lower.data(), lower.size() * sizeof(D2));
+            memcpy(up + (size_t)kHullCap * sizeof(D2), upper.data(), upper.size() * sizeof(D2));
+            OFL_HIP(hipMemcpyAsync(ws.lower, up, lower.size() * sizeof(D2), hipMemcpyHostToDevice, s));
+            OFL_HIP(hipMemcpyAsync(ws.upper, up + (size_t)kHullCap * sizeof(D2), upper.size() * sizeof(D2), hipMemcpyHostToDevice, s));
             hull.n_lower = (int)lower.size();
             hull.n_upper = (int)upper.size();
         }
     }
+    OFL_HIP(hipEventRecord(hs.done, s));
     hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
                        out, valid, valid_rule, ws, hull);
     OFL_HIP(hipGetLastError());

@@ -191,6 +191,20 @@ int ofl_scatter_linear(const float *flow, int sign, int point_precision, const u
                        const float *vals, int C, const uint8_t *vmask, int H, int W,
                        const float *query, float *out, uint8_t *valid, int valid_rule);
 
+/* ------------------------------------------------------------------ sparse point tracking (next tier)
+ * track_pts, utils.py:547-622:
+ *   ofl_sample_points_dev   'ref s' default: bilinear_interpolation(flow[..., ::-1], pts) utils.py:161-196, float64,
+ *                           pts_rc / out_rc are [n][2] in (row, col) order; points must lie inside the field
+ *   ofl_scatter_query_dev   'ref t' (utils.py:610-615) and s_exact_mode (:599-603): griddata(points, values, pts):
+ *                           same triangulation as ofl_scatter_linear_dev, evaluated at n_query float64 points
+ *                           query_xy [n][2] = (x, y); out float64 [n][C]; found[i] = 0 where griddata gives NaN
+ */
+int ofl_sample_points_dev(const float *flow, int H, int W, const double *pts_rc, size_t n, double *out_rc, void *stream);
+int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                          const float *vals, int C, int H, int W,
+                          const double *query_xy, size_t n_query, double *out, uint8_t *found,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* small device helpers of the flow algebra:
  *   ofl_mask_and_dev     out = a & b                      (flow_class.py:643)
  *   ofl_grid_offset_dev  out[y][x] = float32((x, y) + sign * vecs[y][x])   (flow_class.py:1398-1406)

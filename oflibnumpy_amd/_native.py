@@ -69,6 +69,8 @@ SIGNATURES = {
     "ofl_scatter_linear_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_workspace_bytes": (_ci, [_ci, _ci, _ci, ctypes.POINTER(_cs)]),
     "ofl_scatter_linear": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci]),
+    "ofl_sample_points_dev": (_ci, [_vp, _ci, _ci, _vp, _cs, _vp, _vp]),
+    "ofl_scatter_query_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _cs, _vp, _vp, _vp, _cs, _vp]),
     "ofl_mask_and_dev": (_ci, [_vp, _vp, _vp, _cs, _vp]),
     "ofl_grid_offset_dev": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
     "ofl_comm_unique_id": (_ci, [_vp]),

@@ -351,6 +351,90 @@ void scatter_big_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     }
 }
 
+// Triangle containing an arbitrary query point: seed = owner of the nearest grid node (or a neighbour),
+// then the 3 x 3 cells around the seed's cell are tested with SciPy's inclusion rule.
+__device__ __forceinline__ bool locate_query(const float *flow, int sign, const uint8_t *pmask, int H, int W,
+                                             const ScatterWs &ws, double qx, double qy, uint32_t &id,
+                                             size_t (&vi)[3], D2 (&vp)[3], double &c0, double &c1, double &c2)
+{
+    if (!(qx >= -1.0 && qx <= (double)W && qy >= -1.0 && qy <= (double)H)) return false;
+    const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
+    uint32_t seed = kNoOwner;
+    for (int dy = 0; dy <= 1 && seed == kNoOwner; ++dy)
+        for (int dx = 0; dx <= 1 && seed == kNoOwner; ++dx) {
+            const int sx = min(max(nx + (dx ? (qx < nx ? -1 : 1) : 0), 0), W - 1);
+            const int sy = min(max(ny + (dy ? (qy < ny ? -1 : 1) : 0), 0), H - 1);
+            seed = ws.owner[(size_t)sy * W + sx];
+        }
+    if (seed == kNoOwner) return false;
+    const int cw = W - 1, chh = H - 1;
+    const uint32_t cell = seed >> 2;
+    const int sy = (int)(cell / (uint32_t)cw), sx = (int)(cell - (uint32_t)sy * (uint32_t)cw);
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int cx = sx + dx, cy = sy + dy;
+            if (cx < 0 || cy < 0 || cx >= cw || cy >= chh) continue;
+            const size_t i00 = (size_t)cy * W + cx;
+            bool k0 = true, k1 = true, k2 = true, k3 = true;
+            if (pmask) {
+                k0 = pmask[i00] != 0; k1 = pmask[i00 + 1] != 0;
+                k2 = pmask[i00 + W + 1] != 0; k3 = pmask[i00 + W] != 0;
+            }
+            const int n_keep = (int)k0 + (int)k1 + (int)k2 + (int)k3;
+            if (n_keep < 3) continue;
+            const D2 pa = point_of(flow, sign, W, cx, cy), pb = point_of(flow, sign, W, cx + 1, cy);
+            const D2 pc = point_of(flow, sign, W, cx + 1, cy + 1), pd = point_of(flow, sign, W, cx, cy + 1);
+            const int diag = n_keep == 4 ? pick_diagonal(pa, pb, pc, pd) : ((!k0 || !k2) ? 1 : 0);
+            for (int t = 0; t < 2; ++t) {
+                int i0, i1, i2;
+                tri_corners(diag, t, i0, i1, i2);
+                if (!(pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3))) continue;
+                if (bary(pick4(i0, pa, pb, pc, pd), pick4(i1, pa, pb, pc, pd), pick4(i2, pa, pb, pc, pd), qx, qy, c0, c1, c2)) {
+                    id = tri_id((uint32_t)(cy * cw + cx), diag, t);
+                    tri_decode(id, flow, sign, W, vi, vp);
+                    return true;
+                }
+            }
+        }
+    return false;
+}
+
+// Gap fill shared by the dense and the sparse pass (see scatter_resolve_kernel).
+__device__ __forceinline__ bool fill_from_nearest(const float *flow, int sign, int H, int W, const ScatterWs &ws,
+                                                  const HullRef &hull, double qx, double qy, uint32_t &id,
+                                                  size_t (&vi)[3], D2 (&vp)[3], double &c0, double &c1, double &c2)
+{
+    if (!(hull.n_lower > 0 && inside_hull(hull, qx, qy))) return false;
+    const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
+    id = nearest_owner(ws.owner, H, W, nx, ny, qx, qy);
+    if (id == kNoOwner) return false;
+    tri_decode(id, flow, sign, W, vi, vp);
+    (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
+    const double e1x = vp[1].x - vp[0].x, e1y = vp[1].y - vp[0].y, e2x = vp[2].x - vp[0].x, e2y = vp[2].y - vp[0].y;
+    return (e1x * e2y - e1y * e2x) != 0.0;
+}
+
+// pass 2 for sparse query points (one thread per point, float64 in and out)
+__global__ __launch_bounds__(256)
+void scatter_query_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
+                          const float *__restrict__ vals, int C, int H, int W,
+                          const double *__restrict__ query_xy, size_t n_query,
+                          double *__restrict__ out, uint8_t *__restrict__ found_out, ScatterWs ws, HullRef hull)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_query; i += (size_t)gridDim.x * blockDim.x) {
+        const double qx = query_xy[2 * i], qy = query_xy[2 * i + 1];
+        uint32_t id = kNoOwner;
+        size_t vi[3];
+        D2 vp[3];
+        double c0 = 0, c1 = 0, c2 = 0;
+        bool found = locate_query(flow, sign, pmask, H, W, ws, qx, qy, id, vi, vp, c0, c1, c2);
+        if (!found) found = fill_from_nearest(flow, sign, H, W, ws, hull, qx, qy, id, vi, vp, c0, c1, c2);
+        for (int c = 0; c < C; ++c)
+            out[i * C + c] = found ? c0 * (double)vals[vi[0] * C + c] + c1 * (double)vals[vi[1] * C + c] + c2 * (double)vals[vi[2] * C + c] : 0.0;
+        found_out[i] = found ? 1 : 0;
+    }
+}
+
 // pass 2: interpolate.  query == NULL: node (x, y) itself; otherwise the triangle containing the
 // query point is searched in the 3 x 3 cells around the owner of the nearest node.
 __global__ __launch_bounds__(256)
@@ -380,63 +464,13 @@ void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint
     } else {
         const float2 q = *reinterpret_cast<const float2 *>(query + o * 2);
         qx = (double)q.x; qy = (double)q.y;
-        // seed: owner of the nearest grid node (or one of its neighbours)
-        const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
-        uint32_t seed = kNoOwner;
-        if (qx >= -1.0 && qx <= (double)W && qy >= -1.0 && qy <= (double)H) {
-            for (int dy = 0; dy <= 1 && seed == kNoOwner; ++dy)
-                for (int dx = 0; dx <= 1 && seed == kNoOwner; ++dx) {
-                    const int sx = min(max(nx + (dx ? (qx < nx ? -1 : 1) : 0), 0), W - 1);
-                    const int sy = min(max(ny + (dy ? (qy < ny ? -1 : 1) : 0), 0), H - 1);
-                    seed = ws.owner[(size_t)sy * W + sx];
-                }
-        }
-        if (seed != kNoOwner) {
-            const int cw = W - 1, chh = H - 1;
-            const uint32_t cell = seed >> 2;
-            const int sy = (int)(cell / (uint32_t)cw), sx = (int)(cell - (uint32_t)sy * (uint32_t)cw);
-            for (int dy = -1; dy <= 1 && !found; ++dy)
-                for (int dx = -1; dx <= 1 && !found; ++dx) {
-                    const int cx = sx + dx, cy = sy + dy;
-                    if (cx < 0 || cy < 0 || cx >= cw || cy >= chh) continue;
-                    const size_t i00 = (size_t)cy * W + cx;
-                    bool k0 = true, k1 = true, k2 = true, k3 = true;
-                    if (pmask) {
-                        k0 = pmask[i00] != 0; k1 = pmask[i00 + 1] != 0;
-                        k2 = pmask[i00 + W + 1] != 0; k3 = pmask[i00 + W] != 0;
-                    }
-                    const int n_keep = (int)k0 + (int)k1 + (int)k2 + (int)k3;
-                    if (n_keep < 3) continue;
-                    const D2 pa = point_of(flow, sign, W, cx, cy), pb = point_of(flow, sign, W, cx + 1, cy);
-                    const D2 pc = point_of(flow, sign, W, cx + 1, cy + 1), pd = point_of(flow, sign, W, cx, cy + 1);
-                    const int diag = n_keep == 4 ? pick_diagonal(pa, pb, pc, pd) : ((!k0 || !k2) ? 1 : 0);
-                    for (int t = 0; t < 2 && !found; ++t) {
-                        int i0, i1, i2;
-                        tri_corners(diag, t, i0, i1, i2);
-                        if (!(pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3))) continue;
-                        if (bary(pick4(i0, pa, pb, pc, pd), pick4(i1, pa, pb, pc, pd), pick4(i2, pa, pb, pc, pd), qx, qy, c0, c1, c2)) {
-                            found = true;
-                            id = tri_id((uint32_t)(cy * cw + cx), diag, t);
-                            tri_decode(id, flow, sign, W, vi, vp);
-                        }
-                    }
-                }
-        }
+        found = locate_query(flow, sign, pmask, H, W, ws, qx, qy, id, vi, vp, c0, c1, c2);
     }
-    if (!found && hull.n_lower > 0 && inside_hull(hull, qx, qy)) {
-        // Inside the convex hull of the kept points but not covered by a cell triangle: SciPy's Delaunay
-        // triangulation spans such gaps (ragged / curved mesh borders, holes left by dropped points) with
-        // triangles between border vertices.  The linear function of the nearest cell triangle is
-        // continued instead -- identical for data that is affine across the gap.
-        const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
-        id = nearest_owner(ws.owner, H, W, nx, ny, qx, qy);
-        if (id != kNoOwner) {
-            tri_decode(id, flow, sign, W, vi, vp);
-            (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
-            const double e1x = vp[1].x - vp[0].x, e1y = vp[1].y - vp[0].y, e2x = vp[2].x - vp[0].x, e2y = vp[2].y - vp[0].y;
-            found = (e1x * e2y - e1y * e2x) != 0.0;
-        }
-    }
+    // Inside the convex hull of the kept points but not covered by a cell triangle: SciPy's Delaunay
+    // triangulation spans such gaps (ragged / curved mesh borders, holes left by dropped points) with
+    // triangles between border vertices.  The linear function of the nearest cell triangle is
+    // continued instead -- identical for data that is affine across the gap.
+    if (!found) found = fill_from_nearest(flow, sign, H, W, ws, hull, qx, qy, id, vi, vp, c0, c1, c2);
     if (!found) {
         for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;          // NaN -> 0, utils.py:254 / fill_value=0
         if (valid) valid[o] = 0;
@@ -548,26 +582,23 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
     return OFL_OK;
 }
 
-int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
-                           const float *vals, int C, const uint8_t *vmask, int H, int W,
-                           const float *query, float *out, uint8_t *valid, int valid_rule,
-                           void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
+}  // extern "C"
+
+namespace {
+
+// Passes 1, 1b and the hull: everything the interpolation passes need.  `sign` arrives with the point
+// precision already folded in (+-1 / +-2).
+int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, int W,
+                    void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s,
+                    ScatterWs &ws, HullRef &hull)
 {
-    OFL_TRY(need_device());
     if (!flow || !workspace) return fail(OFL_E_INVALID, "ofl_scatter_linear: NULL pointer");
     if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 29))
         return fail(OFL_E_INVALID, "ofl_scatter_linear: H*W must be in [1, 2^29)");
-    if (C < 0 || (C > 0 && (!vals || !out))) return fail(OFL_E_INVALID, "ofl_scatter_linear: C > 0 needs vals and out");
-    if (C == 0 && !valid) return fail(OFL_E_INVALID, "ofl_scatter_linear: nothing to compute");
-    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_linear: sign must be +1 or -1");
-    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad point_precision");
-    if (point_precision == 1) sign *= 2;
-    if (valid_rule != 0 && valid_rule != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
     size_t need = 0;
-    OFL_TRY(ofl_scatter_workspace_bytes(H, W, C, &need));
+    OFL_TRY(ofl_scatter_workspace_bytes(H, W, 0, &need));
     if (workspace_bytes < need) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small (%zu < %zu)", workspace_bytes, need);
-    hipStream_t s = stream_of(stream);
-    ScatterWs ws = carve(workspace, H, W);
+    ws = carve(workspace, H, W);
     OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)H * W * 4, s));
     OFL_HIP(hipMemsetAsync(ws.counters, 0, kHeadBytes, s));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
@@ -605,7 +636,7 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     if (pmask && c[0] == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
     if (c[1] > (unsigned long long)kBigCap)
         return fail(OFL_E_INVALID, "ofl_scatter_linear: %llu triangles exceed the large-triangle list (%d): flow too irregular", c[1], kBigCap);
-    HullRef hull = { ws.lower, ws.upper, 0, 0 };
+    hull = HullRef{ ws.lower, ws.upper, 0, 0 };
     if (c[3] >= 3 && c[3] <= (unsigned long long)ws.cand_cap) {
         std::vector<D2> pts((size_t)c[3]), lower, upper;
         const size_t have = std::min<size_t>(pts.size(), (size_t)kFirstCand);
@@ -624,8 +655,57 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
         }
     }
     OFL_HIP(hipEventRecord(hs.done, s));
+    return OFL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                           const float *vals, int C, const uint8_t *vmask, int H, int W,
+                           const float *query, float *out, uint8_t *valid, int valid_rule,
+                           void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
+{
+    OFL_TRY(need_device());
+    if (C < 0 || (C > 0 && (!vals || !out))) return fail(OFL_E_INVALID, "ofl_scatter_linear: C > 0 needs vals and out");
+    if (C == 0 && !valid) return fail(OFL_E_INVALID, "ofl_scatter_linear: nothing to compute");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_linear: sign must be +1 or -1");
+    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad point_precision");
+    if (point_precision == 1) sign *= 2;
+    if (valid_rule != 0 && valid_rule != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
+    hipStream_t s = stream_of(stream);
+    ScatterWs ws;
+    HullRef hull;
+    OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull));
+    const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
                        out, valid, valid_rule, ws, hull);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+// Sparse queries (point tracking, utils.py:610-615): the triangle containing each of n_query points
+// (x, y in float64) is located through the owner map; out[i][0..C) in float64, found[i] = 0 where the
+// reference's griddata returns NaN.
+int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                          const float *vals, int C, int H, int W,
+                          const double *query_xy, size_t n_query, double *out, uint8_t *found,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    OFL_TRY(need_device());
+    if (C <= 0 || !vals || !out || !found || !query_xy) return fail(OFL_E_INVALID, "ofl_scatter_query: NULL pointer / C <= 0");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_query: sign must be +1 or -1");
+    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_query: bad point_precision");
+    if (point_precision == 1) sign *= 2;
+    hipStream_t s = stream_of(stream);
+    ScatterWs ws;
+    HullRef hull;
+    OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, nullptr, s, ws, hull));
+    if (n_query == 0) return OFL_OK;
+    const size_t nb = (n_query + 255) / 256;
+    hipLaunchKernelGGL(scatter_query_kernel, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, s,
+                       flow, sign, pmask, vals, C, H, W, query_xy, n_query, out, found, ws, hull);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

@@ -111,6 +111,29 @@ void grid_offset_kernel(const float *__restrict__ vecs, int sign, int H, int W, 
     }
 }
 
+// Sparse bilinear sampling of a flow field at float64 points (row, col), restating the reference's
+// bilinear_interpolation(flow[..., ::-1], pts) (utils.py:161-196) in float64, INCLUDING its pairing of the
+// (ver1, hor0) sample with the (ver0, hor1) weight and vice versa.  out[i] = (v, u) interpolated.
+__global__ __launch_bounds__(256)
+void sample_points_kernel(const float *__restrict__ flow, int H, int W, const double *__restrict__ pts, size_t n,
+                          double *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double ver = pts[2 * i], hor = pts[2 * i + 1];
+        const int v0 = (int)floor(ver), h0 = (int)floor(hor);
+        const int v0c = min(max(v0, 0), H - 1), h0c = min(max(h0, 0), W - 1);
+        const int v1c = min(max(v0 + 1, 0), H - 1), h1c = min(max(h0 + 1, 0), W - 1);
+        const double w_a = ((double)v1c - ver) * ((double)h1c - hor), w_b = ((double)v1c - ver) * (hor - (double)h0c);
+        const double w_c = (ver - (double)v0c) * ((double)h1c - hor), w_d = (ver - (double)v0c) * (hor - (double)h0c);
+        const float2 da = reinterpret_cast<const float2 *>(flow)[(size_t)v0c * W + h0c];
+        const float2 db = reinterpret_cast<const float2 *>(flow)[(size_t)v1c * W + h0c];
+        const float2 dc = reinterpret_cast<const float2 *>(flow)[(size_t)v0c * W + h1c];
+        const float2 dd = reinterpret_cast<const float2 *>(flow)[(size_t)v1c * W + h1c];
+        out[2 * i]     = ((w_a * (double)da.y + w_b * (double)db.y) + w_c * (double)dc.y) + w_d * (double)dd.y;
+        out[2 * i + 1] = ((w_a * (double)da.x + w_b * (double)db.x) + w_c * (double)dc.x) + w_d * (double)dd.x;
+    }
+}
+
 int stream_grid(size_t n_items)
 {
     size_t nb = (n_items + 255) / 256;
@@ -167,6 +190,16 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
     if (n_px == 0) return OFL_OK;
     hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n_px / 2)), dim3(256), 0, stream_of(stream),
                        a, ma, b, mb, alpha, n_px, out, mout);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_sample_points_dev(const float *flow, int H, int W, const double *pts_rc, size_t n, double *out_rc, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!flow || !pts_rc || !out_rc || H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_sample_points: bad arguments");
+    if (n == 0) return OFL_OK;
+    hipLaunchKernelGGL(sample_points_kernel, dim3(stream_grid(n)), dim3(256), 0, stream_of(stream), flow, H, W, pts_rc, n, out_rc);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

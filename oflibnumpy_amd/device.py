@@ -458,3 +458,27 @@ def scatter_host(flow, target, pmask, vmask=None):
     res = res.astype(target.dtype)
     v = valid.to_host((h, w), np.uint8).astype(bool) if valid is not None else None
     return res, v
+
+
+def sample_points(flow_buf, h, w, pts_rc):
+    """Bilinear flow samples (v, u) at float64 points (row, col): utils.py:161-196 / :605."""
+    pts = np.ascontiguousarray(pts_rc, np.float64)
+    n = pts.shape[0]
+    dp = DeviceBuffer.from_host(pts)
+    out = DeviceBuffer(max(n, 1) * 16)
+    nat.check(_lib().ofl_sample_points_dev(flow_buf.ptr, h, w, dp.ptr, n, out.ptr, None))
+    return out.to_host((n, 2), np.float64)
+
+
+def scatter_query(pos_flow_buf, sign, vals_buf, C, h, w, query_xy, pmask=None):
+    """griddata(points, values, query) for sparse float64 query points (utils.py:603, 614).
+    Returns (values float64 [n, C], found bool [n])."""
+    q = np.ascontiguousarray(query_xy, np.float64)
+    n = q.shape[0]
+    dq = DeviceBuffer.from_host(q)
+    out = DeviceBuffer(max(n, 1) * C * 8)
+    found = DeviceBuffer(max(n, 1))
+    ws = _workspace(h, w, C)
+    nat.check(_lib().ofl_scatter_query_dev(pos_flow_buf.ptr, sign, 0, pmask.ptr if pmask is not None else None,
+                                           vals_buf.ptr, C, h, w, dq.ptr, n, out.ptr, found.ptr, ws.ptr, ws.nbytes, None))
+    return out.to_host((n, C), np.float64), found.to_host((n,), np.uint8).astype(bool)

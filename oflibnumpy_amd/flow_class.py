@@ -6,8 +6,8 @@ the reference.  Its hot-path methods upload once, run the device-side algebra of
 (all intermediates stay in HBM) and download the result.  Pipelines that must not cross PCIe at all
 use `DeviceFlow` directly.
 
-Out of scope (not on the hot path): resize, track, matrix fitting, KITTI /
-Sintel-mask PNG loaders, visualisation.
+Next-tier row already widened into: `track` / `track_pts`.
+Out of scope (not on the hot path): resize, matrix fitting, KITTI / Sintel-mask PNG loaders, visualisation.
 """
 from __future__ import annotations
 
@@ -19,7 +19,7 @@ import numpy as np
 from . import _native as nat
 from . import device as dev
 from .utils import (get_valid_ref, get_valid_padding, validate_shape, from_matrix, from_transforms,
-                    load_sintel, is_zero_flow, threshold_vectors, _REMAP_DTYPES)
+                    load_sintel, is_zero_flow, threshold_vectors, track_pts, _REMAP_DTYPES)
 
 FlowAlias = 'Flow'
 
@@ -338,6 +338,19 @@ class Flow(object):
         if ref != self._ref:
             return Flow(-self._vecs, ref, self._mask)          # s->t and t->s are a negation only
         return Flow.from_device(self.to_device().invert(ref))
+
+    def track(self, pts: np.ndarray, int_out: bool = None, get_valid_status: bool = None,
+              s_exact_mode: bool = None) -> np.ndarray:
+        """Warp points (N, 2) in (row, col) order with the flow; optionally also return which points are
+        moved by valid vectors to a position inside the flow area (reference flow_class.py:755-795)."""
+        get_valid_status = False if get_valid_status is None else get_valid_status
+        if not isinstance(get_valid_status, bool):
+            raise TypeError("Error tracking points: Get_tracked needs to be a boolean")
+        warped = track_pts(flow=self._vecs, ref=self._ref, pts=pts, int_out=int_out, s_exact_mode=s_exact_mode)
+        if get_valid_status:
+            status = self.valid_source()[np.round(pts[..., 0]).astype('i'), np.round(pts[..., 1]).astype('i')]
+            return warped, status
+        return warped
 
     def valid_target(self, consider_mask: bool = None) -> np.ndarray:
         """Area of the target domain reached by valid vectors (reference flow_class.py:1113-1151)."""

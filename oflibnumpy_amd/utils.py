@@ -238,3 +238,56 @@ def apply_flow(flow: nd, target: nd, ref: str, mask: nd = None, quant: int = Non
     if result.shape != target.shape:
         result = result[:, :, np.newaxis]
     return result
+
+
+# --------------------------------------------------------------------------- sparse point tracking
+def track_pts(flow: nd, ref: str, pts: nd, int_out: bool = None, s_exact_mode: bool = None) -> nd:
+    """Warp points (N, 2) given as (row, col) with a flow field; arguments, defaults, return conventions and
+    exception types of the reference's track_pts (utils.py:547-622).
+
+    's' + integer points: the flow vectors at those pixels (host indexing, nothing to compute);
+    's' + float points:   bilinear samples of the flow (device), or with `s_exact_mode` the Delaunay-linear
+                          interpolation on the regular grid (device scatter kernel, query mode);
+    't':                  Delaunay-linear interpolation of the flow carried by the points grid - flow,
+                          evaluated at `pts` (device scatter kernel, query mode); points outside the hull -> 0.
+    """
+    flow = validate_flow_array(flow, "Error tracking points: ")
+    if not isinstance(pts, np.ndarray):
+        raise TypeError("Error tracking points: Pts needs to be a numpy array")
+    if pts.ndim != 2 or pts.shape[1] != 2:
+        raise ValueError("Error tracking points: Pts needs to have shape N-2")
+    int_out = False if int_out is None else int_out
+    s_exact_mode = False if s_exact_mode is None else s_exact_mode
+    if not isinstance(int_out, bool):
+        raise TypeError("Error tracking points: Int_out needs to be a boolean")
+    if not isinstance(s_exact_mode, bool):
+        raise TypeError("Error tracking points: S_exact_mode needs to be a boolean")
+
+    if is_zero_flow(flow, thresholded=True):
+        warped = pts
+    else:
+        h, w = flow.shape[:2]
+        if ref == 's' and np.issubdtype(pts.dtype, np.integer):
+            warped = pts + flow[pts[:, 0], pts[:, 1], ::-1]
+        elif ref == 's' and not np.issubdtype(pts.dtype, np.floating):
+            raise TypeError("Error tracking points: Pts numpy array needs to have a float or int dtype")
+        else:
+            fbuf = dev.DeviceBuffer.from_host(flow)
+            if ref == 's' and not s_exact_mode:
+                ver, hor = pts[:, 0], pts[:, 1]
+                if np.any(~((0 <= ver) & (ver <= h - 1)) | ~((0 <= hor) & (hor <= w - 1))):
+                    raise IndexError("Some points are outside of the data area.")
+                vecs = dev.sample_points(fbuf, h, w, pts)
+                found = np.ones(len(pts), bool)
+            else:
+                if ref == 's':      # exact mode: values live on the undisplaced regular grid
+                    pos, sign = dev.DeviceBuffer.zeros(h * w * 8), 1
+                else:               # 't': values live at grid - flow
+                    pos, sign = fbuf, -1
+                vals, found = dev.scatter_query(pos, sign, fbuf, 2, h, w, pts[:, ::-1].astype(np.float64))
+                vecs = vals[:, ::-1]            # (u, v) -> (row, col) order
+            warped = pts + vecs
+            warped[~found] = 0                  # NaN -> 0 (reference utils.py:616-618)
+    if int_out:
+        warped = np.round(warped).astype('i')
+    return warped

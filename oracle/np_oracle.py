@@ -337,3 +337,49 @@ def flow_from_matrix(matrix, shape, ref):
 
 def from_transforms(transform_list, shape, ref, mask=None):
     return OFlow(flow_from_matrix(matrix_from_transforms(transform_list), shape, ref), ref, mask)
+
+
+# ------------------------------------------------------------------ sparse point tracking (next-tier row)
+def bilinear_interpolation(data, pts):
+    """utils.py:161-196, restated INCLUDING its pairing of the (ver1, hor0) sample with the (ver0, hor1)
+    weight and vice versa (b / c below) -- results must match the reference, not the textbook."""
+    ver, hor = pts[:, 0], pts[:, 1]
+    h, w = data.shape[:2]
+    if any(~((0 <= ver) & (ver <= h - 1)) | ~((0 <= hor) & (hor <= w - 1))):
+        raise IndexError("Some points are outside of the data area.")
+    v0, h0 = np.floor(ver).astype(int), np.floor(hor).astype(int)
+    v0c, h0c = np.clip(v0, 0, h - 1), np.clip(h0, 0, w - 1)
+    v1c, h1c = np.clip(v0 + 1, 0, h - 1), np.clip(h0 + 1, 0, w - 1)
+    w_a = (v1c - ver) * (h1c - hor)
+    w_b = (v1c - ver) * (hor - h0c)
+    w_c = (ver - v0c) * (h1c - hor)
+    w_d = (ver - v0c) * (hor - h0c)
+    return (w_a[:, None] * data[v0c, h0c] + w_b[:, None] * data[v1c, h0c] +
+            w_c[:, None] * data[v0c, h1c] + w_d[:, None] * data[v1c, h1c])
+
+
+def track_pts(flow, ref, pts, int_out=False, s_exact_mode=False):
+    """utils.py:547-622 (validation omitted)."""
+    flow = flow.astype('float32')
+    if is_zero_flow(flow, True):
+        warped = pts
+    else:
+        h, w = flow.shape[:2]
+        r, c = np.mgrid[:h, :w]
+        grid = np.stack([r.ravel(), c.ravel()], axis=1)
+        flat = flow[..., ::-1].reshape(-1, 2)
+        if ref == 's':
+            if np.issubdtype(pts.dtype, np.integer):
+                vecs = flow[pts[:, 0], pts[:, 1], ::-1]
+            elif s_exact_mode:
+                vecs = griddata(grid, flat, (pts[:, 0], pts[:, 1]), method='linear')
+            else:
+                vecs = bilinear_interpolation(flow[..., ::-1], pts)
+        else:
+            vecs = griddata(grid - flat, flat, (pts[:, 0], pts[:, 1]), method='linear')
+        warped = pts + vecs
+        nan = np.isnan(warped)
+        warped[nan[:, 0] | nan[:, 1]] = 0
+    if int_out:
+        warped = np.round(warped).astype('i')
+    return warped

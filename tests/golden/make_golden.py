@@ -130,6 +130,37 @@ def main():
     put("k7/valid_source_t_masked", f_tm, f_tm.valid_source())
     put("k7/valid_source_t_masked_nomask", f_tm, f_tm.valid_source(False))
 
+    # sparse point tracking (utils.py:547-622, flow_class.py:755-795) -- appended last so that the seeded
+    # arrays above stay byte-identical
+    tshape = (64, 80)
+    pts_f = np.array([[20.5, 10.5], [8.3, 7.2], [50.4, 60.2], [0.0, 0.0], [63.0, 79.0], [31.25, 40.75]])
+    pts_i = np.array([[20, 10], [8, 7], [63, 79], [0, 0]])
+    tyy, txx = np.mgrid[:tshape[0], :tshape[1]].astype('f')
+    twob = np.stack([0.8 * np.sin(txx / 9.0) * np.cos(tyy / 7.0), 0.6 * np.cos(txx / 8.0) * np.sin(tyy / 6.0)], -1).astype('f')
+    out["track/pts_f"] = pts_f
+    out["track/pts_i"] = pts_i
+    for name, tr, extra in (("rot", [['rotation', 0, 0, 12]], None), ("wob", [['rotation', 30, 40, -8], ['scaling', 30, 40, 0.95]], twob)):
+        for ref in ('s', 't'):
+            fv = of.from_transforms(tr, tshape, ref)
+            if extra is not None:
+                fv = (fv + extra).astype('f')
+            tag = "track/{}_{}".format(name, ref)
+            out[tag + "/flow"] = fv
+            out[tag + "/float"] = of.track_pts(fv, ref, pts_f)
+            out[tag + "/float_int_out"] = of.track_pts(fv, ref, pts_f, int_out=True)
+            if ref == 's':
+                out[tag + "/int"] = of.track_pts(fv, ref, pts_i)
+                out[tag + "/exact"] = of.track_pts(fv, ref, pts_f, s_exact_mode=True)
+    ft = Flow.from_transforms([['rotation', 0, 0, 12]], tshape, 't')
+    ft.mask[:, 50:] = False
+    status_pts = np.array([[0, 20], [0, 75], [8.3, 7.2], [40.4, 30.2], [50, 60]])
+    warped, status = ft.track(status_pts, get_valid_status=True)
+    out["track/status_t/flow"] = ft.vecs
+    out["track/status_t/mask"] = ft.mask
+    out["track/status_t/pts"] = status_pts
+    out["track/status_t/warped"] = warped
+    out["track/status_t/status"] = status
+
     path = os.path.join(HERE, "ref_scipy_paths.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -288,3 +288,50 @@ def test_scatter_4k_invert(gpu):
     back = inv.invert()
     m = back.mask
     np.testing.assert_allclose(back.vecs[m], f.vecs[m], rtol=1e-4, atol=2e-3)
+
+
+def test_track_pts_matches_reference(gpu, golden):
+    """Sparse point tracking (reference utils.py:547-622, tests/test_utils.py:543-571) against
+    outputs of the real reference: bilinear 's' mode bit-exact (float64, same operation order, including the
+    reference's swapped b/c pairing), 't' mode and s_exact_mode through the scatter kernel's query pass."""
+    of = gpu
+    g = golden
+    pf, pi = g['track/pts_f'], g['track/pts_i']
+    for name in ('rot', 'wob'):
+        for ref in ('s', 't'):
+            tag = 'track/{}_{}'.format(name, ref)
+            flow = g[tag + '/flow']
+            got = of.track_pts(flow, ref, pf)
+            assert got.dtype == np.float64
+            if ref == 's':
+                np.testing.assert_array_equal(got, g[tag + '/float'])
+                np.testing.assert_array_equal(of.track_pts(flow, ref, pi), g[tag + '/int'])
+                ex = of.track_pts(flow, ref, pf, s_exact_mode=True)
+                # regular grid: every cell is an exact square (both diagonals Delaunay); affine flow -> equal up to
+                # otherwise within the reference's own "order of 0.01 px" remark (utils.py:596-598)
+                np.testing.assert_allclose(ex, g[tag + '/exact'], rtol=0, atol=1e-6 if name == 'rot' else 2e-2)   # float32 flow noise ~1e-7
+            else:
+                np.testing.assert_allclose(got, g[tag + '/float'], rtol=1e-9, atol=1e-9)
+            r = of.track_pts(flow, ref, pf, int_out=True)
+            np.testing.assert_array_equal(r, g[tag + '/float_int_out'])
+            assert r.dtype == g[tag + '/float_int_out'].dtype
+    ft = of.Flow(g['track/status_t/flow'], 't', g['track/status_t/mask'])
+    warped, status = ft.track(g['track/status_t/pts'], get_valid_status=True)
+    np.testing.assert_array_equal(status, g['track/status_t/status'])
+    np.testing.assert_allclose(warped, g['track/status_t/warped'], rtol=1e-9, atol=1e-9)
+    # reference tests/test_utils.py:545-571 at its own size and tolerances
+    f_s = of.from_transforms([['rotation', 0, 0, 30]], [512, 512], 's')
+    f_t = of.from_transforms([['rotation', 0, 0, 30]], [512, 512], 't')
+    pts = np.array([[20.5, 10.5], [8.3, 7.2], [120.4, 160.2]])
+    want = [[12.5035207776, 19.343266740], [3.58801085141, 10.385382907], [24.1694586156, 198.93726969]]
+    np.testing.assert_allclose(of.track_pts(f_s, 's', pts), want, atol=1e-1, rtol=1e-2)
+    np.testing.assert_allclose(of.track_pts(f_s, 's', pts, s_exact_mode=True), want, rtol=1e-7)
+    np.testing.assert_allclose(of.track_pts(f_t, 't', pts), want, atol=1e-6, rtol=1e-6)
+    r = of.track_pts(f_t, 't', pts, int_out=True)
+    np.testing.assert_array_equal(r, np.round(want))
+    f = of.from_transforms([['translation', 10, 20]], [512, 512], 's')
+    np.testing.assert_array_equal(of.track_pts(f, 's', np.array([[20, 10], [8, 7]])), [[40, 20], [28, 17]])
+    with pytest.raises(IndexError):
+        of.track_pts(f_s, 's', np.array([[600.5, 10.5]]))
+    with pytest.raises(TypeError):
+        of.Flow(f_s, 's').track(pts, True, get_valid_status='test')

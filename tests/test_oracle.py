@@ -33,7 +33,7 @@ def _run_case(O, g, tag):
 
 
 def golden_tags(g):
-    return sorted({k.rsplit('/', 1)[0] for k in g.files if '/' in k})
+    return sorted({k.rsplit('/', 1)[0] for k in g.files if '/' in k and not k.startswith('track/')})
 
 
 def test_oracle_matches_reference_outputs(oracle, golden):
@@ -136,3 +136,23 @@ def test_oracle_zero_predicates(oracle):
     m[3, 4] = False
     assert oracle.is_zero_raw(v, m, True) and oracle.is_zero_raw(v, m, False)
     assert oracle.is_zero_flow(v, True) == oracle.is_zero_raw(v, None, True)
+
+
+def test_oracle_track_pts_matches_reference(oracle, golden):
+    """Sparse point tracking (utils.py:547-622) against outputs of the real reference."""
+    g = golden
+    pf, pi = g['track/pts_f'], g['track/pts_i']
+    n = 0
+    for name in ('rot', 'wob'):
+        for ref in ('s', 't'):
+            tag = 'track/{}_{}'.format(name, ref)
+            flow = g[tag + '/flow']
+            np.testing.assert_array_equal(oracle.track_pts(flow, ref, pf), g[tag + '/float'])
+            r = oracle.track_pts(flow, ref, pf, int_out=True)
+            np.testing.assert_array_equal(r, g[tag + '/float_int_out'])
+            assert r.dtype == g[tag + '/float_int_out'].dtype
+            if ref == 's':
+                np.testing.assert_array_equal(oracle.track_pts(flow, ref, pi), g[tag + '/int'])
+                np.testing.assert_array_equal(oracle.track_pts(flow, ref, pf, s_exact_mode=True), g[tag + '/exact'])
+            n += 1
+    assert n == 4

@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built libraries are git-ignored: on a fresh checkout compile them once (hipcc cross-compiles
+    gfx950 without a GPU; gcc builds the oracle).  On the GPU box the prebuilt in-tree files are used."""
+    from oflibnumpy_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        from oflibnumpy_amd.build_native import build_native
+        build_native()
+    from oracle import np_oracle
+    np_oracle.build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(GOLDEN, "ref_scipy_paths.npz"))

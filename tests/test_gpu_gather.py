@@ -389,3 +389,38 @@ def test_config5_tiled_sintel_apply(gpu, oracle):
     ws, vs = fs.apply(img, return_valid_area=True)
     assert ws.shape == img.shape and vs.dtype == bool and 0.3 < vs.mean() <= 1.0
     assert np.isfinite(ws).all()
+
+
+def test_randomised_sweep_compose_and_gather(gpu, oracle):
+    """Seeded sweep over ragged shapes (odd widths take the generic kernels, widths < 128 leave partial tiles),
+    flows mixing sub-threshold, half-pixel, ordinary and far-out-of-range vectors, and random masks: compose
+    (both refs, through the Flow API incl. its early exits) and the image gather stay bit-identical to the oracle."""
+    of = gpu
+    rng = np.random.default_rng(1234)
+    for case in range(40):
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 300))
+        kind = rng.integers(0, 4, size=(h, w, 1))
+        base = rng.standard_normal((h, w, 2)) * rng.choice([0.3, 3.0, 40.0])
+        v = np.where(kind == 0, np.round(base * 2) / 2,                      # exact half / whole pixels
+            np.where(kind == 1, base,
+            np.where(kind == 2, rng.uniform(-9e-4, 9e-4, (h, w, 2)), base * 1e3))).astype(np.float32)
+        if case % 7 == 0:
+            v[...] = rng.uniform(-9e-4, 9e-4, (h, w, 2))                    # thresholded-zero sampling field
+        if case % 11 == 0:
+            v[...] = 0
+        u = (rng.standard_normal((h, w, 2)) * 5).astype(np.float32)
+        m1, m2 = rng.random((h, w)) > 0.2, rng.random((h, w)) > 0.2
+        for ref in ('t', 's'):
+            a, b = (u, v) if ref == 't' else (v, u)          # v always plays the sampling field
+            fa, fb = of.Flow(a, ref, m1), of.Flow(b, ref, m2)
+            got = fa.combine_with(fb, 3)
+            want = oracle.OFlow(a, ref, m1).combine_with(oracle.OFlow(b, ref, m2), 3)
+            np.testing.assert_array_equal(got.vecs, want.vecs, err_msg="case {} {}".format(case, ref))
+            np.testing.assert_array_equal(got.mask, want.mask, err_msg="case {} {}".format(case, ref))
+        c = int(rng.integers(1, 6))
+        img = (rng.random((h, w, c)) * 255).astype(rng.choice([np.uint8, np.float32]))
+        f = of.Flow(v, 't', m1)
+        ow, ov = oracle.OFlow(v, 't', m1).apply(img, m2, return_valid_area=True)
+        gw, gv = f.apply(img, m2, return_valid_area=True)
+        np.testing.assert_array_equal(gw, ow, err_msg="case {} apply".format(case))
+        np.testing.assert_array_equal(gv, ov, err_msg="case {} apply".format(case))

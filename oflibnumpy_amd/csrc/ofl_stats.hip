@@ -55,35 +55,56 @@ void flow_stats_kernel(const float *__restrict__ flow, const uint8_t *__restrict
 }
 
 // out = a + alpha * b, mout = ma & mb  (b/mb optional: out = alpha * a, mout = ma)
+// Each thread moves two float4 (2 x 2 pixels, one per 1-KiB wave chunk) and one 4-byte mask word: every
+// wave instruction covers contiguous memory, and the 1-byte mask streams need half the instructions
+// the vector streams need instead of the same number.
 __global__ __launch_bounds__(256)
 void axpy_kernel(const float *__restrict__ a, const uint8_t *__restrict__ ma,
                  const float *__restrict__ b, const uint8_t *__restrict__ mb, float alpha, size_t n_px,
                  float *__restrict__ out, uint8_t *__restrict__ mout)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t n2 = n_px / 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        const float4 va = reinterpret_cast<const float4 *>(a)[i];
-        float4 r;
-        if (b) {
-            const float4 vb = reinterpret_cast<const float4 *>(b)[i];
-            r = make_float4(__fadd_rn(va.x, __fmul_rn(alpha, vb.x)), __fadd_rn(va.y, __fmul_rn(alpha, vb.y)),
-                            __fadd_rn(va.z, __fmul_rn(alpha, vb.z)), __fadd_rn(va.w, __fmul_rn(alpha, vb.w)));
-        } else {
-            r = make_float4(__fmul_rn(alpha, va.x), __fmul_rn(alpha, va.y), __fmul_rn(alpha, va.z), __fmul_rn(alpha, va.w));
+#ifndef OFL_AXPY_CHUNKS
+#define OFL_AXPY_CHUNKS 2
+#endif
+    // work unit = 128 * OFL_AXPY_CHUNKS pixels per wave (float4 chunks of 128 px, 32 mask words each)
+    constexpr int kCh = OFL_AXPY_CHUNKS, kUnit = 128 * kCh;
+    const size_t n_units = n_px / kUnit;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t u = wave; u < n_units; u += n_waves) {
+        const size_t p0 = u * kUnit;
+#pragma unroll
+        for (int h = 0; h < kCh; ++h) {
+            const size_t i = (p0 + h * 128) / 2 + lane;          // float4 index (2 px)
+            const float4 va = reinterpret_cast<const float4 *>(a)[i];
+            float4 r;
+            if (b) {
+                const float4 vb = reinterpret_cast<const float4 *>(b)[i];
+                r = make_float4(__fadd_rn(va.x, __fmul_rn(alpha, vb.x)), __fadd_rn(va.y, __fmul_rn(alpha, vb.y)),
+                                __fadd_rn(va.z, __fmul_rn(alpha, vb.z)), __fadd_rn(va.w, __fmul_rn(alpha, vb.w)));
+            } else {
+                r = make_float4(__fmul_rn(alpha, va.x), __fmul_rn(alpha, va.y), __fmul_rn(alpha, va.z), __fmul_rn(alpha, va.w));
+            }
+            reinterpret_cast<float4 *>(out)[i] = r;
         }
-        reinterpret_cast<float4 *>(out)[i] = r;
         if (mout) {
-            uint16_t m = reinterpret_cast<const uint16_t *>(ma)[i];
-            if (mb) m &= reinterpret_cast<const uint16_t *>(mb)[i];
-            reinterpret_cast<uint16_t *>(mout)[i] = m;
+#pragma unroll
+            for (int h = 0; h < kCh / 2; ++h) {
+                const size_t i = (p0 + h * 256) / 4 + lane;       // mask word index (4 px)
+                uint32_t m = reinterpret_cast<const uint32_t *>(ma)[i];
+                if (mb) m &= reinterpret_cast<const uint32_t *>(mb)[i];
+                reinterpret_cast<uint32_t *>(mout)[i] = m;
+            }
         }
     }
-    if ((n_px & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const size_t i = n_px - 1;
-        for (int c = 0; c < 2; ++c)
-            out[2 * i + c] = b ? __fadd_rn(a[2 * i + c], __fmul_rn(alpha, b[2 * i + c])) : __fmul_rn(alpha, a[2 * i + c]);
-        if (mout) mout[i] = (uint8_t)(ma[i] & (mb ? mb[i] : 1));
+    // tail (< 256 px): one pixel per thread of the first workgroup
+    const size_t tail0 = n_units * kUnit;
+    if (blockIdx.x == 0) {
+        for (size_t i = tail0 + threadIdx.x; i < n_px; i += blockDim.x) {
+            for (int c = 0; c < 2; ++c)
+                out[2 * i + c] = b ? __fadd_rn(a[2 * i + c], __fmul_rn(alpha, b[2 * i + c])) : __fmul_rn(alpha, a[2 * i + c]);
+            if (mout) mout[i] = (uint8_t)(ma[i] & (mb ? mb[i] : 1));
+        }
     }
 }
 
@@ -133,6 +154,10 @@ void sample_points_kernel(const float *__restrict__ flow, int H, int W, const do
         out[2 * i + 1] = ((w_a * (double)da.x + w_b * (double)db.x) + w_c * (double)dc.x) + w_d * (double)dd.x;
     }
 }
+
+#ifndef OFL_AXPY_CHUNKS
+#define OFL_AXPY_CHUNKS 2
+#endif
 
 int stream_grid(size_t n_items)
 {
@@ -188,7 +213,7 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
     if (!a || !out) return fail(OFL_E_INVALID, "ofl_axpy: NULL pointer");
     if (mout && !ma) return fail(OFL_E_INVALID, "ofl_axpy: mout requires ma");
     if (n_px == 0) return OFL_OK;
-    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n_px / 2)), dim3(256), 0, stream_of(stream),
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n_px / (2 * OFL_AXPY_CHUNKS))), dim3(256), 0, stream_of(stream),
                        a, ma, b, mb, alpha, n_px, out, mout);
     OFL_HIP(hipGetLastError());
     return OFL_OK;

@@ -424,3 +424,46 @@ def test_randomised_sweep_compose_and_gather(gpu, oracle):
         gw, gv = f.apply(img, m2, return_valid_area=True)
         np.testing.assert_array_equal(gw, ow, err_msg="case {} apply".format(case))
         np.testing.assert_array_equal(gv, ov, err_msg="case {} apply".format(case))
+
+
+def test_maximum_dimensions(gpu, oracle):
+    """cv2.remap's own limit (dims < SHRT_MAX): 32766 rows / columns are accepted and correct, 32767 is refused
+    on both the device and the host entry points."""
+    import ctypes
+    of = gpu
+    nat, lib = of.native, of.native.load()
+    rng = np.random.default_rng(9)
+    for shape in ((32766, 4), (2, 32766)):
+        a = (rng.standard_normal(shape + (2,)) * 3).astype('f')
+        b = (rng.standard_normal(shape + (2,)) * 3).astype('f')
+        m1, m2 = rng.random(shape) > 0.1, rng.random(shape) > 0.1
+        got = of.Flow(a, 't', m1).combine_with(of.Flow(b, 't', m2), 3)
+        o, m = oracle.compose3_raw(a, m1, b, m2, -1)
+        np.testing.assert_array_equal(got.vecs, o)
+        np.testing.assert_array_equal(got.mask, m)
+        img = rng.random(shape + (3,), dtype=np.float32)
+        np.testing.assert_array_equal(of.apply_flow(b, img, 't'), oracle.apply_flow(b, img, 't'))
+    rc = lib.ofl_compose3_dev(1, 1, 1, 1, -1, 32767, 4, 1, 1, 1, None, 0, None)
+    assert rc == nat.E_INVALID and b"32766" in lib.ofl_last_error()
+
+
+def test_rccl_broadcast_single_rank(gpu):
+    """The RCCL binding of the sharded workload's one exchange step (ofl_comm_*), exercised with a
+    communicator of one rank: library loading, id creation, init, broadcast on the engine's stream, destroy."""
+    import ctypes
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    nat, lib = of.native, of.native.load()
+    uid = np.zeros(128, np.uint8)
+    nat.check(lib.ofl_comm_unique_id(uid.ctypes.data))
+    assert uid.any()
+    nat.check(lib.ofl_comm_init(uid.ctypes.data, 0, 1))
+    try:
+        payload = np.arange(1 << 16, dtype=np.uint8)
+        buf = dev.DeviceBuffer.from_host(payload)
+        nat.check(lib.ofl_comm_broadcast(buf.ptr, payload.nbytes, 0, None))
+        np.testing.assert_array_equal(buf.to_host(payload.shape, np.uint8), payload)
+        assert lib.ofl_comm_broadcast(buf.ptr, payload.nbytes, 3, None) == nat.E_INVALID     # root out of range
+    finally:
+        nat.check(lib.ofl_comm_destroy())
+    assert lib.ofl_comm_broadcast(1, 16, 0, None) == nat.E_INVALID                            # no communicator

@@ -193,25 +193,50 @@ class OFlow:
         f = self.vecs[self.mask][None] if masked else self.vecs
         return is_zero_flow(f, thresholded)
 
+    def pad(self, padding, mode='constant'):
+        """flow_class.py:508-526."""
+        p = padding
+        vecs = np.pad(self.vecs, ((p[0], p[1]), (p[2], p[3]), (0, 0)), mode=mode)
+        mask = np.pad(self.mask, ((p[0], p[1]), (p[2], p[3])))
+        return OFlow(vecs, self.ref, mask)
+
     def apply(self, target, target_mask=None, return_valid_area=False, consider_mask=True,
-              quant=QUANT_OPENCV):
-        """flow_class.py:528-695 without padding (padding is covered by gather_bilinear(pad=...))."""
+              quant=QUANT_OPENCV, padding=None, cut=True):
+        """flow_class.py:528-695."""
+        sh = self.shape
         if isinstance(target, OFlow):
             return_flow, t, mask = True, target.vecs, target.mask
         else:
             return_flow = False
             t = target if target.ndim == 3 else target[..., None]
-            mask = np.ones(t.shape[:2], 'b') if target_mask is None else target_mask   # int8! (:615)
+            mask = np.ones(t.shape[:2], 'b') if target_mask is None else target_mask.copy()   # int8! (:615)
         with_mask = return_flow or return_valid_area
         if with_mask:
             if self.ref == 's':
-                mask = mask & self.mask                                                  # :643
+                if mask.shape != sh:                                                     # :636-641
+                    tmp = mask[padding[0]:padding[0] + sh[0], padding[2]:padding[2] + sh[1]].copy()
+                    mask = mask.copy()
+                    mask[...] = False
+                    mask[padding[0]:padding[0] + sh[0], padding[2]:padding[2] + sh[1]] = tmp & self.mask
+                else:
+                    mask = mask & self.mask                                              # :643
             t = np.concatenate((t, mask[..., None]), axis=-1)                            # :644
-        warped = apply_flow(self.vecs, t, self.ref, self.mask if consider_mask else None, quant)
+        if padding is None:
+            warped = apply_flow(self.vecs, t, self.ref, self.mask if consider_mask else None, quant)
+        else:
+            flow = self.pad(padding, 'constant' if self.ref == 't' else 'edge')          # :652-660
+            warped = apply_flow(flow.vecs, t, flow.ref, flow.mask if consider_mask else None, quant)
+        if padding is not None and cut:                                                  # :663-664
+            warped = warped[padding[0]:padding[0] + sh[0], padding[2]:padding[2] + sh[1]]
         if with_mask:
             valid = warped[..., -1] == 1                                                 # :668
             if self.ref == 't':
-                valid = valid & self.mask                                                # :680
+                if valid.shape != self.mask.shape:                                       # :673-678
+                    tmp = valid[padding[0]:padding[0] + sh[0], padding[2]:padding[2] + sh[1]].copy()
+                    valid[...] = False
+                    valid[padding[0]:padding[0] + sh[0], padding[2]:padding[2] + sh[1]] = tmp & self.mask
+                else:
+                    valid = valid & self.mask                                            # :680
         if return_flow:
             return OFlow(warped[:, :, :2], target.ref, valid)                            # :684
         if return_valid_area:

@@ -13,6 +13,7 @@ from .flow_class import Flow
 from .flow_operations import *
 from .utils import from_matrix, from_transforms, load_sintel, apply_flow, is_zero_flow, threshold_vectors, track_pts
 from .device import DeviceFlow, DeviceImage, DeviceBuffer
+from .batch import DeviceFlowBatch, combine_flows_batch
 from . import _native as native
 
 __version__ = "0.1.0"

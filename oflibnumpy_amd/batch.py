@@ -1,0 +1,92 @@
+"""Batches of independent flow-field pairs (BASELINE.json config 4): one device launch per stack.
+
+`DeviceFlowBatch` keeps B fields of one shape back to back in HBM ([B][H][W][2] float32 + [B][H][W] uint8),
+the layout `ofl_compose3_dev` takes with `batch > 1`.  `combine_flows_batch` is the array-level convenience:
+it composes the pairs this rank owns (`sharding.shard`) with mode 3 in one launch and honours the
+reference's per-pair zero-flow early exits (flow_class.py:1339-1354) from the flag words of that launch.
+"""
+import numpy as np
+
+from . import _native as nat
+from . import device as dev
+from . import sharding
+from .flow_class import Flow
+
+
+class DeviceFlowBatch:
+    def __init__(self, n, shape, ref):
+        self.n, self.shape, self.ref = int(n), (int(shape[0]), int(shape[1])), ref
+        px = self.shape[0] * self.shape[1]
+        self.vecs = dev.DeviceBuffer(self.n * px * 8)
+        self.mask = dev.DeviceBuffer(self.n * px)
+
+    @classmethod
+    def from_flows(cls, flows):
+        flows = list(flows)
+        if not flows:
+            raise ValueError("empty batch")
+        shape, ref = flows[0].shape, flows[0].ref
+        if any(f.shape != shape or f.ref != ref for f in flows):
+            raise ValueError("all flows of a batch need the same shape and reference")
+        b = cls(len(flows), shape, ref)
+        px = shape[0] * shape[1]
+        lib = nat.load()
+        for i, f in enumerate(flows):
+            m = f.mask.astype(np.uint8)
+            nat.check(lib.ofl_upload(b.vecs.ptr + i * px * 8, f.vecs.ctypes.data, px * 8, None))
+            nat.check(lib.ofl_upload(b.mask.ptr + i * px, m.ctypes.data, px, None))
+            nat.check(lib.ofl_stream_sync(None))
+        return b
+
+    def to_flows(self):
+        h, w = self.shape
+        v = self.vecs.to_host((self.n, h, w, 2), np.float32)
+        m = self.mask.to_host((self.n, h, w), np.uint8).astype(bool)
+        return [Flow(v[i], self.ref, m[i]) for i in range(self.n)]
+
+    def compose3(self, other, quant=nat.QUANT_OPENCV):
+        """self[i].combine_with(other[i], mode=3) for every i in ONE launch.
+        Returns (DeviceFlowBatch out, flag words uint32 [n][8]) -- see ofl_compose3_dev for the words."""
+        if (self.n, self.shape, self.ref) != (other.n, other.shape, other.ref):
+            raise ValueError("batches need the same length, shape and reference")
+        fa, fb, sign = (other, self, +1) if self.ref == 's' else (self, other, -1)
+        out = DeviceFlowBatch(self.n, self.shape, self.ref)
+        words = dev.DeviceBuffer.zeros(32 * self.n)
+        dev.compose3_launch(fa, fb, sign, out, words, batch=self.n, quant=quant)
+        return out, words.to_host((self.n, 8), np.uint32), (fa, fb)
+
+
+def combine_flows_batch(flows_1, flows_2, ref=None, rank=0, world=1, thresholded=False):
+    """Mode-3 composition of many independent pairs.  `flows_1[i] (+) flows_2[i]`; inputs are lists of
+    `Flow` objects or of (H, W, 2) arrays with reference `ref`.  With world > 1 only the contiguous block of
+    pairs owned by `rank` is processed and returned, as a list of (index, Flow)."""
+    if len(flows_1) != len(flows_2):
+        raise ValueError("need as many first as second flows")
+    as_flow = lambda f: f if isinstance(f, Flow) else Flow(f, ref)
+    mine = sharding.shard(len(flows_1), rank, world)
+    if len(mine) == 0:
+        return []
+    f1 = [as_flow(flows_1[i]) for i in mine]
+    f2 = [as_flow(flows_2[i]) for i in mine]
+    b1, b2 = DeviceFlowBatch.from_flows(f1), DeviceFlowBatch.from_flows(f2)
+    out, words, (fa, fb) = b1.compose3(b2)
+    res = out.to_flows()
+    bit = 1 if thresholded else 0                 # OFL_STAT_NONZERO_TH_MASKED / OFL_STAT_NONZERO_MASKED word index
+    results = []
+    for k, i in enumerate(mine):
+        self_f, other_f = f1[k], f2[k]
+        a_cert, b_nonzero = words[k][bit], words[k][4 + bit]
+        # fa/fb roles: 't' -> fa = self, fb = flow; 's' -> fa = flow, fb = self
+        fa_zero = (not a_cert) and (other_f if b1.ref == 's' else self_f).is_zero(thresholded=thresholded)
+        fb_zero = not b_nonzero
+        self_zero, flow_zero = (fb_zero, fa_zero) if b1.ref == 's' else (fa_zero, fb_zero)
+        if self_zero:
+            r = other_f
+        elif flow_zero:
+            r = self_f
+        elif not words[k][7]:                      # sampling field thresholded-zero: plain sum (utils.py:215-216)
+            r = other_f + self_f if b1.ref == 't' else self_f + other_f
+        else:
+            r = res[k]
+        results.append((i, r))
+    return results

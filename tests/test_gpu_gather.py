@@ -467,3 +467,32 @@ def test_rccl_broadcast_single_rank(gpu):
     finally:
         nat.check(lib.ofl_comm_destroy())
     assert lib.ofl_comm_broadcast(1, 16, 0, None) == nat.E_INVALID                            # no communicator
+
+
+def test_combine_flows_batch_api(gpu, oracle):
+    """Batch convenience API: one launch for all pairs a rank owns, per-pair early exits honoured, shards of two
+    ranks together reproduce the single-rank result."""
+    of = gpu
+    shape = [96, 128]
+    rng = np.random.default_rng(3)
+    f1s, f2s = [], []
+    for i in range(7):
+        f1s.append(of.Flow.from_transforms([['rotation', 60, 50, -20 + 7 * i]], shape, 't', rand_mask(shape, i, 0.05)))
+        f2s.append(of.Flow.from_transforms([['translation', 3 * i - 9, 2.5 * i]], shape, 't', rand_mask(shape, 50 + i, 0.05)))
+    f1s[2] = of.Flow.zero(shape, 't')                      # self zero  -> the other operand comes back
+    f2s[4] = of.Flow.zero(shape, 't')                      # flow zero  -> self comes back
+    f2s[5] = of.Flow(np.full(shape + [2], 4e-4, 'f'), 't')  # sampling field below the threshold -> plain sum
+    full = of.combine_flows_batch(f1s, f2s)
+    assert [i for i, _ in full] == list(range(7))
+    for i, r in full:
+        want = f1s[i].combine_with(f2s[i], 3)
+        np.testing.assert_array_equal(r.vecs, want.vecs)
+        np.testing.assert_array_equal(r.mask, want.mask)
+    assert full[2][1] is f2s[2] and full[4][1] is f1s[4]
+    parts = of.combine_flows_batch(f1s, f2s, rank=0, world=2) + of.combine_flows_batch(f1s, f2s, rank=1, world=2)
+    assert [i for i, _ in parts] == list(range(7))
+    for (i, a), (_, b) in zip(parts, full):
+        np.testing.assert_array_equal(a.vecs, b.vecs)
+        np.testing.assert_array_equal(a.mask, b.mask)
+    arr = of.combine_flows_batch([f.vecs for f in f1s[:2]], [f.vecs for f in f2s[:2]], ref='s')
+    np.testing.assert_array_equal(arr[1][1].vecs, of.combine_flows(f1s[1].vecs, f2s[1].vecs, 3, 's'))

@@ -401,8 +401,14 @@ void compose3_kernel(const C3Args a)
 // aligned 16-byte row loads into LDS as {u, v, mask, -} quads, and reads the taps with ds_read_b128.
 // Texture-path bytes per pixel drop to 9 (stream) + ~9 x (source px per output px), independent of the
 // rotation of the sampling grid.  Tiles whose footprint does not fit the LDS budget use the direct path.
-constexpr int kLdsLX  = 8;            // 8 lanes x 4 px = 32 px wide, 32 rows
-constexpr int kLdsCap = 2400;         // staged source pixels per workgroup (16 B each = 37.5 KB -> 4 workgroups / CU)
+#ifndef OFL_LDS_LX
+#define OFL_LDS_LX 8
+#endif
+#ifndef OFL_LDS_CAP
+#define OFL_LDS_CAP 2400
+#endif
+constexpr int kLdsLX  = OFL_LDS_LX;   // 8 lanes x 4 px = 32 px wide, 32 rows (16 -> 64 x 16)
+constexpr int kLdsCap = OFL_LDS_CAP;  // staged source pixels per workgroup (16 B each; 2400 = 37.5 KB -> 4 workgroups / CU)
 
 // Wave-wide min / max on the VALU with DPP row shifts and row broadcasts (gfx9 reduction idiom): four
 // row_shr steps leave each 16-lane row's result in its last lane, row_bcast:15 / row_bcast:31 carry it

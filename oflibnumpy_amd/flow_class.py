@@ -7,7 +7,8 @@ the reference.  Its hot-path methods upload once, run the device-side algebra of
 use `DeviceFlow` directly.
 
 Next-tier row already widened into: `track` / `track_pts`.
-Out of scope (not on the hot path): resize, matrix fitting, KITTI / Sintel-mask PNG loaders, visualisation.
+Dataset loaders (KITTI, Sintel + mask) are host I/O with a small built-in PNG reader.
+Out of scope (not on the hot path): resize, matrix fitting, visualisation.
 """
 from __future__ import annotations
 
@@ -19,7 +20,8 @@ import numpy as np
 from . import _native as nat
 from . import device as dev
 from .utils import (get_valid_ref, get_valid_padding, validate_shape, from_matrix, from_transforms,
-                    load_sintel, is_zero_flow, threshold_vectors, track_pts, _REMAP_DTYPES)
+                    load_sintel, load_sintel_mask, load_kitti, is_zero_flow, threshold_vectors, track_pts,
+                    _REMAP_DTYPES)
 
 FlowAlias = 'Flow'
 
@@ -104,12 +106,20 @@ class Flow(object):
         return cls(from_transforms(transform_list, shape, ref), ref, mask)
 
     @classmethod
+    def from_kitti(cls, path: str, load_valid: bool = None) -> FlowAlias:
+        """KITTI uint16 PNG -> flow with reference 's', optionally with the valid pixels as mask
+        (reference flow_class.py:237-259)."""
+        load_valid = True if load_valid is None else load_valid
+        if not isinstance(load_valid, bool):
+            raise TypeError("Error loading flow from KITTI data: Load_valid needs to be boolean")
+        data = load_kitti(path)
+        return cls(data[..., :2], 's', data[..., 2].astype('bool')) if load_valid else cls(data[..., :2], 's')
+
+    @classmethod
     def from_sintel(cls, path: str, inv_path: str = None) -> FlowAlias:
-        """Sintel .flo -> flow with reference 's' (reference flow_class.py:262-275).  The invalid-pixel
-        PNG (`inv_path`) needs an image decoder that is outside this engine's scope."""
-        if inv_path is not None:
-            raise NotImplementedError("Sintel invalid-pixel PNG masks are not supported by oflibnumpy_amd")
-        return cls(load_sintel(path), 's')
+        """Sintel .flo (+ optional invalid-pixel PNG) -> flow with reference 's' (reference flow_class.py:262-275)."""
+        mask = None if inv_path is None else load_sintel_mask(inv_path)
+        return cls(load_sintel(path), 's', mask)
 
     def copy(self) -> FlowAlias:
         return Flow(self._vecs, self._ref, self._mask)

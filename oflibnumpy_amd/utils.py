@@ -158,6 +158,39 @@ def load_sintel(path: str) -> nd:
         return np.fromfile(f, dtype=np.dtype('<f4')).reshape(h, w, 2)
 
 
+def _read_png_or_none(path):
+    from ._png import read_png
+    try:
+        return read_png(path)
+    except (OSError, ValueError, TypeError, IndexError, KeyError):
+        return None
+
+
+def load_kitti(path: str) -> nd:
+    """KITTI uint16 PNG flow -> float64 (H, W, 3): channels (u, v) = (value - 2^15) / 64 and the valid flag
+    (reference utils.py:426-444; PNG decoding by oflibnumpy_amd._png instead of cv2.imread)."""
+    inp = _read_png_or_none(path)
+    if inp is None:
+        raise ValueError("Error loading flow from KITTI data: Flow data could not be loaded")
+    if inp.ndim != 3 or inp.shape[-1] != 3:
+        raise ValueError("Error loading flow from KITTI data: Loaded flow data has the wrong shape")
+    out = inp.astype('float64')
+    out[..., :2] = (out[..., :2] - 2 ** 15) / 64
+    return out
+
+
+def load_sintel_mask(path: str) -> nd:
+    """Sintel invalid-pixel PNG -> boolean mask of VALID pixels (reference utils.py:473-490)."""
+    if not isinstance(path, str):
+        raise TypeError("Error loading flow from Sintel data: Path needs to be a string")
+    mask = _read_png_or_none(path)
+    if mask is None:
+        raise ValueError("Error loading flow from Sintel data: Invalid mask could not be loaded from path")
+    if mask.ndim == 3:
+        mask = mask[..., :3].any(axis=-1)
+    return ~(mask.astype('bool'))
+
+
 # --------------------------------------------------------------------------- zero-flow predicates
 def threshold_vectors(vecs: nd, threshold: Union[float, int] = None, use_mag: bool = None) -> nd:
     """Copy with small vectors zeroed: per component |v| < threshold, or by magnitude (utils.py:298-316)."""

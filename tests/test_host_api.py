@@ -302,3 +302,45 @@ def test_load_sintel():
     bad = os.path.join(ROOT, "tests", "golden", "make_golden.py")
     with pytest.raises(ValueError):
         of.load_sintel(bad)
+    with pytest.raises(ValueError):
+        of.load_sintel(os.path.join(ROOT, "tests", "golden", "sintel_wrong.flo"))
+
+
+def test_dataset_loaders():
+    """reference tests/test_utils.py:426-470 and tests/test_flow_class.py:115-148 on the reference's own fixtures."""
+    g = lambda n: os.path.join(ROOT, "tests", "golden", n)
+    want = np.arange(0, 10)[:, np.newaxis] * np.arange(0, 20)[np.newaxis, :]
+    out = of.load_kitti(g("kitti.png"))
+    assert isinstance(out, np.ndarray) and out.dtype == np.float64
+    np.testing.assert_array_equal(out[..., 0], want)
+    np.testing.assert_array_equal(out[..., 1], 0)
+    np.testing.assert_array_equal(out[:, 0, 2], 1)
+    np.testing.assert_array_equal(out[:, 10, 2], 0)
+    with pytest.raises(ValueError):
+        of.load_kitti("test")
+    with pytest.raises(ValueError):
+        of.load_kitti(g("kitti_wrong.png"))
+    m = of.load_sintel_mask(g("sintel_invalid.png"))
+    assert m.dtype == bool and m[:, 0].all() and not m[:, 10].any()
+    with pytest.raises(TypeError):
+        of.load_sintel_mask(0)
+    with pytest.raises(ValueError):
+        of.load_sintel_mask("test.png")
+    f = of.Flow.from_kitti(g("kitti.png"), load_valid=True)
+    np.testing.assert_array_equal(f.vecs[..., 0], want)
+    assert f.ref == 's' and f.mask[:, 0].all() and not f.mask[:, 10].any()
+    assert of.Flow.from_kitti(g("kitti.png"), load_valid=False).mask.all()
+    with pytest.raises(TypeError):
+        of.Flow.from_kitti(g("kitti.png"), load_valid='test')
+    with pytest.raises(ValueError):
+        of.Flow.from_kitti('test')
+    with pytest.raises(ValueError):
+        of.Flow.from_kitti(g("kitti_wrong.png"))
+    f = of.Flow.from_sintel(g("sintel.flo"), g("sintel_invalid.png"))
+    assert f.mask[:, 0].all() and not f.mask[:, 10].any()
+    with pytest.raises(ValueError):
+        of.Flow.from_sintel(g("sintel_wrong.flo"))
+    with pytest.raises(ValueError):
+        of.Flow.from_sintel(g("sintel.flo"), 'test.png')
+    with pytest.raises(ValueError):
+        of.Flow.from_sintel(g("sintel.flo"), g("sintel_invalid_wrong.png"))

@@ -22,6 +22,7 @@
 // node -- all L2-friendly because owner triangles of neighbouring nodes are neighbours in memory.
 #include "ofl_common.h"
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <stdlib.h>
 #include <vector>
@@ -622,9 +623,12 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
     } else {
         OFL_HIP(hipEventSynchronize(hs.done));          // the previous call's upload has left the buffer
     }
+    static const bool timing = getenv("OFL_SC_TIMING") != nullptr;      // development knob: host-side split on stderr
+    const auto t0 = std::chrono::steady_clock::now();
     const size_t avail = kHeadBytes + (size_t)std::min(ws.cand_cap, kFirstCand) * sizeof(D2);
     OFL_HIP(hipMemcpyAsync(hs.buf, ws.counters, avail, hipMemcpyDeviceToHost, s));
     OFL_HIP(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();
     const unsigned long long *cbuf = (const unsigned long long *)hs.buf;
     unsigned long long c[4] = { 0, cbuf[1], cbuf[2], cbuf[3] };
     for (int k = 0; k < 256; ++k) c[0] += cbuf[32 + k];
@@ -655,6 +659,12 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
         }
     }
     OFL_HIP(hipEventRecord(hs.done, s));
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ofl scatter] wait+readback %.1f us, hull+upload %.1f us, candidates %llu, hull %d+%d\n",
+                std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                std::chrono::duration<double, std::micro>(t2 - t1).count(), c[3], hull.n_lower, hull.n_upper);
+    }
     return OFL_OK;
 }
 

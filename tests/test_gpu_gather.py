@@ -496,3 +496,33 @@ def test_combine_flows_batch_api(gpu, oracle):
         np.testing.assert_array_equal(a.mask, b.mask)
     arr = of.combine_flows_batch([f.vecs for f in f1s[:2]], [f.vecs for f in f2s[:2]], ref='s')
     np.testing.assert_array_equal(arr[1][1].vecs, of.combine_flows(f1s[1].vecs, f2s[1].vecs, 3, 's'))
+
+
+def test_lds_staged_variant_in_subprocess(gpu):
+    """The opt-in LDS-staged compose kernel (OFL_C3_VARIANT=1, read once per process) produces the same bits
+    as the oracle: small and large footprints (the latter exceed the LDS budget and take the in-kernel
+    direct path), both references, odd tile remainders."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import oflibnumpy_amd as of
+from oracle import np_oracle as O
+rng = np.random.default_rng(5)
+for shape, t1, t2 in (((300, 400), [['rotation', 200, 150, -30]], [['scaling', 100, 80, 0.8]]),
+                      ((257, 130), [['scaling', 60, 60, 0.9]], [['rotation', 65, 128, 40]]),
+                      ((96, 256), [['rotation', 10, 10, 5]], [['scaling', 128, 48, 3.5]]),       # footprint > LDS budget
+                      ((33, 66), [['translation', 1.5, -2.25]], [['translation', 70.5, 0]])):
+    for ref in 'ts':
+        f1 = of.Flow.from_transforms(t1, list(shape), ref, rng.random(shape) > 0.1)
+        f2 = of.Flow.from_transforms(t2, list(shape), ref, rng.random(shape) > 0.1)
+        got = f1.combine_with(f2, 3)
+        want = O.OFlow(f1.vecs, ref, f1.mask).combine_with(O.OFlow(f2.vecs, ref, f2.mask), 3)
+        assert np.array_equal(got.vecs, want.vecs) and np.array_equal(got.mask, want.mask), (shape, ref)
+print("lds-variant-ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OFL_C3_VARIANT="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "lds-variant-ok" in p.stdout, p.stderr[-2000:]

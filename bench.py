@@ -232,7 +232,7 @@ def main():
                        "parallelism": "independent pairs per GPU x{}".format(world), "rccl_broadcast": rccl_note},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "compose3_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "kernel": "compose3_oneshot_kernel", "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         tpath = os.path.join(ROOT, "profiles", "r01_compose3_traffic.json")

@@ -146,6 +146,7 @@ struct C3Args {
     float *out; uint8_t *mout; uint32_t *stats;
     int sign, H, W, tiles_x, tiles_per_field, ntiles;
     float th;
+    int swz_group;         // one-shot kernel: workgroups per XCD-swizzle group (0 = natural order)
     int ablate;            // development knob (OFL_C3_ABLATE): 1 = skip the gather, 2 = skip the stores; 0 in production
 };
 
@@ -353,7 +354,7 @@ void compose3_kernel(const C3Args a)
 {
     const int nb  = gridDim.x;
     const int per = nb >> 3;
-    const int lane_tile = (nb & 7) == 0 ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const int lane_tile = ((nb & 7) == 0 && a.swz_group != 0) ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
     int tile = lane_tile;
     if (tile >= a.ntiles) return;
     C3Stat st = { 0.0f, 0.0f, 0.0f };
@@ -391,6 +392,30 @@ void compose3_kernel(const C3Args a)
         tile = next;
     }
     if (STATS) c3_flush_stats(a, cur_b, st);
+}
+
+// One workgroup per tile (no persistence, no prefetch): the hardware dispatcher keeps every wave slot
+// filled and the active tiles form a window that sweeps memory in order.
+#ifndef OFL_C3_ONESHOT_WAVES
+#define OFL_C3_ONESHOT_WAVES 6       // waves per SIMD the register allocator is asked to leave room for
+#endif
+template <int QUANT, bool STATS>
+__global__ __launch_bounds__(256, OFL_C3_ONESHOT_WAVES)
+void compose3_oneshot_kernel(const C3Args a)
+{
+    // XCD-aware tile order inside groups of a.swz_group workgroups: the 8 XCDs sweep ONE window of memory
+    // together, each owning a contiguous eighth of it (neighbouring tiles share gather halos in one L2)
+    int tile = blockIdx.x;
+    if (a.swz_group > 0) {
+        const int g = blockIdx.x / a.swz_group, r = blockIdx.x - g * a.swz_group;
+        const int size = min(a.swz_group, (int)gridDim.x - g * a.swz_group);
+        tile = g * a.swz_group + xcd_swizzle(r, size);
+    }
+    if (tile >= a.ntiles) return;
+    C3Stat st = { 0.0f, 0.0f, 0.0f };
+    const C3Stream in = c3_load_stream<kC3LanesX>(a, tile);
+    c3_tile<QUANT, STATS>(a, tile, in, st);
+    if (STATS) c3_flush_stats(a, tile / a.tiles_per_field, st);
 }
 
 // ------------------------------------------------------------------------------------ K2, LDS-staged form
@@ -782,7 +807,7 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
                     T *__restrict__ dst, uint8_t *__restrict__ valid,
                     int quant, int arith, int rule, int tiles_x, int nblocks)
 {
-    const int tile = xcd_swizzle(blockIdx.x, nblocks);
+    const int tile = nblocks > 0 ? xcd_swizzle(blockIdx.x, nblocks) : (int)blockIdx.x;     // nblocks <= 0: natural order
     const int ty   = tile / tiles_x, tx = tile - ty * tiles_x;
     const int lx   = threadIdx.x & 31, y = ty * 8 + (threadIdx.x >> 5);
     const int xg[2] = { tx * 128 + 2 * lx, tx * 128 + 64 + 2 * lx };
@@ -888,10 +913,11 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
     if (W % 2 == 0 && C >= 1 && C <= 4) {
         const int tiles_x = (W + 127) / 128, tiles_y = (H + 7) / 8;
         const int nblocks = tiles_x * tiles_y;
+        static const int swz = getenv("OFL_G2_SWZ") ? atoi(getenv("OFL_G2_SWZ")) : 0;          // tuning knob: 1 = XCD swizzle
 #define OFL_GATHER2_LAUNCH(CT)                                                                           \
         hipLaunchKernelGGL((gather2_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, H, W, \
                            flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,   \
-                           arith, rule, tiles_x, nblocks)
+                           arith, rule, tiles_x, swz ? nblocks : 0)
         switch (C) {
         case 1: OFL_GATHER2_LAUNCH(1); break;
         case 2: OFL_GATHER2_LAUNCH(2); break;
@@ -1000,19 +1026,26 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
 
     if (W % 2 == 0) {
         static const int ablate = getenv("OFL_C3_ABLATE") ? atoi(getenv("OFL_C3_ABLATE")) : 0;
-        static const int variant = getenv("OFL_C3_VARIANT") ? atoi(getenv("OFL_C3_VARIANT")) : 0;   // 0 direct (default), 1 LDS-staged (rotated sampling grids)
+        // -1 / 2 (default): one workgroup per tile in natural order -- the dispatcher keeps every wave slot
+        // filled and all XCDs sweep one window of memory (measured +2..7 % over the persistent kernel at 1..8
+        // 4K pairs per launch); 0 persistent grid with stream prefetch; 1 LDS-staged (rotated sampling grids)
+        static const int variant_env = getenv("OFL_C3_VARIANT") ? atoi(getenv("OFL_C3_VARIANT")) : -1;
+        int variant = variant_env;
         const bool use_lds = variant == 1;
         const int tw = use_lds ? 4 * kLdsLX : kC3TileW, thh = use_lds ? 256 / kLdsLX : kC3TileH;
         const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + thh - 1) / thh;
         const long long nt = (long long)tiles_x * tiles_y * batch;
         if (nt > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
-        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, ablate };
+        static const int swz = getenv("OFL_C3_SWZ") ? atoi(getenv("OFL_C3_SWZ")) : 0;             // tuning knob (0 = natural order: measured best)
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, swz, ablate };
         // persistent grid: what the chip keeps resident (a multiple of 8 = one share per XCD), or one
         // workgroup per tile when the problem is smaller than that
         int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr, use_lds);
+        if (variant < 0) variant = 2;
         if (grid > (int)nt) grid = (int)nt;
         if (grid >= 8) grid &= ~7;
 #define OFL_C3(Q, S) do { if (use_lds) hipLaunchKernelGGL((compose3_lds_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
+                          else if (variant == 2) hipLaunchKernelGGL((compose3_oneshot_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); \
                           else hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); } while (0)
         if (quant == OFL_QUANT_OPENCV) { if (stats) OFL_C3(OFL_QUANT_OPENCV, true); else OFL_C3(OFL_QUANT_OPENCV, false); }
         else                           { if (stats) OFL_C3(OFL_QUANT_EXACT, true);  else OFL_C3(OFL_QUANT_EXACT, false); }

@@ -1,6 +1,7 @@
 // ofl_stats.hip -- K4 zero-flow / finite statistics and K5 element-wise epilogues (gfx950).
 // Pure streaming kernels: 16-byte loads per lane, grid-stride over at most 2048 workgroups.
 #include "ofl_common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -163,7 +164,11 @@ int stream_grid(size_t n_items)
 {
     size_t nb = (n_items + 255) / 256;
     if (nb < 1) nb = 1;
-    const size_t cap = (size_t)rt().n_cu * 8;
+    // One workgroup per 256 items, no persistent cap: on MI355X a copy that is dispatched as one workgroup per
+    // chunk streams at 6.0-6.3 TB/s, the same loop on a resident-sized grid at 5.1-5.3 (tools/copy_sweep.hip).
+    const char *env = getenv("OFL_STREAM_GRID_CAP");          // tuning knob: workgroups per CU, 0 = uncapped
+    const size_t per_cu = env ? (size_t)atoi(env) : 0;
+    const size_t cap = per_cu ? (size_t)rt().n_cu * per_cu : (size_t)0x7fffffff;
     return (int)(nb < cap ? nb : cap);
 }
 

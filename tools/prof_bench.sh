@@ -17,4 +17,4 @@ python3 $ROOT/tools/rocprof_summary.py $OUT/trace $OUT/pmc_* > $OUT/summary.txt 
 grep -h '"metric"' $OUT/trace.log | head -1 > $OUT/bench_line_under_profiler.json
 # keep only the summaries (the raw CSVs of 60 dispatches are small, but drop the .db files)
 find $OUT -name "*.db" -delete
-grep -E "compose3|gather_kernel|scatter|stats_kernel|axpy" $OUT/summary.txt | head -60
+grep -E "compose3|gather2?_kernel|scatter|stats_kernel|axpy" $OUT/summary.txt | head -60

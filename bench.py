@@ -112,7 +112,6 @@ def main():
 
     dist = None
     if world > 1:
-        import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
 

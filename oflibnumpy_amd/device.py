@@ -173,12 +173,6 @@ def flow_stats(vecs_buf, mask_buf, n_px, stream=None):
     return int(out.to_host((1,), np.uint32, stream)[0])
 
 
-def _fold_stat_words(words):
-    a = sum((1 << k) for k in range(4) if words[k])
-    b = sum((1 << k) for k in range(4) if words[4 + k])
-    return a, b
-
-
 def compose3_launch(fa, fb, sign, out, stats_buf=None, stats_offset=0, batch=1, quant=nat.QUANT_OPENCV,
                     stream=None):
     """K2 launch on raw DeviceFlow-like triples; asynchronous.  stats_buf: uint32[batch][8] words."""

@@ -251,9 +251,12 @@ class DeviceFlow:
         return self._axpy(None, -1.0)
 
     # -- warping
-    def apply(self, target, consider_mask=True, quant=nat.QUANT_OPENCV):
+    def apply(self, target, consider_mask=True, quant=nat.QUANT_OPENCV, target_mask=None):
         """Flow.apply with a Flow target (flow_class.py:600-603, 632-684): the target's vectors and mask
-        are warped together; the result keeps the TARGET's reference."""
+        are warped together; the result keeps the TARGET's reference.  A `DeviceImage` target returns
+        (warped DeviceImage, valid-area DeviceBuffer) -- see apply_image."""
+        if isinstance(target, DeviceImage):
+            return self.apply_image(target, target_mask, consider_mask, quant)
         if self.ref == 't':
             if self.is_zero(thresholded=True, masked=False):          # utils.py:215-216
                 return target._and_mask(self)
@@ -262,6 +265,46 @@ class DeviceFlow:
                                          want_valid=True, quant=quant)
             return DeviceFlow(dst.buf, valid, self.shape, target.ref)
         return self._scatter_flow(target, consider_mask)
+
+    def apply_image(self, image, target_mask=None, consider_mask=True, quant=nat.QUANT_OPENCV):
+        """Warp an HBM-resident image [H][W][C] and propagate validity (Flow.apply with an ndarray target and
+        return_valid_area=True, flow_class.py:604-695, without padding).  't': any remap dtype, one launch of
+        the gather kernel; 's': float32 images through the scatter kernel.  `target_mask`: uint8 DeviceBuffer
+        or None (all valid)."""
+        h, w = self.shape
+        if image.shape[:2] != (h, w):
+            raise ValueError("image and flow need the same height and width")
+        if self.ref == 't':
+            if self.is_zero(thresholded=True, masked=False):        # identity short cut, utils.py:215-216
+                valid = DeviceBuffer(self.n_px)
+                if target_mask is None:
+                    nat.check(_lib().ofl_copy_dev(valid.ptr, self.mask.ptr, self.n_px, None))
+                else:
+                    _mask_and(self.mask, target_mask, valid, self.n_px)
+                return image, valid
+            arith, rule = nat.ARITH_NATIVE, nat.RULE_EQ1
+            if image.dtype == np.uint8:      # concat dtype of the reference: bool mask -> uint8, default int8 -> int16
+                arith, rule = (nat.ARITH_NATIVE, nat.RULE_GE_HALF) if target_mask is not None else (nat.ARITH_FLOAT_RNE, nat.RULE_GT_HALF)
+            elif image.dtype == np.int16 or (image.dtype == np.uint16 and target_mask is not None):
+                rule = nat.RULE_GT_HALF
+            elif image.dtype == np.uint16:
+                raise TypeError("uint16 image with the default int8 mask needs an int32 remap, which cv2.remap does not provide")
+            return gather_bilinear(image, self.vecs, self.shape, -1, smask=target_mask, fmask=self.mask,
+                                   want_valid=True, quant=quant, arith=arith, rule=rule)
+        if image.dtype != np.float32:
+            raise TypeError("'s'-reference warps of device images need float32 (got {})".format(image.dtype))
+        C = image.shape[2]
+        vmask = self.mask
+        if target_mask is not None:
+            vmask = DeviceBuffer(self.n_px)
+            _mask_and(target_mask, self.mask, vmask, self.n_px)                  # flow_class.py:643
+        if self.is_zero(thresholded=True, masked=False):
+            return image, vmask
+        out = DeviceImage(DeviceBuffer(self.n_px * C * 4), image.shape, np.float32)
+        valid = DeviceBuffer(self.n_px)
+        scatter_linear(self.vecs, +1, self.mask if consider_mask else None, image.buf, C, vmask, h, w, None,
+                       out.buf, valid, 0)
+        return out, valid
 
     def _and_mask(self, other):
         """vecs unchanged, mask = self.mask & other.mask (zero-flow identity warp of a Flow target)."""

@@ -526,3 +526,28 @@ print("lds-variant-ok")
     env = dict(os.environ, OFL_C3_VARIANT="1")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "lds-variant-ok" in p.stdout, p.stderr[-2000:]
+
+
+def test_device_resident_image_warp(gpu, oracle):
+    """DeviceFlow.apply with an HBM-resident image (no PCIe between operations): 't' for uint8 / float32 with and
+    without a target mask, 's' for float32, against the host API (which is pinned against the oracle above)."""
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    rng = np.random.default_rng(12)
+    shape = (120, 168)
+    tmask = rng.random(shape) > 0.1
+    for ref in ('t', 's'):
+        f = of.Flow.from_transforms([['rotation', 60, 80, 14], ['scaling', 50, 50, 0.92]], list(shape), ref, rng.random(shape) > 0.05)
+        d = f.to_device()
+        for dtype in ((np.uint8, np.float32) if ref == 't' else (np.float32,)):
+            img = (rng.random(shape + (3,)) * 255).astype(dtype)
+            dimg = dev.DeviceImage.from_host(img)
+            for tm in (None, tmask):
+                dtm = dev.DeviceBuffer.from_host(tm.astype(np.uint8)) if tm is not None else None
+                warped, valid = d.apply(dimg, target_mask=dtm)
+                hw, hv = f.apply(img, tm, return_valid_area=True)
+                np.testing.assert_array_equal(warped.to_host(), hw)
+                np.testing.assert_array_equal(valid.to_host(shape, np.uint8).astype(bool), hv)
+    z = of.Flow.zero(list(shape), 't').to_device()
+    w, v = z.apply(dimg)
+    assert w is dimg and v.to_host(shape, np.uint8).all()

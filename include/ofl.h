@@ -212,6 +212,20 @@ int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, cons
 int ofl_mask_and_dev(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, void *stream);
 int ofl_grid_offset_dev(const float *vecs, int sign, int H, int W, float *out, void *stream);
 
+/* ------------------------------------------------------------------ K4: bilinear resize of a flow field
+ * Replaces resize_flow (src/oflibnumpy/utils.py:493-525: cv2.resize(flow, None, fx, fy), INTER_LINEAR, then
+ * vecs[..., 0] *= fx, vecs[..., 1] *= fy) and the mask half of Flow.resize (flow_class.py:501-506:
+ * np.round(cv2.resize(mask.astype('f'), ..))).  The caller supplies the output size Ho = cvRound(H * fy),
+ * Wo = cvRound(W * fx), the inverse scales scale_y = 1 / fy, scale_x = 1 / fx (doubles, as OpenCV derives
+ * them) and the float32 channel factors mul_u = float32(fx), mul_v = float32(fy).
+ * vecs float32[H][W][2] -> out float32[Ho][Wo][2];  mask uint8[H][W] -> mout uint8[Ho][Wo] (both or neither).
+ */
+int ofl_resize_flow(const float *vecs, const uint8_t *mask, int H, int W, int Ho, int Wo,
+                    double scale_y, double scale_x, float mul_u, float mul_v, float *out, uint8_t *mout);
+int ofl_resize_flow_dev(const float *vecs, const uint8_t *mask, int H, int W, int Ho, int Wo,
+                        double scale_y, double scale_x, float mul_u, float mul_v,
+                        float *out, uint8_t *mout, void *stream);
+
 /* ------------------------------------------------------------------ C1: shared-source broadcast (RCCL)
  * The only exchange step of the sharded workload: one broadcast of a shared source image / flow
  * from rank `root` to all ranks over xGMI.  The 128-byte unique id is created on rank 0 with

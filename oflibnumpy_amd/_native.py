@@ -31,7 +31,7 @@ class NoDeviceError(NativeError):
     """No usable HIP device: the MI355X engine has no CPU fallback."""
 
 
-_vp, _ci, _cs, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
+_vp, _ci, _cs, _cf, _cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_double
 _pvp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); must list every symbol of include/ofl.h (tests check this)
@@ -73,6 +73,8 @@ SIGNATURES = {
     "ofl_scatter_query_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _cs, _vp, _vp, _vp, _cs, _vp]),
     "ofl_mask_and_dev": (_ci, [_vp, _vp, _vp, _cs, _vp]),
     "ofl_grid_offset_dev": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
+    "ofl_resize_flow": (_ci, [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _cd, _cf, _cf, _vp, _vp]),
+    "ofl_resize_flow_dev": (_ci, [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _cd, _cf, _cf, _vp, _vp, _vp]),
     "ofl_comm_unique_id": (_ci, [_vp]),
     "ofl_comm_init": (_ci, [_vp, _ci, _ci]),
     "ofl_comm_broadcast": (_ci, [_vp, _cs, _ci, _vp]),

@@ -1,0 +1,144 @@
+// K4: bilinear resize of a flow field and its mask (Flow.resize / resize_flow; reference
+// src/oflibnumpy/utils.py:519-523 and flow_class.py:501-506, which call cv2.resize(.., None, fx, fy) with the
+// default INTER_LINEAR).  One launch resamples the vectors, scales the two channels and rounds the mask.
+// HBM-bound: every source line that is touched is read once (neighbouring output pixels share taps through
+// the vector L1 / L2), every output pixel is written once with 16-byte stores.
+#include "ofl_common.h"
+
+#pragma clang fp contract(off)
+
+using namespace ofl;
+
+namespace {
+
+struct ResizeCoef { int s0, s1; float w0, w1; };
+
+// opencv resize.cpp: fx = (float)((dx + 0.5) * scale - 0.5); sx = floor(fx); fx -= sx.  Columns collapse the tap
+// pair onto the border sample, rows clip the indices and keep the weights.
+__device__ __forceinline__ ResizeCoef resize_coef(int d, double scale, int n, bool clamp_weight)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    ResizeCoef c;
+    if (clamp_weight) {
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= n - 1) { s = n - 1; f = 0.f; }
+        c.s0 = s;
+        c.s1 = min(s + 1, n - 1);
+    } else {
+        c.s0 = min(max(s, 0), n - 1);
+        c.s1 = min(max(s + 1, 0), n - 1);
+    }
+    c.w0 = 1.f - f;
+    c.w1 = f;
+    return c;
+}
+
+__device__ __forceinline__ float resize_blend(float v00, float v01, float v10, float v11, const ResizeCoef &cx, const ResizeCoef &cy)
+{
+    float r0 = v00 * cx.w0; r0 = r0 + v01 * cx.w1;
+    float r1 = v10 * cx.w0; r1 = r1 + v11 * cx.w1;
+    float v = r0 * cy.w0;
+    return v + r1 * cy.w1;
+}
+
+__device__ __forceinline__ float2 resize_px(const float2 *__restrict__ src, const uint8_t *__restrict__ mask, int W,
+                                            const ResizeCoef &cx, const ResizeCoef &cy, float mul_u, float mul_v, uint8_t &m)
+{
+    const size_t i00 = (size_t)cy.s0 * W + cx.s0, i01 = (size_t)cy.s0 * W + cx.s1;
+    const size_t i10 = (size_t)cy.s1 * W + cx.s0, i11 = (size_t)cy.s1 * W + cx.s1;
+    const float2 a = src[i00], b = src[i01], c = src[i10], d = src[i11];
+    if (mask) {
+        const float v = resize_blend((float)(mask[i00] != 0), (float)(mask[i01] != 0), (float)(mask[i10] != 0),
+                                     (float)(mask[i11] != 0), cx, cy);
+        m = (uint8_t)(v > 0.5f);                     // np.round (half to even) of a value in [0, 1]
+    }
+    return make_float2(resize_blend(a.x, b.x, c.x, d.x, cx, cy) * mul_u, resize_blend(a.y, b.y, c.y, d.y, cx, cy) * mul_v);
+}
+
+// block (64, 4): a wave covers 128 consecutive output pixels of one row (two per lane -> 1 KiB per store instruction)
+__global__ __launch_bounds__(256)
+void resize_flow_kernel(const float2 *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W, int Ho, int Wo,
+                        double scale_y, double scale_x, float mul_u, float mul_v,
+                        float2 *__restrict__ out, uint8_t *__restrict__ mout)
+{
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int dx = (blockIdx.x * 64 + threadIdx.x) * 2;
+    if (dy >= Ho || dx >= Wo) return;
+    const ResizeCoef cy = resize_coef(dy, scale_y, H, false);
+    const ResizeCoef cx0 = resize_coef(dx, scale_x, W, true);
+    const size_t o = (size_t)dy * Wo + dx;
+    uint8_t m0 = 0, m1 = 0;
+    const float2 p0 = resize_px(src, mask, W, cx0, cy, mul_u, mul_v, m0);
+    if (dx + 1 < Wo) {
+        const ResizeCoef cx1 = resize_coef(dx + 1, scale_x, W, true);
+        const float2 p1 = resize_px(src, mask, W, cx1, cy, mul_u, mul_v, m1);
+        if ((o & 1) == 0) {                          // 16-byte aligned pair (always when Wo is even)
+            reinterpret_cast<float4 *>(out)[o >> 1] = make_float4(p0.x, p0.y, p1.x, p1.y);
+            if (mout) *reinterpret_cast<uint16_t *>(mout + o) = (uint16_t)(m0 | (m1 << 8));
+        } else {
+            out[o] = p0; out[o + 1] = p1;
+            if (mout) { mout[o] = m0; mout[o + 1] = m1; }
+        }
+    } else {
+        out[o] = p0;
+        if (mout) mout[o] = m0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofl_resize_flow_dev(const float *vecs, const uint8_t *mask, int H, int W, int Ho, int Wo,
+                        double scale_y, double scale_x, float mul_u, float mul_v,
+                        float *out, uint8_t *mout, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!vecs || !out) return fail(OFL_E_INVALID, "ofl_resize_flow: NULL pointer");
+    if (H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return fail(OFL_E_INVALID, "ofl_resize_flow: sizes must be positive");
+    if (!(scale_y > 0.0) || !(scale_x > 0.0)) return fail(OFL_E_INVALID, "ofl_resize_flow: scales must be positive");
+    if ((mask == nullptr) != (mout == nullptr)) return fail(OFL_E_INVALID, "ofl_resize_flow: mask and mout go together");
+    const unsigned gy = (unsigned)((Ho + 3) / 4), gx = (unsigned)((Wo + 127) / 128);
+    if (gy > 65535u) return fail(OFL_E_INVALID, "ofl_resize_flow: output too tall");
+    hipLaunchKernelGGL(resize_flow_kernel, dim3(gx, gy), dim3(64, 4), 0, stream_of(stream),
+                       reinterpret_cast<const float2 *>(vecs), mask, H, W, Ho, Wo, scale_y, scale_x, mul_u, mul_v,
+                       reinterpret_cast<float2 *>(out), mout);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_resize_flow(const float *vecs, const uint8_t *mask, int H, int W, int Ho, int Wo,
+                    double scale_y, double scale_x, float mul_u, float mul_v, float *out, uint8_t *mout)
+{
+    OFL_TRY(need_device());
+    if (!vecs || !out) return fail(OFL_E_INVALID, "ofl_resize_flow: NULL pointer");
+    if (H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return fail(OFL_E_INVALID, "ofl_resize_flow: sizes must be positive");
+    const size_t n_in = (size_t)H * W, n_out = (size_t)Ho * Wo;
+    hipStream_t s = rt().stream;
+    void *dv = nullptr, *dm = nullptr, *dout = nullptr, *dmo = nullptr;
+    int rc = OFL_OK;
+    hipError_t e = hipSuccess;
+    do {
+        if ((e = hipMalloc(&dv, n_in * 8)) != hipSuccess) break;
+        if ((e = hipMalloc(&dout, n_out * 8 + 16)) != hipSuccess) break;
+        if (mask && (e = hipMalloc(&dm, n_in)) != hipSuccess) break;
+        if (mask && (e = hipMalloc(&dmo, n_out + 16)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(dv, vecs, n_in * 8, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if (mask && (e = hipMemcpyAsync(dm, mask, n_in, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((rc = ofl_resize_flow_dev((const float *)dv, (const uint8_t *)dm, H, W, Ho, Wo, scale_y, scale_x, mul_u, mul_v,
+                                      (float *)dout, (uint8_t *)dmo, s)) != OFL_OK) break;
+        if ((e = hipMemcpyAsync(out, dout, n_out * 8, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (mask && (e = hipMemcpyAsync(mout, dmo, n_out, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    if (e != hipSuccess) rc = hip_fail(e, "ofl_resize_flow");
+    if (dv) (void)hipFree(dv);
+    if (dm) (void)hipFree(dm);
+    if (dout) (void)hipFree(dout);
+    if (dmo) (void)hipFree(dmo);
+    return rc;
+}
+
+}  // extern "C"

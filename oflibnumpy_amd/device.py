@@ -306,6 +306,16 @@ class DeviceFlow:
                        out.buf, valid, 0)
         return out, valid
 
+    def resize(self, scale):
+        """Flow.resize (flow_class.py:491-506) on HBM-resident data: one launch of the resize kernel."""
+        fy, fx = resize_scales(scale)
+        h, w = self.shape
+        ho, wo = resized_shape(h, w, fy, fx)
+        out = DeviceFlow.empty((ho, wo), self.ref)
+        nat.check(_lib().ofl_resize_flow_dev(self.vecs.ptr, self.mask.ptr, h, w, ho, wo, 1.0 / fy, 1.0 / fx,
+                                             float(np.float32(fx)), float(np.float32(fy)), out.vecs.ptr, out.mask.ptr, None))
+        return out
+
     def _and_mask(self, other):
         """vecs unchanged, mask = self.mask & other.mask (zero-flow identity warp of a Flow target)."""
         out_mask = DeviceBuffer(self.n_px)
@@ -442,6 +452,45 @@ class DeviceFlow:
 def _mask_and(a, b, out, n):
     """out = a & b for uint8 masks (flow_class.py:643)."""
     nat.check(_lib().ofl_mask_and_dev(a.ptr, b.ptr, out.ptr, n, None))
+
+
+def resize_scales(scale, error_string="Error resizing flow: "):
+    """Validation of resize_flow's `scale` (utils.py:505-518): returns (vertical, horizontal) factors."""
+    if isinstance(scale, (float, int)):
+        scale = [scale, scale]
+    elif isinstance(scale, (tuple, list)):
+        if len(scale) != 2:
+            raise ValueError(error_string + "Scale {} must have a length of 2".format(type(scale)))
+        if not all(isinstance(item, (float, int)) for item in scale):
+            raise ValueError(error_string + "Scale {} items must be integers or floats".format(type(scale)))
+    else:
+        raise TypeError(error_string + "Scale must be an integer, float, or list or tuple of integers or floats")
+    if any(s <= 0 for s in scale):
+        raise ValueError(error_string + "Scale values must be larger than 0")
+    return float(scale[0]), float(scale[1])
+
+
+def resized_shape(h, w, fy, fx):
+    """cv2.resize(dsize=None, fx, fy): dsize = (cvRound(W * fx), cvRound(H * fy)), round half to even."""
+    ho, wo = int(np.rint(h * fy)), int(np.rint(w * fx))
+    if ho <= 0 or wo <= 0:
+        raise ValueError("Error resizing flow: scale {} leaves no pixels of a {}x{} field".format((fy, fx), h, w))
+    return ho, wo
+
+
+def resize_host(vecs, mask, scale):
+    """resize_flow / Flow.resize for host arrays through ofl_resize_flow (upload, one launch, download)."""
+    fy, fx = resize_scales(scale)
+    vecs = np.ascontiguousarray(vecs, np.float32)
+    h, w = vecs.shape[:2]
+    ho, wo = resized_shape(h, w, fy, fx)
+    out = np.empty((ho, wo, 2), np.float32)
+    m = None if mask is None else np.ascontiguousarray(mask).astype(np.uint8)
+    mout = None if mask is None else np.empty((ho, wo), np.uint8)
+    hp = lambda a: None if a is None else a.ctypes.data
+    nat.check(_lib().ofl_resize_flow(hp(vecs), hp(m), h, w, ho, wo, 1.0 / fy, 1.0 / fx,
+                                     float(np.float32(fx)), float(np.float32(fy)), hp(out), hp(mout)))
+    return out, (None if mout is None else mout.astype(bool))
 
 
 def grid_minus(vecs, out, h, w):

@@ -8,7 +8,7 @@ use `DeviceFlow` directly.
 
 Next-tier row already widened into: `track` / `track_pts`.
 Dataset loaders (KITTI, Sintel + mask) are host I/O with a small built-in PNG reader.
-Out of scope (not on the hot path): resize, matrix fitting, visualisation.
+Out of scope (not on the hot path): matrix fitting, visualisation.
 """
 from __future__ import annotations
 
@@ -188,6 +188,13 @@ class Flow(object):
 
     def __neg__(self) -> FlowAlias:
         return self * -1
+
+    def resize(self, scale: Union[float, int, list, tuple]) -> FlowAlias:
+        """Resize the flow field, scaling the vectors accordingly; the mask is resized bilinearly and rounded
+        (flow_class.py:491-506)."""
+        dev.resize_scales(scale)
+        vecs, mask = dev.resize_host(self._vecs, self._mask, scale)
+        return Flow(vecs, self._ref, mask)
 
     def pad(self, padding: Union[list, tuple] = None, mode: str = None) -> FlowAlias:
         """Pad vecs ('constant' zeros, 'edge' or 'symmetric') and the mask with False (flow_class.py:508-526)."""

@@ -8,7 +8,7 @@ import numpy as np
 from .flow_class import Flow
 
 nd = np.ndarray
-__all__ = ['combine_flows', 'switch_flow_ref', 'invert_flow', 'valid_target', 'valid_source']
+__all__ = ['combine_flows', 'switch_flow_ref', 'invert_flow', 'valid_target', 'valid_source', 'get_flow_padding']
 
 
 def combine_flows(input_1: Union[Flow, nd], input_2: Union[Flow, nd], mode: int, ref: str = None,
@@ -42,3 +42,8 @@ def valid_target(flow: nd, ref: str) -> nd:
 def valid_source(flow: nd, ref: str) -> nd:
     """Boolean valid area in the source domain (reference flow_operations.py:213-228)."""
     return Flow(flow, ref).valid_source()
+
+
+def get_flow_padding(flow: nd, ref: str) -> list:
+    """Padding [top, bottom, left, right] needed to keep every warped pixel (reference flow_operations.py:231-248)."""
+    return Flow(flow, ref).get_padding()

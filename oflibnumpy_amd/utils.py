@@ -192,6 +192,14 @@ def load_sintel_mask(path: str) -> nd:
 
 
 # --------------------------------------------------------------------------- zero-flow predicates
+def resize_flow(flow: nd, scale: Union[float, int, list, tuple]) -> nd:
+    """Resize a flow field array and scale its vectors accordingly (reference utils.py:493-525): bilinear
+    cv2.resize semantics, one launch of the resize kernel (ofl_resize_flow)."""
+    flow = validate_flow_array(flow, "Error resizing flow: ")
+    dev.resize_scales(scale)
+    return dev.resize_host(flow, None, scale)[0]
+
+
 def threshold_vectors(vecs: nd, threshold: Union[float, int] = None, use_mag: bool = None) -> nd:
     """Copy with small vectors zeroed: per component |v| < threshold, or by magnitude (utils.py:298-316)."""
     threshold = DEFAULT_THRESHOLD if threshold is None else threshold

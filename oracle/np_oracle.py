@@ -59,6 +59,9 @@ def lib():
         L.orc_compose3.restype = ci
         L.orc_is_zero.argtypes = [vp, vp, cs, ci, ctypes.c_double]
         L.orc_is_zero.restype = ci
+        L.orc_resize_flow.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_float, ctypes.c_float, vp, vp]
+        L.orc_resize_flow.restype = ci
         L.orc_set_threads.argtypes = [ci]
         L.orc_set_threads.restype = ci
         _lib = L
@@ -119,6 +122,21 @@ def is_zero_raw(vecs, mask=None, thresholded=True):
     m = _mask_u8(mask)
     return bool(lib().orc_is_zero(_p(vecs), _p(m), vecs.size // 2, int(bool(thresholded)),
                                   DEFAULT_THRESHOLD))
+
+
+def resize_flow(flow, scale, mask=None):
+    """utils.py:493-525 (+ the mask of flow_class.py:504-506 when `mask` is given): cv2.resize(INTER_LINEAR)."""
+    scale = [scale, scale] if isinstance(scale, (int, float)) else list(scale)
+    flow = np.ascontiguousarray(flow, np.float32)
+    H, W = flow.shape[:2]
+    Ho, Wo = int(np.rint(H * scale[0])), int(np.rint(W * scale[1]))        # saturate_cast<int>(double) = cvRound
+    out = np.empty((Ho, Wo, 2), np.float32)
+    m = _mask_u8(mask)
+    mout = np.empty((Ho, Wo), np.uint8) if mask is not None else None
+    rc = lib().orc_resize_flow(_p(flow), _p(m), H, W, Ho, Wo, 1.0 / scale[0], 1.0 / scale[1],
+                               float(np.float32(scale[1])), float(np.float32(scale[0])), _p(out), _p(mout))
+    assert rc == 0
+    return (out, mout.astype(bool)) if mask is not None else out
 
 
 # ----------------------------------------------------------------- L1: apply_flow restated
@@ -192,6 +210,11 @@ class OFlow:
         """flow_class.py:1230-1245."""
         f = self.vecs[self.mask][None] if masked else self.vecs
         return is_zero_flow(f, thresholded)
+
+    def resize(self, scale):
+        """flow_class.py:491-506."""
+        v, m = resize_flow(self.vecs, scale, self.mask)
+        return OFlow(v, self.ref, m)
 
     def pad(self, padding, mode='constant'):
         """flow_class.py:508-526."""

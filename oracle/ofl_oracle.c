@@ -302,3 +302,69 @@ int orc_is_zero(const float *flow, const uint8_t *mask, size_t n_px, int thresho
     }
     return zero;
 }
+
+/*
+ * Flow.resize / resize_flow  (utils.py:519-523, flow_class.py:501-506): cv2.resize(.., None, fx, fy) with the
+ * default INTER_LINEAR on the float32 vectors and on mask.astype('f'), per-channel vector scaling, np.round
+ * of the mask.  OpenCV is not vendored by the reference (parity unpinned below float rounding); this follows
+ * the published algorithm of opencv 4.2 modules/imgproc/src/resize.cpp (resize() -> resizeGeneric_ with
+ * HResizeLinear / VResizeLinear for float): per output column
+ *     fx = (float)((dx + 0.5) * scale_x - 0.5); sx = floor(fx); fx -= sx;
+ *     sx < 0 -> (sx, fx) = (0, 0);  sx >= W-1 -> (sx, fx) = (W-1, 0)
+ * rows alike but with the row INDICES clipped to [0, H-1] and the weights kept; horizontal pass
+ * S[sx]*(1-fx) + S[sx+1]*fx first, then vertical R0*(1-fy) + R1*fy, all float32, no contraction.
+ * (For fx = fy = 0.5 exactly OpenCV dispatches to its 2x2 area average, the same value up to the
+ * summation order of four floats.)  scale_x, scale_y = 1/fx, 1/fy as doubles; Ho, Wo = cvRound(H*fy), ..
+ * mul_u, mul_v: float32 factors applied to channel 0 / 1 (utils.py:521-522).
+ * Mask: interpolated as float32 0/1, np.round half-to-even -> valid iff value > 0.5 (flow_class.py:504-506).
+ */
+static void orc_resize_coef(int d, double scale, int n, int clamp_weight, int *s0, int *s1, float *w0, float *w1)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp_weight) {             /* columns: the tap pair collapses on the border sample */
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= n - 1) { s = n - 1; f = 0.f; }
+        *s0 = s;
+        *s1 = s + 1 < n ? s + 1 : n - 1;
+    } else {                        /* rows: indices clipped, weights kept */
+        *s0 = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
+        *s1 = s + 1 < 0 ? 0 : (s + 1 > n - 1 ? n - 1 : s + 1);
+    }
+    *w0 = 1.f - f;
+    *w1 = f;
+}
+
+int orc_resize_flow(const float *vecs, const uint8_t *mask, int H, int W, int Ho, int Wo,
+                    double scale_y, double scale_x, float mul_u, float mul_v, float *out, uint8_t *mout)
+{
+    if (!vecs || !out || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return 1;
+#pragma omp parallel for schedule(static)
+    for (int dy = 0; dy < Ho; ++dy) {
+        int y0, y1;
+        float b0, b1;
+        orc_resize_coef(dy, scale_y, H, 0, &y0, &y1, &b0, &b1);
+        for (int dx = 0; dx < Wo; ++dx) {
+            int x0, x1;
+            float a0, a1;
+            orc_resize_coef(dx, scale_x, W, 1, &x0, &x1, &a0, &a1);
+            const size_t i00 = (size_t)y0 * W + x0, i01 = (size_t)y0 * W + x1;
+            const size_t i10 = (size_t)y1 * W + x0, i11 = (size_t)y1 * W + x1;
+            const size_t o = (size_t)dy * Wo + dx;
+            for (int c = 0; c < 2; ++c) {
+                float r0 = vecs[i00 * 2 + c] * a0; r0 = r0 + vecs[i01 * 2 + c] * a1;
+                float r1 = vecs[i10 * 2 + c] * a0; r1 = r1 + vecs[i11 * 2 + c] * a1;
+                float v = r0 * b0; v = v + r1 * b1;
+                out[o * 2 + c] = v * (c == 0 ? mul_u : mul_v);
+            }
+            if (mask && mout) {
+                float r0 = (float)(mask[i00] != 0) * a0; r0 = r0 + (float)(mask[i01] != 0) * a1;
+                float r1 = (float)(mask[i10] != 0) * a0; r1 = r1 + (float)(mask[i11] != 0) * a1;
+                float v = r0 * b0; v = v + r1 * b1;
+                mout[o] = (uint8_t)(v > 0.5f);
+            }
+        }
+    }
+    return 0;
+}

@@ -551,3 +551,45 @@ def test_device_resident_image_warp(gpu, oracle):
     z = of.Flow.zero(list(shape), 't').to_device()
     w, v = z.apply(dimg)
     assert w is dimg and v.to_host(shape, np.uint8).all()
+
+
+def test_resize_matches_oracle(gpu, oracle):
+    """Flow.resize / resize_flow / DeviceFlow.resize: bit-exact against the oracle (which reproduces the
+    reference's known answers, tests/test_oracle.py) for up-, down-, anisotropic and non-integer scales, odd
+    sizes, speckled masks; plus the reference's own mask known answer (tests/test_flow_class.py:380-389)."""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(21)
+    for shape in ((20, 10), (37, 53), (64, 129), (1, 7), (9, 1)):
+        vecs = (rng.standard_normal(shape + (2,)) * 5).astype(np.float32)
+        mask = rng.random(shape) > 0.3
+        f = of.Flow(vecs, 's', mask)
+        for scale in (.2, .5, 1, 1.5, 2, 10, 1 / 3, (0.5, 2), (2, 0.5), [1.7, 0.9], 3):
+            fy, fx = (scale, scale) if isinstance(scale, (int, float)) else scale
+            if int(np.rint(shape[0] * fy)) <= 0 or int(np.rint(shape[1] * fx)) <= 0:
+                with pytest.raises(ValueError):
+                    f.resize(scale)
+                continue
+            ev, em = O.resize_flow(vecs, scale, mask)
+            r = f.resize(scale)
+            assert r.ref == 's'
+            np.testing.assert_array_equal(r.vecs, ev)
+            np.testing.assert_array_equal(r.mask, em)
+            np.testing.assert_array_equal(of.resize_flow(vecs, scale), ev)
+            dv, dm = f.to_device().resize(scale).to_host()
+            np.testing.assert_array_equal(dv, ev)
+            np.testing.assert_array_equal(dm, em)
+    small, large = (20, 40), (30, 80)
+    m_small = np.ones(small, bool)
+    m_small[:6, :20] = False
+    m_large = np.ones(large, bool)
+    m_large[:9, :40] = False
+    fl = of.Flow.from_transforms([['rotation', 0, 0, 30]], small, 't', m_small).resize((1.5, 2))
+    np.testing.assert_array_equal(fl.mask, m_large)
+    big = of.Flow.from_transforms([['rotation', 0, 0, 30]], (150, 240), 't')
+    np.testing.assert_allclose(big.resize(1 / 3).vecs, of.Flow.from_transforms([['rotation', 0, 0, 30]], (50, 80), 't').vecs,
+                               atol=1, rtol=.1)
+    # full size: 4K -> 1080p -> 4K keeps an affine field (interior) and runs the big grid
+    f4k = of.Flow.from_transforms([['scaling', 1000, 800, 0.9]], (2160, 3840), 't')
+    half = f4k.resize(0.5)
+    assert half.shape == (1080, 1920)
+    np.testing.assert_allclose(half.vecs[2:-2, 2:-2], of.Flow.from_transforms([['scaling', 500 - 0.25, 400 - 0.25, 0.9]], (1080, 1920), 't').vecs[2:-2, 2:-2], atol=2e-3)

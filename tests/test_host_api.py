@@ -161,6 +161,7 @@ def test_operators():
 def test_pad_and_get_padding():
     f = of.Flow.from_transforms([['rotation', 0, 0, 45]], (7, 7), 's')
     assert f.get_padding() == [5, 0, 0, 3]                       # reference test_get_padding
+    assert of.get_flow_padding(f.vecs, f.ref) == [5, 0, 0, 3]
     ft = of.Flow.from_transforms([['rotation', 0, 0, 45]], (7, 7), 't')
     assert ft.get_padding() == [0, 3, 5, 0]
     m = np.ones((7, 7), bool)
@@ -344,3 +345,23 @@ def test_dataset_loaders():
         of.Flow.from_sintel(g("sintel.flo"), 'test.png')
     with pytest.raises(ValueError):
         of.Flow.from_sintel(g("sintel.flo"), g("sintel_invalid_wrong.png"))
+
+
+def test_resize_argument_validation():
+    """Error types of reference tests/test_utils.py:506-518 -- raised before anything touches the GPU."""
+    flow = of.Flow.from_transforms([['rotation', 30, 50, 30]], [20, 10], 's')
+    for fn in (lambda s: of.resize_flow(flow.vecs, s), flow.resize):
+        with pytest.raises(TypeError):
+            fn('test')
+        with pytest.raises(ValueError):
+            fn(['test', 0])
+        with pytest.raises(ValueError):
+            fn([1, 2, 3])
+        with pytest.raises(ValueError):
+            fn(0)
+        with pytest.raises(ValueError):
+            fn(-0.1)
+    with pytest.raises(TypeError):
+        of.resize_flow('test', 1)
+    with pytest.raises(ValueError):
+        of.resize_flow(np.zeros((5, 5, 3)), 1)

@@ -156,3 +156,45 @@ def test_oracle_track_pts_matches_reference(oracle, golden):
                 np.testing.assert_array_equal(oracle.track_pts(flow, ref, pf, s_exact_mode=True), g[tag + '/exact'])
             n += 1
     assert n == 4
+
+
+def test_oracle_resize_reference_known_answers(oracle):
+    """Restates the reference's resize tests on the oracle: the exact mask of tests/test_flow_class.py:380-389,
+    the shapes and corner vectors of tests/test_utils.py:472-496, and the field test of :498-504."""
+    O = oracle
+    small, large = (20, 40), (30, 80)
+    m_small = np.ones(small, bool)
+    m_small[:6, :20] = False
+    m_large = np.ones(large, bool)
+    m_large[:9, :40] = False
+    f = O.from_transforms([['rotation', 0, 0, 30]], small, 't', m_small).resize((1.5, 2))
+    assert f.vecs.shape == large + (2,) and f.ref == 't'
+    np.testing.assert_array_equal(f.mask, m_large)
+
+    shape = [20, 10]
+    flow = O.from_transforms([['rotation', 30, 50, 30]], shape, 's').vecs
+    for scale in (.2, .5, 1, 1.5, 2, 10):
+        r = O.resize_flow(flow, scale)
+        np.testing.assert_array_equal(r.shape[:2], scale * np.array(shape))
+        np.testing.assert_allclose(r[0, 0], flow[0, 0] * scale, rtol=.1)
+    np.testing.assert_array_equal(O.resize_flow(flow, 1), flow)                   # identity is exact
+    for scale in ([.5, 2], (2, .5)):
+        r = O.resize_flow(flow, scale)
+        np.testing.assert_array_equal(r.shape[:2], np.array(scale) * np.array(shape))
+        np.testing.assert_allclose(r[0, 0], flow[0, 0] * np.array(scale)[::-1], rtol=.1)
+    f_small = O.from_transforms([['rotation', 0, 0, 30]], (50, 80), 't').vecs
+    f_large = O.from_transforms([['rotation', 0, 0, 30]], (150, 240), 't').vecs
+    np.testing.assert_allclose(O.resize_flow(f_large, 1 / 3), f_small, atol=1, rtol=.1)
+    # an affine field is reproduced by linear interpolation away from the replicated border: resizing by an
+    # integer factor k maps output node d to source (d + 0.5) / k - 0.5
+    aff = O.from_transforms([['rotation', 10, 20, 25], ['scaling', 0, 0, 1.1]], (40, 60), 't').vecs
+    up = O.resize_flow(aff, 2)
+    yy, xx = np.mgrid[:80, :120]
+    sy, sx = (yy + 0.5) / 2 - 0.5, (xx + 0.5) / 2 - 0.5
+    inner = (sy >= 0) & (sy <= 39) & (sx >= 0) & (sx <= 59)
+    m = O.matrix_from_transforms([['rotation', 10, 20, 25], ['scaling', 0, 0, 1.1]])
+    inv = np.linalg.inv(m)
+    expect_u = (sx - (inv[0, 0] * sx + inv[0, 1] * sy + inv[0, 2])) * 2
+    expect_v = (sy - (inv[1, 0] * sx + inv[1, 1] * sy + inv[1, 2])) * 2
+    np.testing.assert_allclose(up[..., 0][inner], expect_u[inner], atol=2e-4)
+    np.testing.assert_allclose(up[..., 1][inner], expect_v[inner], atol=2e-4)

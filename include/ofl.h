@@ -139,6 +139,16 @@ int ofl_gather_bilinear_dev(const void *src, int dtype, int C, int H, int W,
                             const uint8_t *smask, const uint8_t *fmask,
                             void *dst, uint8_t *valid,
                             int quant, int arith, int rule, void *stream);
+/* One row band of the same result, for a field split over several GPUs: the source
+ * image (and smask) are replicated, each rank holds rows [row0, row0 + rows) of the flow / its mask and
+ * produces the same rows of dst / valid:
+ *     dst_rows[y][x][c] = B(src[..][c]; (x, row0 + y) + sign * flow_rows[y][x]),  0 <= y < rows
+ * flow_rows [rows][W][2], fmask_rows [rows][W] or NULL, dst_rows [rows][W][C], valid_rows [rows][W] or NULL.
+ * Bands are disjoint, so there is no exchange step after the launch.
+ */
+int ofl_gather_rows_dev(const void *src, int dtype, int C, int H, int W, int row0, int rows,
+                        const float *flow_rows, int sign, const uint8_t *smask, const uint8_t *fmask_rows,
+                        void *dst_rows, uint8_t *valid_rows, int quant, int arith, int rule, void *stream);
 int ofl_gather_bilinear(const void *src, int dtype, int C, int H, int W,
                         const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
                         const uint8_t *smask, const uint8_t *fmask,

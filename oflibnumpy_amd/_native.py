@@ -59,6 +59,7 @@ SIGNATURES = {
     "ofl_mem_info": (_ci, [ctypes.POINTER(_cs), ctypes.POINTER(_cs)]),
     "ofl_compose3_dev": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp]),
     "ofl_compose3": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci]),
+    "ofl_gather_rows_dev": (_ci, [_vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _vp]),
     "ofl_gather_bilinear_dev": (_ci, [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp,
                                       _ci, _ci, _ci, _vp]),
     "ofl_gather_bilinear": (_ci, [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp,

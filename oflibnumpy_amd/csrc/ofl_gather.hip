@@ -671,14 +671,15 @@ void gather_kernel(const T *__restrict__ src, int Crt, int H, int W,
                    const float *__restrict__ flow, int fH, int fW, int pad_top, int pad_left, int sign,
                    const uint8_t *__restrict__ smask, const uint8_t *__restrict__ fmask,
                    T *__restrict__ dst, uint8_t *__restrict__ valid,
-                   int quant, int arith, int rule, int tiles_x, int nblocks)
+                   int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows)
 {
     const int C    = CT > 0 ? CT : Crt;
     const int tile = xcd_swizzle(blockIdx.x, nblocks);
     const int ty   = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x    = tx * 32 + (threadIdx.x & 31);
-    const int y    = ty * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
+    const int yl   = ty * 8 + (threadIdx.x >> 5);           // row inside the output band [row0, row0 + rows)
+    const int y    = row0 + yl;
+    if (x >= W || yl >= rows) return;
 
     float fu = 0.0f, fv = 0.0f;
     const int  fy = y - pad_top, fx = x - pad_left;
@@ -707,7 +708,7 @@ void gather_kernel(const T *__restrict__ src, int Crt, int H, int W,
         in[k]  = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
         off[k] = in[k] ? (size_t)yy * W + xx : 0;
     }
-    const size_t o = (size_t)y * W + x;
+    const size_t o = (size_t)yl * W + x;
     const bool fixed_u8 = (sizeof(T) == 1) && arith == OFL_ARITH_NATIVE;
 
     auto do_channel = [&](int cc) {
@@ -805,13 +806,13 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
                     const float *__restrict__ flow, int fH, int fW, int pad_top, int pad_left, int sign,
                     const uint8_t *__restrict__ smask, const uint8_t *__restrict__ fmask,
                     T *__restrict__ dst, uint8_t *__restrict__ valid,
-                    int quant, int arith, int rule, int tiles_x, int nblocks)
+                    int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows)
 {
     const int tile = nblocks > 0 ? xcd_swizzle(blockIdx.x, nblocks) : (int)blockIdx.x;     // nblocks <= 0: natural order
     const int ty   = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int lx   = threadIdx.x & 31, y = ty * 8 + (threadIdx.x >> 5);
+    const int lx   = threadIdx.x & 31, yl = ty * 8 + (threadIdx.x >> 5), y = row0 + yl;     // output band [row0, row0 + rows)
     const int xg[2] = { tx * 128 + 2 * lx, tx * 128 + 64 + 2 * lx };
-    const bool act[2] = { y < H && xg[0] < W, y < H && xg[1] < W };
+    const bool act[2] = { yl < rows && xg[0] < W, yl < rows && xg[1] < W };
     const int  fy = y - pad_top;
     const bool row_in_flow = (unsigned)fy < (unsigned)fH;
     const bool aligned = ((pad_left | fW) & 1) == 0;          // 16-byte aligned flow pairs
@@ -883,7 +884,7 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (!act[g]) continue;
-        const size_t o = (size_t)y * W + xg[g];
+        const size_t o = (size_t)yl * W + xg[g];
         T *d = dst + o * CT;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -908,16 +909,16 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
 template <typename T>
 int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int fH, int fW, int pad_top,
                     int pad_left, int sign, const uint8_t *smask, const uint8_t *fmask, void *dst,
-                    uint8_t *valid, int quant, int arith, int rule, hipStream_t s)
+                    uint8_t *valid, int quant, int arith, int rule, int row0, int rows, hipStream_t s)
 {
     if (W % 2 == 0 && C >= 1 && C <= 4) {
-        const int tiles_x = (W + 127) / 128, tiles_y = (H + 7) / 8;
+        const int tiles_x = (W + 127) / 128, tiles_y = (rows + 7) / 8;
         const int nblocks = tiles_x * tiles_y;
         static const int swz = getenv("OFL_G2_SWZ") ? atoi(getenv("OFL_G2_SWZ")) : 0;          // tuning knob: 1 = XCD swizzle
 #define OFL_GATHER2_LAUNCH(CT)                                                                           \
         hipLaunchKernelGGL((gather2_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, H, W, \
                            flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,   \
-                           arith, rule, tiles_x, swz ? nblocks : 0)
+                           arith, rule, tiles_x, swz ? nblocks : 0, row0, rows)
         switch (C) {
         case 1: OFL_GATHER2_LAUNCH(1); break;
         case 2: OFL_GATHER2_LAUNCH(2); break;
@@ -928,12 +929,12 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
         OFL_HIP(hipGetLastError());
         return OFL_OK;
     }
-    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    const int tiles_x = (W + 31) / 32, tiles_y = (rows + 7) / 8;
     const int nblocks = tiles_x * tiles_y;
 #define OFL_GATHER_LAUNCH(CT)                                                                          \
     hipLaunchKernelGGL((gather_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, C, H, W, \
                        flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,     \
-                       arith, rule, tiles_x, nblocks)
+                       arith, rule, tiles_x, nblocks, row0, rows)
     switch (C) {
     case 1: OFL_GATHER_LAUNCH(1); break;
     case 2: OFL_GATHER_LAUNCH(2); break;
@@ -1105,11 +1106,11 @@ int ofl_compose3(const float *fa, const uint8_t *ma, const float *fb, const uint
     return OFL_OK;
 }
 
-int ofl_gather_bilinear_dev(const void *src, int dtype, int C, int H, int W,
+static int gather_rows_impl(const void *src, int dtype, int C, int H, int W,
                             const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
                             const uint8_t *smask, const uint8_t *fmask,
                             void *dst, uint8_t *valid,
-                            int quant, int arith, int rule, void *stream)
+                            int quant, int arith, int rule, int row0, int rows, void *stream)
 {
     OFL_TRY(need_device());
     OFL_TRY(check_dims("ofl_gather_bilinear", H, W));
@@ -1129,14 +1130,35 @@ int ofl_gather_bilinear_dev(const void *src, int dtype, int C, int H, int W,
     if (quant != OFL_QUANT_OPENCV && quant != OFL_QUANT_EXACT) return fail(OFL_E_INVALID, "ofl_gather_bilinear: bad quant");
     if (rule < OFL_RULE_EQ1 || rule > OFL_RULE_GT_HALF) return fail(OFL_E_INVALID, "ofl_gather_bilinear: bad rule");
     if (arith != OFL_ARITH_NATIVE && arith != OFL_ARITH_FLOAT_RNE) return fail(OFL_E_INVALID, "ofl_gather_bilinear: bad arith");
+    if (row0 < 0 || rows <= 0 || row0 + rows > H)
+        return fail(OFL_E_INVALID, "ofl_gather_bilinear: rows [%d, %d) outside the %d-row result", row0, row0 + rows, H);
     hipStream_t s = stream_of(stream);
     switch (dtype) {
-    case OFL_U8:  return launch_gather_t<uint8_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, s);
-    case OFL_I16: return launch_gather_t<int16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, s);
-    case OFL_U16: return launch_gather_t<uint16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, s);
-    case OFL_F32: return launch_gather_t<float>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, s);
-    default:      return launch_gather_t<double>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, s);
+    case OFL_U8:  return launch_gather_t<uint8_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
+    case OFL_I16: return launch_gather_t<int16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
+    case OFL_U16: return launch_gather_t<uint16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
+    case OFL_F32: return launch_gather_t<float>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
+    default:      return launch_gather_t<double>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
     }
+}
+
+int ofl_gather_bilinear_dev(const void *src, int dtype, int C, int H, int W,
+                            const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
+                            const uint8_t *smask, const uint8_t *fmask,
+                            void *dst, uint8_t *valid,
+                            int quant, int arith, int rule, void *stream)
+{
+    return gather_rows_impl(src, dtype, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid,
+                            quant, arith, rule, 0, H, stream);
+}
+
+int ofl_gather_rows_dev(const void *src, int dtype, int C, int H, int W, int row0, int rows,
+                        const float *flow_rows, int sign, const uint8_t *smask, const uint8_t *fmask_rows,
+                        void *dst_rows, uint8_t *valid_rows, int quant, int arith, int rule, void *stream)
+{
+    if (rows <= 0 || row0 < 0) return fail(OFL_E_INVALID, "ofl_gather_rows: bad row band");
+    return gather_rows_impl(src, dtype, C, H, W, flow_rows, rows, W, row0, 0, sign, smask, fmask_rows, dst_rows, valid_rows,
+                            quant, arith, rule, row0, rows, stream);
 }
 
 int ofl_gather_bilinear(const void *src, int dtype, int C, int H, int W,

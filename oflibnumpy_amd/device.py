@@ -153,6 +153,21 @@ def gather_bilinear(src, flow_buf, flow_shape, sign, smask=None, fmask=None, wan
     return dst, valid
 
 
+def gather_rows(src, row0, rows, flow_rows, sign, smask=None, fmask_rows=None, want_valid=False,
+                quant=nat.QUANT_OPENCV, arith=nat.ARITH_NATIVE, rule=nat.RULE_EQ1, stream=None):
+    """K1 on one row band of a field split over several GPUs: `src` is the replicated
+    H x W image, `flow_rows` / `fmask_rows` hold rows [row0, row0 + rows) only; returns the same rows of the
+    warped image (and of the valid area)."""
+    H, W, C = src.shape
+    dst = DeviceImage(DeviceBuffer(rows * W * C * src.dtype.itemsize), (rows, W, C), src.dtype)
+    valid = DeviceBuffer(rows * W) if want_valid else None
+    nat.check(_lib().ofl_gather_rows_dev(
+        src.buf.ptr, _DT_CODE[src.dtype], C, H, W, row0, rows, flow_rows.ptr, sign,
+        smask.ptr if smask is not None else None, fmask_rows.ptr if fmask_rows is not None else None,
+        dst.buf.ptr, valid.ptr if valid is not None else None, quant, arith, rule, stream))
+    return dst, valid
+
+
 def gather_valid_only(H, W, flow_buf, flow_shape, sign, smask=None, fmask=None, pad=(0, 0),
                       quant=nat.QUANT_OPENCV, rule=nat.RULE_EQ1, stream=None):
     """K1 without image channels: where does a warped all-ones (or smask) image stay == 1?

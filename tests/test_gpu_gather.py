@@ -383,6 +383,25 @@ def test_config5_tiled_sintel_apply(gpu, oracle):
     np.testing.assert_array_equal(f.apply(u8), oracle.OFlow(big, 't', f.mask).apply(u8))
     bands = [sharding.row_band(H, r, 8) for r in range(8)]
     assert bands[0][0] == 0 and bands[-1][1] == H and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+    # each rank's launch (ofl_gather_rows_dev): replicated image and target mask, its own rows of the flow
+    from oflibnumpy_amd import device as dev
+    dimg, dtm = dev.DeviceImage.from_host(img), dev.DeviceBuffer.from_host(tmask.astype(np.uint8))
+    for world in (8, 3):
+        parts, vparts = [], []
+        for r in range(world):
+            r0, r1 = sharding.row_band(H, r, world)
+            fl = dev.DeviceBuffer.from_host(np.ascontiguousarray(big[r0:r1]))
+            fm = dev.DeviceBuffer.from_host(np.ascontiguousarray(f.mask[r0:r1]).astype(np.uint8))
+            d, vv = dev.gather_rows(dimg, r0, r1 - r0, fl, -1, smask=dtm, fmask_rows=fm, want_valid=True)
+            parts.append(d.to_host())
+            vparts.append(vv.to_host((r1 - r0, W), np.uint8).astype(bool))
+        np.testing.assert_array_equal(np.concatenate(parts), ow)
+        np.testing.assert_array_equal(np.concatenate(vparts), ov)
+    odd = dev.DeviceImage.from_host(np.ascontiguousarray(img[:, :W - 1]))          # odd width: generic kernel
+    ow_odd = oracle.OFlow(big[:, :W - 1], 't').apply(img[:, :W - 1])
+    r0, r1 = 16, 203
+    d, _ = dev.gather_rows(odd, r0, r1 - r0, dev.DeviceBuffer.from_host(np.ascontiguousarray(big[r0:r1, :W - 1])), -1)
+    np.testing.assert_array_equal(d.to_host(), ow_odd[r0:r1])
     # as loaded ('s', Flow.from_sintel): the scatter path runs; cells shear too far for the cell-wise
     # triangulation to be Delaunay, so only structural properties are pinned here (deviation c)
     fs = of.Flow(big, 's')

@@ -220,6 +220,13 @@ int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, cons
  *   ofl_grid_offset_dev  out[y][x] = float32((x, y) + sign * vecs[y][x])   (flow_class.py:1398-1406)
  */
 int ofl_mask_and_dev(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, void *stream);
+/*   ofl_flow_extent_dev  extent (device float32[4]) = { min y, max y, min x, max x } of the positions
+ *                        float32((x, y) + sign * threshold_vectors(vecs)[y][x]) over the masked pixels
+ *                        (Flow.get_padding, flow_class.py:1214-1226: sign -1 for ref 't', +1 for 's');
+ *                        { +inf, -inf, +inf, -inf } when no pixel is masked
+ */
+int ofl_flow_extent_dev(const float *vecs, const uint8_t *mask, int H, int W, int sign, float threshold,
+                        float *extent, void *stream);
 int ofl_grid_offset_dev(const float *vecs, int sign, int H, int W, float *out, void *stream);
 
 /* ------------------------------------------------------------------ K4: bilinear resize of a flow field

@@ -72,6 +72,7 @@ SIGNATURES = {
     "ofl_scatter_linear": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci]),
     "ofl_sample_points_dev": (_ci, [_vp, _ci, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_query_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _cs, _vp, _vp, _vp, _cs, _vp]),
+    "ofl_flow_extent_dev": (_ci, [_vp, _vp, _ci, _ci, _ci, _cf, _vp, _vp]),
     "ofl_mask_and_dev": (_ci, [_vp, _vp, _vp, _cs, _vp]),
     "ofl_grid_offset_dev": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
     "ofl_resize_flow": (_ci, [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _cd, _cf, _cf, _vp, _vp]),

@@ -32,7 +32,7 @@ class DeviceFlowBatch:
         px = shape[0] * shape[1]
         lib = nat.load()
         for i, f in enumerate(flows):
-            m = f.mask.astype(np.uint8)
+            m = np.ascontiguousarray(f.mask).view(np.uint8)
             nat.check(lib.ofl_upload(b.vecs.ptr + i * px * 8, f.vecs.ctypes.data, px * 8, None))
             nat.check(lib.ofl_upload(b.mask.ptr + i * px, m.ctypes.data, px, None))
             nat.check(lib.ofl_stream_sync(None))
@@ -41,7 +41,7 @@ class DeviceFlowBatch:
     def to_flows(self):
         h, w = self.shape
         v = self.vecs.to_host((self.n, h, w, 2), np.float32)
-        m = self.mask.to_host((self.n, h, w), np.uint8).astype(bool)
+        m = self.mask.to_host((self.n, h, w), np.uint8).view(np.bool_)
         return [Flow(v[i], self.ref, m[i]) for i in range(self.n)]
 
     def compose3(self, other, quant=nat.QUANT_OPENCV):

@@ -2,6 +2,7 @@
 // Pure streaming kernels: 16-byte loads per lane, grid-stride over at most 2048 workgroups.
 #include "ofl_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #pragma clang fp contract(off)
 
@@ -52,6 +53,66 @@ void flow_stats_kernel(const float *__restrict__ flow, const uint8_t *__restrict
     if (threadIdx.x == 0 && block_bits) {
         const uint32_t cur = __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((cur | block_bits) != cur) atomicOr(stats, block_bits);
+    }
+}
+
+// Extent of the sampling positions of the masked vectors (Flow.get_padding, flow_class.py:1214-1226):
+// thresholded vectors (|component| < th -> 0, utils.py:310-315), position = float32(grid + sign * v) exactly as
+// NumPy's in-place float32 -= int64 rounds it; min / max over the masked pixels through order-preserving
+// uint32 keys and one atomicMin / atomicMax per wave and quantity.  ext = { min y, max y, min x, max x }.
+__device__ __forceinline__ uint32_t order_key(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ float order_value(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ void flow_extent_init_kernel(uint32_t *ext)
+{
+    if (threadIdx.x < 4) ext[threadIdx.x] = (threadIdx.x & 1) ? 0u : 0xffffffffu;     // max slots / min slots
+}
+
+__global__ void flow_extent_finish_kernel(uint32_t *ext)
+{
+    if (threadIdx.x < 4) {
+        const uint32_t k = ext[threadIdx.x];
+        float v = order_value(k);
+        if (!(threadIdx.x & 1) && k == 0xffffffffu) v = __uint_as_float(0x7f800000u);      // nothing masked: +inf
+        if ((threadIdx.x & 1) && k == 0u) v = __uint_as_float(0xff800000u);                // nothing masked: -inf
+        reinterpret_cast<float *>(ext)[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void flow_extent_kernel(const float *__restrict__ flow, const uint8_t *__restrict__ mask, int H, int W, int sign,
+                        float th, uint32_t *__restrict__ ext)
+{
+    const size_t n = (size_t)H * W, stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t kmin_y = 0xffffffffu, kmax_y = 0u, kmin_x = 0xffffffffu, kmax_x = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (mask && !mask[i]) continue;
+        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        float2 f = reinterpret_cast<const float2 *>(flow)[i];
+        if (f.x < th && f.x > -th) f.x = 0.0f;
+        if (f.y < th && f.y > -th) f.y = 0.0f;
+        const uint32_t kx = order_key(map_coord(x, f.x, sign)), ky = order_key(map_coord(y, f.y, sign));
+        kmin_x = min(kmin_x, kx); kmax_x = max(kmax_x, kx);
+        kmin_y = min(kmin_y, ky); kmax_y = max(kmax_y, ky);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin_y = min(kmin_y, (uint32_t)__shfl_xor((int)kmin_y, off)); kmax_y = max(kmax_y, (uint32_t)__shfl_xor((int)kmax_y, off));
+        kmin_x = min(kmin_x, (uint32_t)__shfl_xor((int)kmin_x, off)); kmax_x = max(kmax_x, (uint32_t)__shfl_xor((int)kmax_x, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (kmin_y != 0xffffffffu) atomicMin(&ext[0], kmin_y);
+        if (kmax_y != 0u) atomicMax(&ext[1], kmax_y);
+        if (kmin_x != 0xffffffffu) atomicMin(&ext[2], kmin_x);
+        if (kmax_x != 0u) atomicMax(&ext[3], kmax_x);
     }
 }
 
@@ -240,6 +301,23 @@ int ofl_mask_and_dev(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n,
     if (!a || !b || !out) return fail(OFL_E_INVALID, "ofl_mask_and: NULL pointer");
     if (n == 0) return OFL_OK;
     hipLaunchKernelGGL(mask_and_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, stream_of(stream), a, b, out, n);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_flow_extent_dev(const float *vecs, const uint8_t *mask, int H, int W, int sign, float threshold,
+                        float *extent, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!vecs || !extent || H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_flow_extent: bad arguments");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_flow_extent: sign must be +1 or -1");
+    hipStream_t s = stream_of(stream);
+    uint32_t *ext = reinterpret_cast<uint32_t *>(extent);
+    hipLaunchKernelGGL(flow_extent_init_kernel, dim3(1), dim3(64), 0, s, ext);
+    const size_t n = (size_t)H * W;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);          // <= 4096 wave atomics per slot
+    hipLaunchKernelGGL(flow_extent_kernel, dim3(grid), dim3(256), 0, s, vecs, mask, H, W, sign, threshold, ext);
+    hipLaunchKernelGGL(flow_extent_finish_kernel, dim3(1), dim3(64), 0, s, ext);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

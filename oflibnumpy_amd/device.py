@@ -217,13 +217,17 @@ class DeviceFlow:
     def from_host(cls, vecs, ref='t', mask=None):
         vecs = np.ascontiguousarray(vecs, dtype=np.float32)
         h, w = vecs.shape[:2]
-        m = np.ones((h, w), np.uint8) if mask is None else np.ascontiguousarray(mask).astype(np.uint8)
+        if mask is None:
+            m = np.ones((h, w), np.uint8)
+        else:
+            m = np.ascontiguousarray(mask)
+            m = m.view(np.uint8) if m.dtype == np.bool_ else m.astype(np.uint8)
         return cls(DeviceBuffer.from_host(vecs), DeviceBuffer.from_host(m), (h, w), ref)
 
     def to_host(self):
         """-> (vecs float32 [H,W,2], mask bool [H,W])"""
         h, w = self.shape
-        return self.vecs.to_host((h, w, 2), np.float32), self.mask.to_host((h, w), np.uint8).astype(bool)
+        return self.vecs.to_host((h, w, 2), np.float32), self.mask.to_host((h, w), np.uint8).view(np.bool_)    # bytes are 0 / 1
 
     def relabel(self, ref):
         return DeviceFlow(self.vecs, self.mask, self.shape, ref, self._stats)
@@ -246,6 +250,18 @@ class DeviceFlow:
         else:
             bit = nat.STAT_NONZERO_TH if thresholded else nat.STAT_NONZERO
         return not (s & bit)
+
+    def get_padding(self):
+        """Flow.get_padding (flow_class.py:1197-1228): one min/max reduction over the masked sampling positions."""
+        h, w = self.shape
+        ext = DeviceBuffer(16)
+        nat.check(_lib().ofl_flow_extent_dev(self.vecs.ptr, self.mask.ptr, h, w, -1 if self.ref == 't' else 1,
+                                             np.float32(DEFAULT_THRESHOLD), ext.ptr, None))
+        min_y, max_y, min_x, max_x = (float(v) for v in ext.to_host((4,), np.float32))
+        if not np.isfinite(min_y):
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")   # NumPy's error in the reference
+        pads = [max(-min_y, 0), max(max_y - (h - 1), 0), max(-min_x, 0), max(max_x - (w - 1), 0)]
+        return [int(np.ceil(p)) for p in pads]
 
     # -- element-wise algebra (Flow.__add__/__sub__/__neg__, flow_class.py:310-375, 479-489)
     def _axpy(self, other, alpha):
@@ -557,7 +573,7 @@ def scatter_host(flow, target, pmask, vmask=None):
     if np.issubdtype(target.dtype, np.integer):
         res = np.round(res)
     res = res.astype(target.dtype)
-    v = valid.to_host((h, w), np.uint8).astype(bool) if valid is not None else None
+    v = valid.to_host((h, w), np.uint8).view(np.bool_) if valid is not None else None
     return res, v
 
 
@@ -582,4 +598,4 @@ def scatter_query(pos_flow_buf, sign, vals_buf, C, h, w, query_xy, pmask=None):
     ws = _workspace(h, w, C)
     nat.check(_lib().ofl_scatter_query_dev(pos_flow_buf.ptr, sign, 0, pmask.ptr if pmask is not None else None,
                                            vals_buf.ptr, C, h, w, dq.ptr, n, out.ptr, found.ptr, ws.ptr, ws.nbytes, None))
-    return out.to_host((n, C), np.float64), found.to_host((n,), np.uint8).astype(bool)
+    return out.to_host((n, C), np.float64), found.to_host((n,), np.uint8).view(np.bool_)

@@ -213,8 +213,13 @@ class Flow(object):
 
     @classmethod
     def from_device(cls, dflow: dev.DeviceFlow) -> FlowAlias:
+        """Download a device result.  The arrays come out of the kernels as float32 / 0-1 bytes computed from
+        already validated inputs, so the constructor's copy-and-validate passes (3 x the PCIe time at 4K) are
+        skipped."""
         vecs, mask = dflow.to_host()
-        return cls(vecs, dflow.ref, mask)
+        f = cls.__new__(cls)
+        f._vecs, f._mask, f._ref = vecs, mask, get_valid_ref(dflow.ref)
+        return f
 
     # ------------------------------------------------------------------ hot path
     def apply(self, target: Union[np.ndarray, FlowAlias], target_mask: np.ndarray = None,
@@ -309,8 +314,9 @@ class Flow(object):
                 rule = nat.RULE_GT_HALF
                 if t.dtype == np.uint8:
                     arith = nat.ARITH_FLOAT_RNE        # uint8 image inside an int16 concat
-        if is_zero_flow(self._vecs, thresholded=True):      # identity short cut, reference utils.py:215-216
-            warped = t
+        fbuf = dev.DeviceBuffer.from_host(self._vecs)
+        if not (dev.flow_stats(fbuf, None, self._vecs.shape[0] * self._vecs.shape[1]) & nat.STAT_NONZERO_TH):
+            warped = t                                      # identity short cut, reference utils.py:215-216
             valid = None
             if with_mask:
                 valid = np.zeros(t.shape[:2], bool)
@@ -318,13 +324,12 @@ class Flow(object):
                 valid &= tmask.astype(bool)
             return warped, valid
         src = dev.DeviceImage.from_host(t)
-        fbuf = dev.DeviceBuffer.from_host(self._vecs)
         smask = dev.DeviceBuffer.from_host(tmask.astype(np.uint8)) if (with_mask and not default_mask) else None
-        fmask = dev.DeviceBuffer.from_host(self._mask.astype(np.uint8)) if with_mask else None
+        fmask = dev.DeviceBuffer.from_host(self._mask.view(np.uint8)) if with_mask else None
         dst, valid = dev.gather_bilinear(src, fbuf, self.shape, -1, smask=smask, fmask=fmask,
                                          want_valid=with_mask, pad=pad_tl, arith=arith, rule=rule)
         warped = dst.to_host()
-        valid = valid.to_host(t.shape[:2], np.uint8).astype(bool) if with_mask else None
+        valid = valid.to_host(t.shape[:2], np.uint8).view(np.bool_) if with_mask else None
         return warped, valid
 
     def _apply_s(self, t, tmask, with_mask, consider_mask, padding):
@@ -345,9 +350,10 @@ class Flow(object):
             return Flow(self._vecs, 't' if self._ref == 's' else 's', self._mask)
         if mode != 'valid':
             raise ValueError("Error switching flow reference: Mode not recognised, should be 'valid' or 'invalid'")
-        if self.is_zero(thresholded=False):
+        d = self.to_device()
+        if d.is_zero(thresholded=False):
             return self.switch_ref(mode='invalid')
-        return Flow.from_device(self.to_device().switch_ref())
+        return Flow.from_device(d.switch_ref())
 
     def invert(self, ref: str = None) -> FlowAlias:
         """Inverse flow in the requested reference (reference flow_class.py:735-753)."""
@@ -375,7 +381,7 @@ class Flow(object):
         if not isinstance(consider_mask, bool):
             raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
         buf = self.to_device().valid_target(consider_mask)
-        return buf.to_host(self.shape, np.uint8).astype(bool)
+        return buf.to_host(self.shape, np.uint8).view(np.bool_)
 
     def valid_source(self, consider_mask: bool = None) -> np.ndarray:
         """Area of the source domain that ends up valid in the target (reference flow_class.py:1153-1195)."""
@@ -383,29 +389,22 @@ class Flow(object):
         if not isinstance(consider_mask, bool):
             raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
         buf = self.to_device().valid_source(consider_mask)
-        return buf.to_host(self.shape, np.uint8).astype(bool)
+        return buf.to_host(self.shape, np.uint8).view(np.bool_)
 
     def get_padding(self) -> list:
         """[top, bottom, left, right] padding needed so that no valid vector leaves the padded area
         (reference flow_class.py:1197-1228)."""
-        v = threshold_vectors(self._vecs)
-        if self._ref == 's':
-            v *= -1
-        rows, cols = np.mgrid[:self.shape[0], :self.shape[1]]
-        px = cols - v[..., 0]
-        py = rows - v[..., 1]
-        m = self._mask
-        pads = [max(-np.min(py[m]), 0), max(np.max(py[m]) - (self.shape[0] - 1), 0),
-                max(-np.min(px[m]), 0), max(np.max(px[m]) - (self.shape[1] - 1), 0)]
-        return [int(np.ceil(p)) for p in pads]
+        return self.to_device().get_padding()
 
     def is_zero(self, thresholded: bool = None, masked: bool = None) -> bool:
         """All (masked) vectors zero?  (reference flow_class.py:1230-1245)"""
         masked = True if masked is None else masked
         if not isinstance(masked, bool):
             raise TypeError("Error checking whether flow is zero: Masked needs to be a boolean")
-        f = self._vecs[self._mask][np.newaxis, ...] if masked else self._vecs
-        return is_zero_flow(f, thresholded)
+        thresholded = True if thresholded is None else thresholded
+        if not isinstance(thresholded, bool):
+            raise TypeError("Error checking whether flow is zero: Thresholded needs to be a boolean")
+        return self.to_device().is_zero(thresholded, masked)
 
     def combine_with(self, flow: FlowAlias, mode: int, thresholded: bool = None) -> FlowAlias:
         """flow_1 (+) flow_2 = flow_3: mode k returns flow_k from the other two (`self` comes first in

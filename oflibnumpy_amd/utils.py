@@ -217,10 +217,8 @@ def is_zero_flow(flow: nd, thresholded: bool = None) -> bool:
     thresholded = True if thresholded is None else thresholded
     if not isinstance(thresholded, bool):
         raise TypeError("Error checking whether flow is zero: Thresholded needs to be a boolean")
-    if thresholded:
-        th = np.float32(DEFAULT_THRESHOLD)
-        return bool(np.all((flow < th) & (flow > -th)))
-    return bool(np.all(flow == 0))
+    bits = dev.flow_stats(dev.DeviceBuffer.from_host(flow), None, flow.shape[0] * flow.shape[1])
+    return not (bits & (nat.STAT_NONZERO_TH if thresholded else nat.STAT_NONZERO))
 
 
 # --------------------------------------------------------------------------- THE seam: apply_flow
@@ -244,8 +242,6 @@ def apply_flow(flow: nd, target: nd, ref: str, mask: nd = None, quant: int = Non
     """
     ref = get_valid_ref(ref)
     flow = validate_flow_array(flow, "Error applying flow to a target: ")
-    if is_zero_flow(flow, thresholded=True):
-        return target
     if not isinstance(target, np.ndarray):
         raise TypeError("Error applying flow to a target: Target needs to be a numpy array")
     if target.ndim < 2 or target.ndim > 3:
@@ -260,13 +256,16 @@ def apply_flow(flow: nd, target: nd, ref: str, mask: nd = None, quant: int = Non
         if mask.dtype != bool:
             raise TypeError("Error applying flow to a target: Mask needs to be boolean")
     quant = nat.QUANT_OPENCV if quant is None else quant
-
+    if ref == 't' and target.dtype.type not in _REMAP_DTYPES:
+        raise TypeError("Error applying flow to a target: dtype {} is not supported by the bilinear "
+                        "remap (uint8, int16, uint16, float32, float64)".format(target.dtype))
+    # the reference tests for a zero flow before it looks at the target (utils.py:214-216); here the arguments are
+    # validated first because the zero test is a device reduction over the uploaded field
+    fbuf = dev.DeviceBuffer.from_host(flow)
+    if not (dev.flow_stats(fbuf, None, flow.shape[0] * flow.shape[1]) & nat.STAT_NONZERO_TH):
+        return target
     if ref == 't':
-        if target.dtype.type not in _REMAP_DTYPES:
-            raise TypeError("Error applying flow to a target: dtype {} is not supported by the bilinear "
-                            "remap (uint8, int16, uint16, float32, float64)".format(target.dtype))
         src = dev.DeviceImage.from_host(target)
-        fbuf = dev.DeviceBuffer.from_host(flow)
         arith, _ = _remap_rules(target.dtype)
         dst, _ = dev.gather_bilinear(src, fbuf, flow.shape[:2], -1, quant=quant, arith=arith)
         result = dst.to_host()

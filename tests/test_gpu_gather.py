@@ -612,3 +612,59 @@ def test_resize_matches_oracle(gpu, oracle):
     half = f4k.resize(0.5)
     assert half.shape == (1080, 1920)
     np.testing.assert_allclose(half.vecs[2:-2, 2:-2], of.Flow.from_transforms([['scaling', 500 - 0.25, 400 - 0.25, 0.9]], (1080, 1920), 't').vecs[2:-2, 2:-2], atol=2e-3)
+
+
+def test_is_zero_and_get_padding_on_device(gpu, oracle):
+    """Flow.is_zero / is_zero_flow (reference tests/test_flow_class.py:1007-1024, tests/test_utils.py:520-540) and
+    Flow.get_padding (tests/test_flow_class.py:982-1004 known answers) run as device reductions."""
+    of = gpu
+    shape = (10, 10)
+    mask = np.ones(shape, bool)
+    mask[0, 0] = False
+    v = np.zeros(shape + (2,))
+    v[0, 0] = 10
+    f = of.Flow(v, mask=mask)
+    assert f.is_zero() is True and f.is_zero(masked=True) is True and f.is_zero(masked=False) is False
+    assert f.is_zero(thresholded=False) is True
+    v = np.zeros(shape + (2,), np.float32)
+    v[1, 1] = [9e-4, -9e-4]
+    assert of.is_zero_flow(v) and of.is_zero_flow(v, True) and not of.is_zero_flow(v, False)
+    v[1, 1] = [1e-3, 0]
+    assert not of.is_zero_flow(v)
+    # zero flow: the target itself comes back (reference utils.py:215-216)
+    tgt = np.ones((10, 10), np.float32)
+    assert of.apply_flow(np.zeros((10, 10, 2)), tgt, 't') is tgt
+    assert of.apply_flow(np.full((10, 10, 2), 9e-4), tgt, 's') is tgt
+    w, vv = of.Flow.zero((10, 10)).apply(tgt, return_valid_area=True)
+    assert np.array_equal(w, tgt) and vv.all()
+    z = of.Flow.zero((20, 20), 's')
+    assert z.switch_ref().ref == 't' and not z.switch_ref().vecs.any()       # exact-zero short cut (flow_class.py:716-718)
+    f = of.Flow.from_transforms([['rotation', 0, 0, 45]], (7, 7), 's')
+    assert f.get_padding() == [5, 0, 0, 3]                       # reference test_get_padding
+    assert of.get_flow_padding(f.vecs, f.ref) == [5, 0, 0, 3]
+    ft = of.Flow.from_transforms([['rotation', 0, 0, 45]], (7, 7), 't')
+    assert ft.get_padding() == [0, 3, 5, 0]
+    m = np.ones((7, 7), bool)
+    m[:, 4:] = False
+    assert of.Flow.from_transforms([['rotation', 0, 0, 45]], (7, 7), 's', m).get_padding() == [3, 0, 0, 1]
+    with pytest.raises(ValueError):
+        of.Flow(ft.vecs, 't', np.zeros((7, 7), bool)).get_padding()
+    # restated reference arithmetic (float32 positions) on ragged shapes, both references, random masks
+    rng = np.random.default_rng(5)
+    for shape in ((37, 53), (128, 257), (1, 9), (600, 801)):
+        for ref in ('t', 's'):
+            vecs = (rng.standard_normal(shape + (2,)) * 7).astype(np.float32)
+            vecs[rng.random(shape) < 0.3] *= 1e-4                 # below the threshold
+            msk = rng.random(shape) > 0.4
+            fl = of.Flow(vecs, ref, msk)
+            t = vecs.copy()
+            t[(t < 1e-3) & (t > -1e-3)] = 0
+            if ref == 's':
+                t *= -1
+            yy, xx = np.mgrid[:shape[0], :shape[1]]
+            t[..., 0] -= xx
+            t[..., 1] -= yy
+            t *= -1
+            exp = [max(-np.min(t[msk, 1]), 0), max(np.max(t[msk, 1]) - (shape[0] - 1), 0),
+                   max(-np.min(t[msk, 0]), 0), max(np.max(t[msk, 0]) - (shape[1] - 1), 0)]
+            assert fl.get_padding() == [int(np.ceil(p)) for p in exp]

@@ -33,7 +33,8 @@ namespace {
 
 constexpr uint32_t kNoOwner   = 0xFFFFFFFFu;
 constexpr double   kEps       = 100.0 * 2.220446049250313e-16;   // scipy _qhull: eps = 100 * DBL_EPSILON
-constexpr int      kSmallArea = 1024;                             // bbox nodes a single thread scans itself
+constexpr int      kSmallArea = 1024;                             // bbox nodes scanned inside the raster kernel (lane or wave)
+constexpr int      kCoopMinArea = 64;                             // smallest bbox a whole wave scans together
 constexpr int      kBigCap    = 1 << 20;                          // capacity of the big-triangle list
 constexpr int      kCandCap   = 1 << 22;                          // hull candidates kept on the device
 constexpr int      kHullCap   = 1 << 16;                          // vertices per hull chain
@@ -173,6 +174,43 @@ __device__ __forceinline__ TriBox tri_box(const D2 &p0, const D2 &p1, const D2 &
     return b;
 }
 
+// value of `v` in lane `src` (wave-uniform index)
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Appends the points of the lanes that `want` to the hull-candidate list: ONE atomicAdd per wave (a counter
+// word bumped once per point serialises at ~12 ns per atomic).  Must be called by all lanes of the wave.
+__device__ __forceinline__ void push_candidate(const ScatterWs &ws, bool want, const D2 &p)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&ws.counters[3], (unsigned long long)__popcll(m));
+    const int lo = __builtin_amdgcn_readlane((int)(base & 0xffffffffull), leader), hi = __builtin_amdgcn_readlane((int)(base >> 32), leader);
+    base = ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+    if (want) {
+        const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (slot < (unsigned long long)ws.cand_cap) ws.cand[slot] = p;
+    }
+}
+
+// p strictly inside the (non-degenerate) triangle a b c, with a relative safety margin
+__device__ __forceinline__ bool strictly_inside(const D2 &a, const D2 &b, const D2 &c, const D2 &p)
+{
+    const double det = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
+    if (det == 0.0) return false;
+    double w1 = (p.x - a.x) * (c.y - a.y) - (p.y - a.y) * (c.x - a.x);
+    double w2 = (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x);
+    double w0 = det - w1 - w2;
+    if (det < 0) { w0 = -w0; w1 = -w1; w2 = -w2; }
+    const double margin = 1e-9 * fabs(det);
+    return w0 > margin && w1 > margin && w2 > margin;
+}
+
 __device__ __forceinline__ uint32_t tri_id(uint32_t cell, int diag, int t) { return (cell << 2) | ((uint32_t)diag << 1) | (uint32_t)t; }
 
 __global__ __launch_bounds__(256)
@@ -194,65 +232,118 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
     // Convex-hull candidates: kept points on the border of the kept mesh (image border, or a dropped
     // neighbour); corners of folded cells are added further down.  Every vertex of the convex hull of the
     // kept points is among them; interior points of a properly embedded mesh never are.
-    if (x < W && y < H && (!pmask || pmask[(size_t)y * W + x])) {
-        bool cand = (x == 0 || y == 0 || x == W - 1 || y == H - 1);
-        if (!cand && pmask) {
-            for (int dy = -1; dy <= 1 && !cand; ++dy)
-                for (int dx = -1; dx <= 1 && !cand; ++dx)
-                    cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
+    {
+        bool cand = false;
+        if (x < W && y < H && (!pmask || pmask[(size_t)y * W + x])) {
+            cand = (x == 0 || y == 0 || x == W - 1 || y == H - 1);
+            if (!cand && pmask) {
+                for (int dy = -1; dy <= 1 && !cand; ++dy)
+                    for (int dx = -1; dx <= 1 && !cand; ++dx)
+                        cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
+            }
         }
-        if (cand) {
-            const unsigned long long slot = atomicAdd(&ws.counters[3], 1ull);
-            if (slot < (unsigned long long)ws.cand_cap) ws.cand[slot] = point_of(flow, sign, W, x, y);
-        }
+        D2 p = { 0.0, 0.0 };
+        if (cand) p = point_of(flow, sign, W, x, y);
+        push_candidate(ws, cand, p);
     }
-    if (x >= cw || y >= ch) return;
+    // From here on every lane of the wave stays active (lanes without a cell just carry live = false): the
+    // cooperative scan below moves triangles between lanes.
+    bool live = x < cw && y < ch;
     const size_t i00 = (size_t)y * W + x;
-    bool k0 = true, k1 = true, k2 = true, k3 = true;
-    if (pmask) {
+    bool k0 = live, k1 = live, k2 = live, k3 = live;
+    if (live && pmask) {
         k0 = pmask[i00] != 0; k1 = pmask[i00 + 1] != 0;
         k2 = pmask[i00 + W + 1] != 0; k3 = pmask[i00 + W] != 0;
     }
     const int n_keep = (int)k0 + (int)k1 + (int)k2 + (int)k3;
-    if (n_keep < 3) return;
-    const D2 pa = point_of(flow, sign, W, x, y), pb = point_of(flow, sign, W, x + 1, y);
-    const D2 pc = point_of(flow, sign, W, x + 1, y + 1), pd = point_of(flow, sign, W, x, y + 1);
-    int diag;
-    if (n_keep == 4) diag = pick_diagonal(pa, pb, pc, pd);
-    else diag = (!k0 || !k2) ? 1 : 0;     // the only diagonal that leaves a fully kept triangle
-    // a cell that is not properly oriented (folded mesh) can push interior points onto the convex hull
-    // of the point set: its corners become hull candidates (duplicates are harmless)
-    if (!(cross2(pa, pb, pc) > 0 && cross2(pa, pc, pd) > 0 && cross2(pb, pc, pd) > 0 && cross2(pb, pd, pa) > 0)) {
+    live = live && n_keep >= 3;
+    D2 pa = { 0.0, 0.0 }, pb = pa, pc = pa, pd = pa;
+    int diag = 0;
+    bool folded = false;
+    if (live) {
+        pa = point_of(flow, sign, W, x, y);         pb = point_of(flow, sign, W, x + 1, y);
+        pc = point_of(flow, sign, W, x + 1, y + 1); pd = point_of(flow, sign, W, x, y + 1);
+        if (n_keep == 4) diag = pick_diagonal(pa, pb, pc, pd);
+        else diag = (!k0 || !k2) ? 1 : 0;     // the only diagonal that leaves a fully kept triangle
+        // a cell that is not properly oriented (folded mesh) can push interior points onto the convex hull
+        // of the point set: its corners become hull candidates (duplicates are harmless)
+        folded = !(cross2(pa, pb, pc) > 0 && cross2(pa, pc, pd) > 0 && cross2(pb, pc, pd) > 0 && cross2(pb, pd, pa) > 0);
+    }
+    if (__any(folded)) {
+        // A point strictly inside a triangle of kept points is not a hull vertex: corners of folded cells
+        // inside the two triangles spanned by the four warped image corners (when all four are kept) are
+        // dropped here -- motion boundaries fold thousands of cells far away from the hull.
+        const bool guard = !pmask || (pmask[0] && pmask[W - 1] && pmask[(size_t)(H - 1) * W] && pmask[(size_t)H * W - 1]);
+        D2 ga = { 0.0, 0.0 }, gb = ga, gc = ga, gd = ga;
+        if (guard) {
+            ga = point_of(flow, sign, W, 0, 0);         gb = point_of(flow, sign, W, W - 1, 0);
+            gc = point_of(flow, sign, W, W - 1, H - 1); gd = point_of(flow, sign, W, 0, H - 1);
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (pick4(k, k0, k1, k2, k3)) {
-                const unsigned long long slot = atomicAdd(&ws.counters[3], 1ull);
-                if (slot < (unsigned long long)ws.cand_cap) ws.cand[slot] = pick4(k, pa, pb, pc, pd);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const D2 p = pick4(k, pa, pb, pc, pd);
+            bool want = folded && pick4(k, k0, k1, k2, k3);
+            if (want && guard && (strictly_inside(ga, gb, gc, p) || strictly_inside(ga, gc, gd, p))) want = false;
+            push_candidate(ws, want, p);
+        }
     }
     const uint32_t cell = (uint32_t)(y * cw + x);
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         int i0, i1, i2;
         tri_corners(diag, t, i0, i1, i2);
-        if (!(pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3))) continue;
+        bool ok = live && pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3);
         const D2 q0 = pick4(i0, pa, pb, pc, pd), q1 = pick4(i1, pa, pb, pc, pd), q2 = pick4(i2, pa, pb, pc, pd);
-        const TriBox b = tri_box(q0, q1, q2, W, H);
-        if (b.x1 < b.x0 || b.y1 < b.y0) continue;
+        TriBox b = { 0, -1, 0, -1 };
+        if (ok) b = tri_box(q0, q1, q2, W, H);
+        ok = ok && b.x1 >= b.x0 && b.y1 >= b.y0;
         const uint32_t id = tri_id(cell, diag, t);
-        const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
+        const long long area = ok ? (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) : 0;
         if (area > kSmallArea) {
             const unsigned long long slot = atomicAdd(&ws.counters[1], 1ull);
             atomicAdd(&ws.counters[2], (unsigned long long)area);
             if (slot < (unsigned long long)kBigCap) ws.big[slot] = id;
-            continue;
+            ok = false;
         }
-        TriEdge te;
-        if (!tri_setup(q0, q1, q2, te)) continue;
-        for (int gy = b.y0; gy <= b.y1; ++gy)
-            for (int gx = b.x0; gx <= b.x1; ++gx)
-                if (tri_inside(te, (double)gx, (double)gy))
-                    atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+        TriEdge te = {};
+        if (ok) ok = tri_setup(q0, q1, q2, te);
+        // Load balance inside the wave: a lane whose bounding box is much larger than the wave's average
+        // (motion boundaries, seams of tiled fields) would keep 63 lanes waiting, so such triangles are
+        // broadcast and scanned by all 64 lanes together; the others are scanned by their own lane.
+        const int a = ok ? (int)area : 0;
+        int wave_sum = a;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wave_sum += __shfl_xor(wave_sum, off);
+#ifndef OFL_SC_COOP
+#define OFL_SC_COOP 1
+#endif
+        const bool coop = OFL_SC_COOP && a > kCoopMinArea && a * 16 > wave_sum;           // > 4 x the wave mean
+        if (ok && !coop) {
+            for (int gy = b.y0; gy <= b.y1; ++gy)
+                for (int gx = b.x0; gx <= b.x1; ++gx)
+                    if (tri_inside(te, (double)gx, (double)gy))
+                        atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+        }
+        unsigned long long todo = __ballot(coop);
+        while (todo) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            TriEdge tb;
+            tb.p0.x = lane_bcast(te.p0.x, src); tb.p0.y = lane_bcast(te.p0.y, src);
+            tb.e1x = lane_bcast(te.e1x, src);   tb.e1y = lane_bcast(te.e1y, src);
+            tb.e2x = lane_bcast(te.e2x, src);   tb.e2y = lane_bcast(te.e2y, src);
+            tb.det = lane_bcast(te.det, src);   tb.tol = lane_bcast(te.tol, src);
+            const int bx0 = __builtin_amdgcn_readlane(b.x0, src), bx1 = __builtin_amdgcn_readlane(b.x1, src);
+            const int by0 = __builtin_amdgcn_readlane(b.y0, src), by1 = __builtin_amdgcn_readlane(b.y1, src);
+            const uint32_t bid = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
+            const int bw = bx1 - bx0 + 1, n = bw * (by1 - by0 + 1);
+            for (int k = lane; k < n; k += 64) {
+                const int ry = k / bw, gx = bx0 + (k - ry * bw), gy = by0 + ry;
+                if (tri_inside(tb, (double)gx, (double)gy))
+                    atomicMin(&ws.owner[(size_t)gy * W + gx], bid);
+            }
+        }
     }
 }
 
@@ -520,15 +611,25 @@ ScatterWs carve(void *workspace, int H, int W)
 // containing the two extreme-x end points.
 void convex_chains(std::vector<D2> &pts, std::vector<D2> &lower, std::vector<D2> &upper)
 {
-    // sort by (x, y): counting sort into ~n/4 x-buckets, then tiny std::sorts -- the candidates are a few
-    // thousand points spread evenly along the mesh border, a comparison sort of all of them costs ~0.5 ms
+    // Order by (x, y) without a comparison sort of everything: counting sort into ~n/4 x-buckets, then tiny
+    // sorts.  The candidates are the warped image border: two rows spread evenly over the buckets and two
+    // columns that can share ONE abscissa (scalings, translations) -- of a bucket whose points all have the
+    // same x only the lowest and the highest can be hull vertices, so it is reduced, not sorted.  Points
+    // above the chord from the leftmost to the rightmost point are fed to the upper chain only, points below
+    // it to the lower chain only (they cannot be vertices of the other one).
+    static thread_local std::vector<uint32_t> start, key, pos;
+    static thread_local std::vector<D2> sorted;
     const size_t n = pts.size();
-    double xmin = pts[0].x, xmax = pts[0].x;
-    for (const D2 &p : pts) { xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x); }
+    D2 L = pts[0], R = pts[0];
+    for (const D2 &p : pts) {
+        if (p.x < L.x || (p.x == L.x && p.y < L.y)) L = p;
+        if (p.x > R.x || (p.x == R.x && p.y > R.y)) R = p;
+    }
+    const double xmin = L.x, xmax = R.x;
     const size_t nb = std::max<size_t>(1, n / 4);
     const double scale = xmax > xmin ? (double)(nb - 1) / (xmax - xmin) : 0.0;
-    std::vector<uint32_t> start(nb + 1, 0);
-    std::vector<uint32_t> key(n);
+    start.assign(nb + 1, 0);
+    key.resize(n);
     for (size_t i = 0; i < n; ++i) {
         size_t b = (size_t)((pts[i].x - xmin) * scale);
         if (b >= nb) b = nb - 1;
@@ -536,21 +637,46 @@ void convex_chains(std::vector<D2> &pts, std::vector<D2> &lower, std::vector<D2>
         ++start[b + 1];
     }
     for (size_t b = 0; b < nb; ++b) start[b + 1] += start[b];
-    std::vector<D2> sorted(n);
-    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-    for (size_t i = 0; i < n; ++i) sorted[fill[key[i]]++] = pts[i];
+    sorted.resize(n);
+    pos.assign(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < n; ++i) sorted[pos[key[i]]++] = pts[i];
     auto less = [](const D2 &a, const D2 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); };
-    for (size_t b = 0; b < nb; ++b)
-        if (start[b + 1] - start[b] > 1) std::sort(sorted.begin() + start[b], sorted.begin() + start[b + 1], less);
     auto cross = [](const D2 &o, const D2 &a, const D2 &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
     lower.clear(); upper.clear();
-    for (const D2 &p : sorted) {       // smallest y at every x
-        while (lower.size() >= 2 && cross(lower[lower.size() - 2], lower.back(), p) <= 0) lower.pop_back();
-        lower.push_back(p);
-    }
-    for (const D2 &p : sorted) {       // largest y at every x
-        while (upper.size() >= 2 && cross(upper[upper.size() - 2], upper.back(), p) >= 0) upper.pop_back();
-        upper.push_back(p);
+    auto feed = [&](const D2 &p) {
+        const double side = cross(L, R, p);          // > 0: above the chord 
+        if (side <= 0) {
+            while (lower.size() >= 2 && cross(lower[lower.size() - 2], lower.back(), p) <= 0) lower.pop_back();
+            lower.push_back(p);
+        }
+        if (side >= 0) {
+            while (upper.size() >= 2 && cross(upper[upper.size() - 2], upper.back(), p) >= 0) upper.pop_back();
+            upper.push_back(p);
+        }
+    };
+    for (size_t b = 0; b < nb; ++b) {
+        const size_t s = start[b], e = start[b + 1];
+        if (e - s > 8) {
+            double bx0 = sorted[s].x, bx1 = bx0, y0 = sorted[s].y, y1 = y0;
+            for (size_t i = s + 1; i < e; ++i) {
+                bx0 = std::min(bx0, sorted[i].x); bx1 = std::max(bx1, sorted[i].x);
+                y0 = std::min(y0, sorted[i].y);   y1 = std::max(y1, sorted[i].y);
+            }
+            if (bx0 == bx1) {                      // one abscissa: lowest first, highest second
+                feed(D2{ bx0, y0 });
+                if (y1 > y0) feed(D2{ bx0, y1 });
+                continue;
+            }
+            std::sort(sorted.begin() + s, sorted.begin() + e, less);
+        } else {
+            for (size_t i = s + 1; i < e; ++i) {   // insertion sort of a handful of points
+                const D2 v = sorted[i];
+                size_t j = i;
+                while (j > s && less(v, sorted[j - 1])) { sorted[j] = sorted[j - 1]; --j; }
+                sorted[j] = v;
+            }
+        }
+        for (size_t i = s; i < e; ++i) feed(sorted[i]);
     }
 }
 

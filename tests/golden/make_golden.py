@@ -161,6 +161,21 @@ def main():
     out["track/status_t/warped"] = warped
     out["track/status_t/status"] = status
 
+    # discontinuous fields (motion boundaries): a block moving over a static background, 's' reference -- appended
+    # after everything else for the same reason
+    dshape = (40, 56)
+    for name, (du, dv) in (("block_int", (3.0, -2.0)), ("block_frac", (4.3, 2.6))):
+        v = np.zeros(dshape + (2,), np.float32)
+        v[12:28, 16:40] = [du, dv]
+        f = Flow(v, 's')
+        dimg = np.random.default_rng(11).random(dshape + (3,), dtype=np.float32)
+        out["disc/" + name + "/img"] = dimg
+        w, va = f.apply(dimg, return_valid_area=True)
+        put("disc_apply/" + name, f, w)
+        out["disc_apply/" + name + "/out_valid"] = va
+        put("disc_invert/" + name, f, f.invert())
+        put("disc_valid_target/" + name, f, f.valid_target())
+
     path = os.path.join(HERE, "ref_scipy_paths.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -25,6 +25,11 @@ def _run_case(O, g, tag):
         return f.apply(g['img_u8'])
     if op.startswith('combine2'):
         return f.combine_with(O.OFlow(g[tag + '/in2_vecs'], f.ref, g[tag + '/in2_mask']), 2)
+    if op.startswith('disc_'):
+        name = tag.split('/')[1]
+        if op == 'disc_apply':
+            return f.apply(g['disc/' + name + '/img'], return_valid_area=True)
+        return f.invert() if op == 'disc_invert' else f.valid_target()
     if op == 'k7':
         n = tag.split('/')[1]
         fn = f.valid_target if n.startswith('valid_target') else f.valid_source
@@ -33,13 +38,18 @@ def _run_case(O, g, tag):
 
 
 def golden_tags(g):
-    return sorted({k.rsplit('/', 1)[0] for k in g.files if '/' in k and not k.startswith('track/')})
+    return sorted({k.rsplit('/', 1)[0] for k in g.files if '/' in k and not k.startswith(('track/', 'disc'))})
+
+
+def disc_tags(g):
+    """Discontinuous fields (a block moving over a static background): disc_apply/..., disc_invert/..., disc_valid_target/..."""
+    return sorted({k.rsplit('/', 1)[0] for k in g.files if k.startswith('disc_')})
 
 
 def test_oracle_matches_reference_outputs(oracle, golden):
     """Every captured reference output is reproduced bit for bit by the restated algebra."""
-    tags = golden_tags(golden)
-    assert len(tags) >= 80
+    tags = golden_tags(golden) + disc_tags(golden)
+    assert len(tags) >= 86
     for tag in tags:
         r = _run_case(oracle, golden, tag)
         if isinstance(r, oracle.OFlow):

@@ -76,6 +76,20 @@ def main():
     t = timed(lambda: d2.switch_ref(), it)
     report("switch_ref s->t (K3)", (h, w), 18, *t)
 
+    # K3 on discontinuous fields (motion boundaries fold and stretch cells): a rigid object moving 30 px over a
+    # static background, and 64-px stripes of alternating 20-px motion
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    obj = np.zeros((h, w, 2), np.float32)
+    obj[600:1500, 1000:2600] = [30.0, -12.0]
+    stripes = np.zeros((h, w, 2), np.float32)
+    stripes[..., 0] = (np.floor(xx / 64) % 2) * 20.0
+    for name, v in (("rigid object +30 px", obj), ("64-px stripes of 20-px motion", stripes)):
+        dd = dev.DeviceFlow.from_host(v, 's')
+        dd.stats()
+        t = timed(lambda: dd.invert(), it)
+        report("invert s->s, {} (K3)".format(name), (h, w), 18, *t, note="discontinuous field")
+    del yy, xx, obj, stripes
+
     # K4: Flow.resize of the 4K field: 9 B per source px read + 9 B per output px written
     for scale in (0.5, 2, 1.5):
         ho, wo = dev.resized_shape(h, w, scale, scale)

@@ -34,6 +34,9 @@ namespace {
 constexpr uint32_t kNoOwner   = 0xFFFFFFFFu;
 constexpr double   kEps       = 100.0 * 2.220446049250313e-16;   // scipy _qhull: eps = 100 * DBL_EPSILON
 constexpr int      kSmallArea = 1024;                             // bbox nodes scanned inside the raster kernel (lane or wave)
+#ifndef OFL_SC_COOP
+#define OFL_SC_COOP 1
+#endif
 constexpr int      kCoopMinArea = 64;                             // smallest bbox a whole wave scans together
 constexpr int      kBigCap    = 1 << 20;                          // capacity of the big-triangle list
 constexpr int      kCandCap   = 1 << 22;                          // hull candidates kept on the device
@@ -211,7 +214,93 @@ __device__ __forceinline__ bool strictly_inside(const D2 &a, const D2 &b, const 
     return w0 > margin && w1 > margin && w2 > margin;
 }
 
+// p inside or on the boundary of the (non-degenerate) triangle a b c without being one of its vertices
+__device__ __forceinline__ bool inside_or_on(const D2 &a, const D2 &b, const D2 &c, const D2 &p)
+{
+    if ((p.x == a.x && p.y == a.y) || (p.x == b.x && p.y == b.y) || (p.x == c.x && p.y == c.y)) return false;
+    const double det = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
+    if (det == 0.0) return false;
+    double w1 = (p.x - a.x) * (c.y - a.y) - (p.y - a.y) * (c.x - a.x);
+    double w2 = (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x);
+    double w0 = det - w1 - w2;
+    if (det < 0) { w0 = -w0; w1 = -w1; w2 = -w2; }
+    return w0 >= 0.0 && w1 >= 0.0 && w2 >= 0.0;
+}
+
 __device__ __forceinline__ uint32_t tri_id(uint32_t cell, int diag, int t) { return (cell << 2) | ((uint32_t)diag << 1) | (uint32_t)t; }
+
+// decode a triangle id into its three source vertices (linear pixel indices) and positions
+__device__ __forceinline__ void tri_decode(uint32_t id, const float *flow, int sign, int W,
+                                           size_t (&vi)[3], D2 (&vp)[3])
+{
+    const int cw = W - 1;
+    const uint32_t cell = id >> 2;
+    const int diag = (id >> 1) & 1, t = id & 1;
+    const int y = (int)(cell / (uint32_t)cw), x = (int)(cell - (uint32_t)y * (uint32_t)cw);
+    int i0, i1, i2;
+    tri_corners(diag, t, i0, i1, i2);
+    const int ci[3] = { i0, i1, i2 };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int px = x + (((ci[k] + 1) >> 1) & 1), py = y + (ci[k] >> 1);     // corner a,b,c,d -> (0,0),(1,0),(1,1),(0,1)
+        vi[k] = (size_t)py * W + px;
+        vp[k] = point_of(flow, sign, W, px, py);
+    }
+}
+
+// Convex-hull candidates among the kept points: the points on the border of the kept mesh (image border, or
+// next to a dropped point); corners of folded cells are added by the raster pass further down.  Every vertex of the
+// convex hull of the kept points is among them.  Must be called by all lanes of the wave.
+__device__ __forceinline__ void hull_candidate(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
+                                               int H, int W, int x, int y, const ScatterWs &ws)
+{
+    {
+        bool cand = false, on_border = false;
+        if (x < W && y < H && (!pmask || pmask[(size_t)y * W + x])) {
+            cand = on_border = (x == 0 || y == 0 || x == W - 1 || y == H - 1);
+            if (!cand && pmask) {
+                for (int dy = -1; dy <= 1 && !cand; ++dy)
+                    for (int dx = -1; dx <= 1 && !cand; ++dx)
+                        cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
+            }
+        }
+        D2 p = { 0.0, 0.0 };
+        if (cand) {
+            // A point inside or on the boundary of a triangle of OTHER kept points is not an extreme point of
+            // the set, so it cannot be a hull vertex.  Image-border points are tested against the triangles
+            // (P[j-d], P[j+d], inward neighbour) along their border for d = 1, 2, 4, 8, 16: straight or inward-
+            // bulging borders (every smooth warp) shed all but a few points here instead of on the host.
+            // Border points of mask holes are tested against the two triangles of the warped image corners.
+            p = point_of(flow, sign, W, x, y);
+            const bool corner = (x == 0 || x == W - 1) && (y == 0 || y == H - 1);
+            auto kept = [&](int xx, int yy) { return !pmask || pmask[(size_t)yy * W + xx] != 0; };
+#ifndef OFL_SC_FILTER
+#define OFL_SC_FILTER 1
+#endif
+            if (OFL_SC_FILTER && on_border && !corner && W > 2 && H > 2) {
+                const bool horiz = (y == 0 || y == H - 1);           // border runs along x
+                const int qx = horiz ? x : (x == 0 ? 1 : W - 2), qy = horiz ? (y == 0 ? 1 : H - 2) : y;
+                if (kept(qx, qy)) {
+                    const D2 q = point_of(flow, sign, W, qx, qy);
+                    const int pos = horiz ? x : y, len = horiz ? W : H;
+                    for (int d = 1; d <= 16 && cand; d <<= 1) {
+                        if (pos - d < 0 || pos + d >= len) break;
+                        const int ax = horiz ? x - d : x, ay = horiz ? y : y - d, bx = horiz ? x + d : x, by = horiz ? y : y + d;
+                        if (!kept(ax, ay) || !kept(bx, by)) continue;
+                        if (inside_or_on(point_of(flow, sign, W, ax, ay), point_of(flow, sign, W, bx, by), q, p)) cand = false;
+                    }
+                }
+            } else if (!on_border) {
+                if (kept(0, 0) && kept(W - 1, 0) && kept(0, H - 1) && kept(W - 1, H - 1)) {
+                    const D2 ga = point_of(flow, sign, W, 0, 0), gb = point_of(flow, sign, W, W - 1, 0);
+                    const D2 gc = point_of(flow, sign, W, W - 1, H - 1), gd = point_of(flow, sign, W, 0, H - 1);
+                    if (strictly_inside(ga, gb, gc, p) || strictly_inside(ga, gc, gd, p)) cand = false;
+                }
+            }
+        }
+        push_candidate(ws, cand, p);
+    }
+}
 
 __global__ __launch_bounds__(256)
 void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
@@ -229,50 +318,27 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
         if (threadIdx.x == 0 && block_sum)
             atomicAdd(&ws.kept_slots[(blockIdx.y * gridDim.x + blockIdx.x) & 255], (unsigned long long)block_sum);
     }
-    // Convex-hull candidates: kept points on the border of the kept mesh (image border, or a dropped
-    // neighbour); corners of folded cells are added further down.  Every vertex of the convex hull of the
-    // kept points is among them; interior points of a properly embedded mesh never are.
-    {
-        bool cand = false;
-        if (x < W && y < H && (!pmask || pmask[(size_t)y * W + x])) {
-            cand = (x == 0 || y == 0 || x == W - 1 || y == H - 1);
-            if (!cand && pmask) {
-                for (int dy = -1; dy <= 1 && !cand; ++dy)
-                    for (int dx = -1; dx <= 1 && !cand; ++dx)
-                        cand = !pmask[(size_t)(y + dy) * W + (x + dx)];
-            }
-        }
-        D2 p = { 0.0, 0.0 };
-        if (cand) p = point_of(flow, sign, W, x, y);
-        push_candidate(ws, cand, p);
-    }
-    // From here on every lane of the wave stays active (lanes without a cell just carry live = false): the
-    // cooperative scan below moves triangles between lanes.
-    bool live = x < cw && y < ch;
+    hull_candidate(flow, sign, pmask, H, W, x, y, ws);
+    if (x >= cw || y >= ch) return;
     const size_t i00 = (size_t)y * W + x;
-    bool k0 = live, k1 = live, k2 = live, k3 = live;
-    if (live && pmask) {
+    bool k0 = true, k1 = true, k2 = true, k3 = true;
+    if (pmask) {
         k0 = pmask[i00] != 0; k1 = pmask[i00 + 1] != 0;
         k2 = pmask[i00 + W + 1] != 0; k3 = pmask[i00 + W] != 0;
     }
     const int n_keep = (int)k0 + (int)k1 + (int)k2 + (int)k3;
-    live = live && n_keep >= 3;
-    D2 pa = { 0.0, 0.0 }, pb = pa, pc = pa, pd = pa;
-    int diag = 0;
-    bool folded = false;
-    if (live) {
-        pa = point_of(flow, sign, W, x, y);         pb = point_of(flow, sign, W, x + 1, y);
-        pc = point_of(flow, sign, W, x + 1, y + 1); pd = point_of(flow, sign, W, x, y + 1);
-        if (n_keep == 4) diag = pick_diagonal(pa, pb, pc, pd);
-        else diag = (!k0 || !k2) ? 1 : 0;     // the only diagonal that leaves a fully kept triangle
-        // a cell that is not properly oriented (folded mesh) can push interior points onto the convex hull
-        // of the point set: its corners become hull candidates (duplicates are harmless)
-        folded = !(cross2(pa, pb, pc) > 0 && cross2(pa, pc, pd) > 0 && cross2(pb, pc, pd) > 0 && cross2(pb, pd, pa) > 0);
-    }
-    if (__any(folded)) {
-        // A point strictly inside a triangle of kept points is not a hull vertex: corners of folded cells
-        // inside the two triangles spanned by the four warped image corners (when all four are kept) are
-        // dropped here -- motion boundaries fold thousands of cells far away from the hull.
+    if (n_keep < 3) return;
+    const D2 pa = point_of(flow, sign, W, x, y), pb = point_of(flow, sign, W, x + 1, y);
+    const D2 pc = point_of(flow, sign, W, x + 1, y + 1), pd = point_of(flow, sign, W, x, y + 1);
+    int diag;
+    if (n_keep == 4) diag = pick_diagonal(pa, pb, pc, pd);
+    else diag = (!k0 || !k2) ? 1 : 0;     // the only diagonal that leaves a fully kept triangle
+    // a cell that is not properly oriented (folded mesh) can push interior points onto the convex hull
+    // of the point set: its corners become hull candidates (duplicates are harmless)
+    // (a point strictly inside a triangle of kept points is never a hull vertex: corners inside the two
+    // triangles of the four warped image corners are dropped -- motion boundaries fold thousands of cells
+    // far away from the hull)
+    if (!(cross2(pa, pb, pc) > 0 && cross2(pa, pc, pd) > 0 && cross2(pb, pc, pd) > 0 && cross2(pb, pd, pa) > 0)) {
         const bool guard = !pmask || (pmask[0] && pmask[W - 1] && pmask[(size_t)(H - 1) * W] && pmask[(size_t)H * W - 1]);
         D2 ga = { 0.0, 0.0 }, gb = ga, gc = ga, gd = ga;
         if (guard) {
@@ -282,64 +348,61 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const D2 p = pick4(k, pa, pb, pc, pd);
-            bool want = folded && pick4(k, k0, k1, k2, k3);
+            bool want = pick4(k, k0, k1, k2, k3);
             if (want && guard && (strictly_inside(ga, gb, gc, p) || strictly_inside(ga, gc, gd, p))) want = false;
-            push_candidate(ws, want, p);
+            push_candidate(ws, want, p);            // one atomic per wave: ballots count the lanes that are here
         }
     }
     const uint32_t cell = (uint32_t)(y * cw + x);
-    const int lane = threadIdx.x & 63;
+    unsigned coop_bits = 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         int i0, i1, i2;
         tri_corners(diag, t, i0, i1, i2);
-        bool ok = live && pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3);
+        if (!(pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3))) continue;
         const D2 q0 = pick4(i0, pa, pb, pc, pd), q1 = pick4(i1, pa, pb, pc, pd), q2 = pick4(i2, pa, pb, pc, pd);
-        TriBox b = { 0, -1, 0, -1 };
-        if (ok) b = tri_box(q0, q1, q2, W, H);
-        ok = ok && b.x1 >= b.x0 && b.y1 >= b.y0;
+        const TriBox b = tri_box(q0, q1, q2, W, H);
+        if (b.x1 < b.x0 || b.y1 < b.y0) continue;
         const uint32_t id = tri_id(cell, diag, t);
-        const long long area = ok ? (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) : 0;
+        const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
         if (area > kSmallArea) {
             const unsigned long long slot = atomicAdd(&ws.counters[1], 1ull);
             atomicAdd(&ws.counters[2], (unsigned long long)area);
             if (slot < (unsigned long long)kBigCap) ws.big[slot] = id;
-            ok = false;
+            continue;
         }
-        TriEdge te = {};
-        if (ok) ok = tri_setup(q0, q1, q2, te);
-        // Load balance inside the wave: a lane whose bounding box is much larger than the wave's average
-        // (motion boundaries, seams of tiled fields) would keep 63 lanes waiting, so such triangles are
-        // broadcast and scanned by all 64 lanes together; the others are scanned by their own lane.
-        const int a = ok ? (int)area : 0;
-        int wave_sum = a;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wave_sum += __shfl_xor(wave_sum, off);
-#ifndef OFL_SC_COOP
-#define OFL_SC_COOP 1
-#endif
-        const bool coop = OFL_SC_COOP && a > kCoopMinArea && a * 16 > wave_sum;           // > 4 x the wave mean
-        if (ok && !coop) {
-            for (int gy = b.y0; gy <= b.y1; ++gy)
-                for (int gx = b.x0; gx <= b.x1; ++gx)
-                    if (tri_inside(te, (double)gx, (double)gy))
-                        atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+        // Load balance inside the wave: a lane whose bounding box is much larger than its neighbours' (motion
+        // boundaries, seams of tiled fields) would keep the other lanes waiting.  When few lanes of the wave
+        // hold such a triangle it is only FLAGGED here and scanned by the whole wave afterwards.
+        if (OFL_SC_COOP && area > kCoopMinArea && __popcll(__ballot(area > kCoopMinArea)) <= 16) {
+            coop_bits |= 1u << t;
+            continue;
         }
-        unsigned long long todo = __ballot(coop);
+        TriEdge te;
+        if (!tri_setup(q0, q1, q2, te)) continue;
+        for (int gy = b.y0; gy <= b.y1; ++gy)
+            for (int gx = b.x0; gx <= b.x1; ++gx)
+                if (tri_inside(te, (double)gx, (double)gy))
+                    atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+    }
+    if (!OFL_SC_COOP || !__any(coop_bits != 0)) return;
+    const int lane = threadIdx.x & 63;
+    for (int t = 0; t < 2; ++t) {
+        unsigned long long todo = __ballot((coop_bits >> t) & 1u);
         while (todo) {
             const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
             todo &= todo - 1;
+            // every lane rebuilds the shared triangle from its id (three cached loads)
+            const uint32_t bid = tri_id((uint32_t)__builtin_amdgcn_readlane((int)cell, src), __builtin_amdgcn_readlane(diag, src), t);
+            size_t vi[3];
+            D2 vp[3];
+            tri_decode(bid, flow, sign, W, vi, vp);
+            const TriBox bb = tri_box(vp[0], vp[1], vp[2], W, H);
             TriEdge tb;
-            tb.p0.x = lane_bcast(te.p0.x, src); tb.p0.y = lane_bcast(te.p0.y, src);
-            tb.e1x = lane_bcast(te.e1x, src);   tb.e1y = lane_bcast(te.e1y, src);
-            tb.e2x = lane_bcast(te.e2x, src);   tb.e2y = lane_bcast(te.e2y, src);
-            tb.det = lane_bcast(te.det, src);   tb.tol = lane_bcast(te.tol, src);
-            const int bx0 = __builtin_amdgcn_readlane(b.x0, src), bx1 = __builtin_amdgcn_readlane(b.x1, src);
-            const int by0 = __builtin_amdgcn_readlane(b.y0, src), by1 = __builtin_amdgcn_readlane(b.y1, src);
-            const uint32_t bid = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
-            const int bw = bx1 - bx0 + 1, n = bw * (by1 - by0 + 1);
+            if (!tri_setup(vp[0], vp[1], vp[2], tb)) continue;
+            const int bw = bb.x1 - bb.x0 + 1, n = bw * (bb.y1 - bb.y0 + 1);
             for (int k = lane; k < n; k += 64) {
-                const int ry = k / bw, gx = bx0 + (k - ry * bw), gy = by0 + ry;
+                const int ry = k / bw, gx = bb.x0 + (k - ry * bw), gy = bb.y0 + ry;
                 if (tri_inside(tb, (double)gx, (double)gy))
                     atomicMin(&ws.owner[(size_t)gy * W + gx], bid);
             }
@@ -397,25 +460,6 @@ __device__ __forceinline__ uint32_t nearest_owner(const uint32_t *owner, int H, 
         if (best != kNoOwner) return best;
     }
     return kNoOwner;
-}
-
-// decode a triangle id into its three source vertices (linear pixel indices) and positions
-__device__ __forceinline__ void tri_decode(uint32_t id, const float *flow, int sign, int W,
-                                           size_t (&vi)[3], D2 (&vp)[3])
-{
-    const int cw = W - 1;
-    const uint32_t cell = id >> 2;
-    const int diag = (id >> 1) & 1, t = id & 1;
-    const int y = (int)(cell / (uint32_t)cw), x = (int)(cell - (uint32_t)y * (uint32_t)cw);
-    int i0, i1, i2;
-    tri_corners(diag, t, i0, i1, i2);
-    const int ci[3] = { i0, i1, i2 };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int px = x + (((ci[k] + 1) >> 1) & 1), py = y + (ci[k] >> 1);     // corner a,b,c,d -> (0,0),(1,0),(1,1),(0,1)
-        vi[k] = (size_t)py * W + px;
-        vp[k] = point_of(flow, sign, W, px, py);
-    }
 }
 
 // pass 1b: one wave per large triangle, 64 nodes of the bounding box per step
@@ -611,25 +655,15 @@ ScatterWs carve(void *workspace, int H, int W)
 // containing the two extreme-x end points.
 void convex_chains(std::vector<D2> &pts, std::vector<D2> &lower, std::vector<D2> &upper)
 {
-    // Order by (x, y) without a comparison sort of everything: counting sort into ~n/4 x-buckets, then tiny
-    // sorts.  The candidates are the warped image border: two rows spread evenly over the buckets and two
-    // columns that can share ONE abscissa (scalings, translations) -- of a bucket whose points all have the
-    // same x only the lowest and the highest can be hull vertices, so it is reduced, not sorted.  Points
-    // above the chord from the leftmost to the rightmost point are fed to the upper chain only, points below
-    // it to the lower chain only (they cannot be vertices of the other one).
-    static thread_local std::vector<uint32_t> start, key, pos;
-    static thread_local std::vector<D2> sorted;
+    // sort by (x, y): counting sort into ~n/4 x-buckets, then tiny std::sorts -- the candidates are a few
+    // thousand points spread evenly along the mesh border, a comparison sort of all of them costs ~0.5 ms
     const size_t n = pts.size();
-    D2 L = pts[0], R = pts[0];
-    for (const D2 &p : pts) {
-        if (p.x < L.x || (p.x == L.x && p.y < L.y)) L = p;
-        if (p.x > R.x || (p.x == R.x && p.y > R.y)) R = p;
-    }
-    const double xmin = L.x, xmax = R.x;
+    double xmin = pts[0].x, xmax = pts[0].x;
+    for (const D2 &p : pts) { xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x); }
     const size_t nb = std::max<size_t>(1, n / 4);
     const double scale = xmax > xmin ? (double)(nb - 1) / (xmax - xmin) : 0.0;
-    start.assign(nb + 1, 0);
-    key.resize(n);
+    std::vector<uint32_t> start(nb + 1, 0);
+    std::vector<uint32_t> key(n);
     for (size_t i = 0; i < n; ++i) {
         size_t b = (size_t)((pts[i].x - xmin) * scale);
         if (b >= nb) b = nb - 1;
@@ -637,46 +671,41 @@ void convex_chains(std::vector<D2> &pts, std::vector<D2> &lower, std::vector<D2>
         ++start[b + 1];
     }
     for (size_t b = 0; b < nb; ++b) start[b + 1] += start[b];
-    sorted.resize(n);
-    pos.assign(start.begin(), start.end() - 1);
-    for (size_t i = 0; i < n; ++i) sorted[pos[key[i]]++] = pts[i];
+    std::vector<D2> sorted(n);
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < n; ++i) sorted[fill[key[i]]++] = pts[i];
     auto less = [](const D2 &a, const D2 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); };
-    auto cross = [](const D2 &o, const D2 &a, const D2 &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
-    lower.clear(); upper.clear();
-    auto feed = [&](const D2 &p) {
-        const double side = cross(L, R, p);          // > 0: above the chord 
-        if (side <= 0) {
-            while (lower.size() >= 2 && cross(lower[lower.size() - 2], lower.back(), p) <= 0) lower.pop_back();
-            lower.push_back(p);
-        }
-        if (side >= 0) {
-            while (upper.size() >= 2 && cross(upper[upper.size() - 2], upper.back(), p) >= 0) upper.pop_back();
-            upper.push_back(p);
-        }
-    };
+    size_t out = 0;                                   // compacted in place: reduced buckets shrink
     for (size_t b = 0; b < nb; ++b) {
-        const size_t s = start[b], e = start[b + 1];
-        if (e - s > 8) {
-            double bx0 = sorted[s].x, bx1 = bx0, y0 = sorted[s].y, y1 = y0;
-            for (size_t i = s + 1; i < e; ++i) {
+        const size_t s0 = start[b], e0 = start[b + 1];
+        if (e0 - s0 > 8) {
+            double bx0 = sorted[s0].x, bx1 = bx0;
+            D2 lo = sorted[s0], hi = sorted[s0];
+            for (size_t i = s0 + 1; i < e0; ++i) {
                 bx0 = std::min(bx0, sorted[i].x); bx1 = std::max(bx1, sorted[i].x);
-                y0 = std::min(y0, sorted[i].y);   y1 = std::max(y1, sorted[i].y);
+                if (sorted[i].y < lo.y) lo = sorted[i];
+                if (sorted[i].y > hi.y) hi = sorted[i];
             }
-            if (bx0 == bx1) {                      // one abscissa: lowest first, highest second
-                feed(D2{ bx0, y0 });
-                if (y1 > y0) feed(D2{ bx0, y1 });
+            if (bx0 == bx1) {                         // one abscissa: only the lowest and the highest point matter
+                sorted[out++] = lo;
+                if (hi.y > lo.y) sorted[out++] = hi;
                 continue;
             }
-            std::sort(sorted.begin() + s, sorted.begin() + e, less);
-        } else {
-            for (size_t i = s + 1; i < e; ++i) {   // insertion sort of a handful of points
-                const D2 v = sorted[i];
-                size_t j = i;
-                while (j > s && less(v, sorted[j - 1])) { sorted[j] = sorted[j - 1]; --j; }
-                sorted[j] = v;
-            }
         }
-        for (size_t i = s; i < e; ++i) feed(sorted[i]);
+        if (e0 - s0 > 1) std::sort(sorted.begin() + s0, sorted.begin() + e0, less);
+        if (out != s0) std::copy(sorted.begin() + s0, sorted.begin() + e0, sorted.begin() + out);
+        out += e0 - s0;
+    }
+    sorted.resize(out);
+    auto cross = [](const D2 &o, const D2 &a, const D2 &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
+    lower.clear(); upper.clear();
+    for (const D2 &p : sorted) {       // smallest y at every x
+        while (lower.size() >= 2 && cross(lower[lower.size() - 2], lower.back(), p) <= 0) lower.pop_back();
+        lower.push_back(p);
+    }
+    for (const D2 &p : sorted) {       // largest y at every x
+        while (upper.size() >= 2 && cross(upper[upper.size() - 2], upper.back(), p) >= 0) upper.pop_back();
+        upper.push_back(p);
     }
 }
 

@@ -125,6 +125,7 @@ def main():
     # ---------------------------------------------------------------- inputs resident in HBM
     ref = args.ref
     rccl_note = "not needed (1 GPU)" if world == 1 else "skipped (ranks share a GPU)"
+    rccl_hung = False
     B = max(1, args.batch)
     set_bytes = BYTES_PER_PX * h * w * B
     n_sets = args.sets if args.sets > 0 else max(2, -(-(3 * 256 << 20) // set_bytes))
@@ -161,19 +162,32 @@ def main():
         # the one exchange step of the workload: broadcast a shared source field over xGMI (RCCL).  It is
         # set-up, outside the timed region; a failure is reported in the JSON line instead of aborting.
         from oflibnumpy_amd import sharding
-        try:
-            uid = np.zeros(128, np.uint8)
-            if rank == 0:
-                nat.check(lib.ofl_comm_unique_id(uid.ctypes.data))
-            uid = np.ascontiguousarray(sharding.broadcast_bytes(dist, uid, 0))
-            nat.check(lib.ofl_comm_init(uid.ctypes.data, rank, world))
-            nat.check(lib.ofl_comm_broadcast(sets[0][0].vecs.ptr, h * w * 8, 0, None))     # first field of the first batch
-            nat.check(lib.ofl_comm_broadcast(sets[0][0].mask.ptr, h * w, 0, None))
-            device_sync()
-            rccl_note = "ok"
-        except Exception as e:      # noqa: BLE001 - reported, not hidden
-            rccl_note = "failed: {}".format(e)
-            print("rank {}: RCCL broadcast failed: {}".format(rank, e), file=sys.stderr)
+        import threading
+        result = {}
+
+        def exchange():
+            try:
+                uid = np.zeros(128, np.uint8)
+                if rank == 0:
+                    nat.check(lib.ofl_comm_unique_id(uid.ctypes.data))
+                uid = np.ascontiguousarray(sharding.broadcast_bytes(dist, uid, 0))
+                nat.check(lib.ofl_comm_init(uid.ctypes.data, rank, world))
+                nat.check(lib.ofl_comm_broadcast(sets[0][0].vecs.ptr, h * w * 8, 0, None))     # first field of the first batch
+                nat.check(lib.ofl_comm_broadcast(sets[0][0].mask.ptr, h * w, 0, None))
+                device_sync()
+                result["note"] = "ok"
+            except Exception as e:      # noqa: BLE001 - reported, not hidden
+                result["note"] = "failed: {}".format(e)
+
+        # watchdog: a communicator that cannot be set up (no usable interface, peer access refused) must not hang
+        # the benchmark of a path that needs no collective; the outcome is reported in the JSON line
+        worker = threading.Thread(target=exchange, daemon=True)
+        worker.start()
+        worker.join(float(os.environ.get("OFL_RCCL_TIMEOUT", "180")))
+        rccl_note = result.get("note", "timed out")
+        rccl_hung = worker.is_alive()
+        if rccl_note != "ok":
+            print("rank {}: RCCL broadcast {}".format(rank, rccl_note), file=sys.stderr)
     total = args.warmup + args.steps
     stats = None if args.no_stats else dev.DeviceBuffer.zeros(32 * B * total)
 
@@ -243,6 +257,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(h, w, ref)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        if rccl_hung:                         # a rank still stuck inside the communicator set-up cannot shut down cleanly
+            sys.stdout.flush()
+            os._exit(0)
         nat.check(lib.ofl_comm_destroy())      # no-op when no communicator was created
         dist.barrier()
         dist.destroy_process_group()

@@ -800,6 +800,12 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
     }
 }
 
+#ifndef OFL_G2_NT_FLOW
+#define OFL_G2_NT_FLOW 0       // measured: non-temporal flow loads / image stores do not help this kernel (they do help K2)
+#endif
+#ifndef OFL_G2_NT_DST
+#define OFL_G2_NT_DST 0
+#endif
 template <typename T, int CT>
 __global__ __launch_bounds__(256)
 void gather2_kernel(const T *__restrict__ src, int H, int W,
@@ -819,14 +825,27 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
 
     float fu[4], fv[4];
     bool  inf[4];
+    uint32_t fmw[2] = { 0u, 0u };          // flow-mask bytes of the pixel pairs, fetched with the flow (not at the store)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int fx = xg[g] - pad_left;
         inf[2 * g]     = act[g] && row_in_flow && (unsigned)fx < (unsigned)fW;
         inf[2 * g + 1] = act[g] && row_in_flow && (unsigned)(fx + 1) < (unsigned)fW;
         fu[2 * g] = fv[2 * g] = fu[2 * g + 1] = fv[2 * g + 1] = 0.0f;
+        if (fmask && valid) {
+            if (aligned && inf[2 * g] && inf[2 * g + 1]) {
+                fmw[g] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(fmask + (size_t)fy * fW + fx));
+            } else {
+                if (inf[2 * g]) fmw[g] |= fmask[(size_t)fy * fW + fx];
+                if (inf[2 * g + 1]) fmw[g] |= (uint32_t)fmask[(size_t)fy * fW + fx + 1] << 8;
+            }
+        }
         if (aligned && inf[2 * g] && inf[2 * g + 1]) {
+#if OFL_G2_NT_FLOW
+            const v4f f = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(flow + ((size_t)fy * fW + fx) * 2));
+#else
             const float4 f = *reinterpret_cast<const float4 *>(flow + ((size_t)fy * fW + fx) * 2);
+#endif
             fu[2 * g] = f.x; fv[2 * g] = f.y; fu[2 * g + 1] = f.z; fv[2 * g + 1] = f.w;
         } else {
 #pragma unroll
@@ -881,6 +900,7 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
             if (act[j >> 1]) gather_px<T, CT, false>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
     }
 
+    uint32_t vword[2] = { 0u, 0u };
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (!act[g]) continue;
@@ -889,19 +909,31 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
+#if OFL_G2_NT_DST
+            for (int c = 0; c < CT; ++c) __builtin_nontemporal_store(res[2 * g + e][c], &d[e * CT + c]);
+#else
             for (int c = 0; c < CT; ++c) d[e * CT + c] = res[2 * g + e][c];
+#endif
         if (want_valid) {
-            uint32_t m = 0;
+            uint32_t m = (ok[2 * g] ? 1u : 0u) | (ok[2 * g + 1] ? 0x100u : 0u);
+            if (fmask) m &= ((fmw[g] & 0xffu) ? 1u : 0u) | ((fmw[g] & 0xff00u) ? 0x100u : 0u);
+            vword[g] = m;
+        }
+    }
+    if (want_valid) {
+        // Validity bytes leave as DWORDS: the lane pairs (2k, 2k + 1) own four consecutive pixels, the even lane
+        // stores both lanes' bytes -- sub-dword stores cost as much per instruction as 16-byte ones.
+        const bool quad = (W & 3) == 0;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                bool v = ok[2 * g + e];
-                if (fmask) {
-                    const int fx = xg[g] + e - pad_left;
-                    v = v && inf[2 * g + e] && fmask[(size_t)fy * fW + fx] != 0;
-                }
-                m |= (v ? 1u : 0u) << (8 * e);
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)vword[g], 1);
+            if (!act[g]) continue;
+            const size_t o = (size_t)yl * W + xg[g];
+            if (quad) {
+                if ((lx & 1) == 0) __builtin_nontemporal_store(vword[g] | (other << 16), reinterpret_cast<uint32_t *>(valid + o));
+            } else {
+                __builtin_nontemporal_store((uint16_t)vword[g], reinterpret_cast<uint16_t *>(valid + o));
             }
-            *reinterpret_cast<uint16_t *>(valid + o) = (uint16_t)m;
         }
     }
 }

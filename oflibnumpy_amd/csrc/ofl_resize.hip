@@ -11,6 +11,11 @@ using namespace ofl;
 
 namespace {
 
+#ifndef OFL_RS_NT
+#define OFL_RS_NT 1            // non-temporal output stores
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 struct ResizeCoef { int s0, s1; float w0, w1; };
 
 // opencv resize.cpp: fx = (float)((dx + 0.5) * scale - 0.5); sx = floor(fx); fx -= sx.  Columns collapse the tap
@@ -75,8 +80,14 @@ void resize_flow_kernel(const float2 *__restrict__ src, const uint8_t *__restric
         const ResizeCoef cx1 = resize_coef(dx + 1, scale_x, W, true);
         const float2 p1 = resize_px(src, mask, W, cx1, cy, mul_u, mul_v, m1);
         if ((o & 1) == 0) {                          // 16-byte aligned pair (always when Wo is even)
+#if OFL_RS_NT
+            const v4f v = { p0.x, p0.y, p1.x, p1.y };
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(out) + (o >> 1));
+            if (mout) __builtin_nontemporal_store((uint16_t)(m0 | (m1 << 8)), reinterpret_cast<uint16_t *>(mout + o));
+#else
             reinterpret_cast<float4 *>(out)[o >> 1] = make_float4(p0.x, p0.y, p1.x, p1.y);
             if (mout) *reinterpret_cast<uint16_t *>(mout + o) = (uint16_t)(m0 | (m1 << 8));
+#endif
         } else {
             out[o] = p0; out[o + 1] = p1;
             if (mout) { mout[o] = m0; mout[o + 1] = m1; }

@@ -90,12 +90,12 @@ def main():
         report("invert s->s, {} (K3)".format(name), (h, w), 18, *t, note="discontinuous field")
     del yy, xx, obj, stripes
 
-    # K4: Flow.resize of the 4K field: 9 B per source px read + 9 B per output px written
+    # K6: Flow.resize of the 4K field: 9 B per source px read + 9 B per output px written
     for scale in (0.5, 2, 1.5):
         ho, wo = dev.resized_shape(h, w, scale, scale)
         t = timed(lambda: d2.resize(scale), it)
         n_eq = (h * w + ho * wo) * 9 / (h * w)
-        report("resize x{} (K4)".format(scale), (h, w), n_eq, *t, note="{}x{} -> {}x{}; bytes = 9 B x (source + output px)".format(h, w, ho, wo))
+        report("resize x{} (K6)".format(scale), (h, w), n_eq, *t, note="{}x{} -> {}x{}; bytes = 9 B x (source + output px)".format(h, w, ho, wo))
 
     # config 5: Sintel .flo tiled to 4320 x 7680, apply to an RGB f32 image: 't' (gather) and 's' (scatter)
     flo = of.load_sintel(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sintel.flo"))

@@ -411,3 +411,31 @@ def test_discontinuous_fields_vs_reference(gpu, golden):
             np.testing.assert_allclose(r.vecs[~band], golden[tag + '/out_vecs'][~band], rtol=RTOL, atol=1e-5, err_msg=tag)
         else:
             np.testing.assert_array_equal(f.valid_target()[~band], golden[tag + '/out'][~band], err_msg=tag)
+
+
+def test_apply_entry_points_agree_both_refs(gpu):
+    """Restates reference tests/test_flow_class.py:417-438 (Flow.apply == apply_flow for 3-D, 2-D and Flow targets,
+    with and without a mask, both references) and tests/test_utils.py:267-283 (rotation vs scipy.ndimage.rotate,
+    loose; translation vs scipy.ndimage.shift, exact) on a smooth synthetic uint8 image."""
+    from scipy import ndimage
+    of = gpu
+    yy, xx = np.mgrid[:512, :512]
+    img = np.stack([127 + 100 * np.sin(xx / 23.0) * np.cos(yy / 31.0), 127 + 90 * np.cos(xx / 17.0 + yy / 41.0),
+                    (xx + yy) / 4.0], -1).astype(np.uint8)
+    for ref in ('t', 's'):
+        flow = of.Flow.from_transforms([['rotation', 30, 50, 30]], img.shape[:2], ref)
+        mask = np.ones(img.shape[:2], bool)
+        want = of.apply_flow(flow.vecs, img, ref)
+        np.testing.assert_array_equal(flow.apply(img), want)
+        np.testing.assert_array_equal(flow.apply(img, mask, return_valid_area=True)[0], want)
+        want2 = of.apply_flow(flow.vecs, img[..., 0], ref)
+        assert want2.shape == img.shape[:2]
+        np.testing.assert_array_equal(flow.apply(img[..., 0]), want2)
+        np.testing.assert_array_equal(flow.apply(img[..., 0], mask, return_valid_area=True)[0], want2)
+        np.testing.assert_array_equal(want2, want[..., 0])
+        np.testing.assert_array_equal(flow.apply(flow).vecs, of.apply_flow(flow.vecs, flow.vecs, ref))
+        rot = of.Flow.from_transforms([['rotation', 255.5, 255.5, -30]], img.shape[:2], ref).vecs
+        control = ndimage.rotate(img[..., 0], -30, reshape=False)
+        np.testing.assert_allclose(control[200:300, 200:300], of.apply_flow(rot, img[..., 0], ref)[200:300, 200:300], atol=20, rtol=0.05)
+        tr = of.Flow.from_transforms([['translation', 10, 20]], img.shape[:2], ref).vecs
+        np.testing.assert_array_equal(of.apply_flow(tr, img, ref), ndimage.shift(img, [20, 10, 0]))

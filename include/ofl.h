@@ -196,6 +196,16 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
                            const float *vals, int C, const uint8_t *vmask, int H, int W,
                            const float *query, float *out, uint8_t *valid, int valid_rule,
                            void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
+/* One row band of the grid result (SURVEY 8e, config 5 as loaded, ref 's'): every rank holds the full inputs
+ * (flow, masks, values are replicated), rasterises only the triangles that reach rows
+ * [row0 - 16, row0 + rows + 16) and resolves rows [row0, row0 + rows): out_rows [rows][W][C],
+ * valid_rows [rows][W].  The concatenation of the bands equals ofl_scatter_linear_dev bit for bit; bands are
+ * disjoint, nothing is exchanged afterwards.  Same workspace size as the full call.
+ */
+int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                         const float *vals, int C, const uint8_t *vmask, int H, int W, int row0, int rows,
+                         float *out_rows, uint8_t *valid_rows, int valid_rule,
+                         void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
 int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes);
 int ofl_scatter_linear(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                        const float *vals, int C, const uint8_t *vmask, int H, int W,

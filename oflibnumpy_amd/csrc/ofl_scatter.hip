@@ -55,6 +55,8 @@ struct ScatterWs {          // layout of the caller-provided workspace
     unsigned long long *counters;   // [1] big-list length, [2] big-list work, [3] candidates
     unsigned long long *kept_slots; // [256] partial counts of kept points
     int       cand_cap;
+    int       oy0, oy1;     // rows [oy0, oy1) the owner map covers (0, H unless one row band is computed);
+                            // `owner` is biased so that owner[y * W + x] addresses row y for y in that range
 };
 
 struct HullRef { const D2 *lower, *upper; int n_lower, n_upper; };
@@ -227,6 +229,15 @@ __device__ __forceinline__ bool inside_or_on(const D2 &a, const D2 &b, const D2 
     return w0 >= 0.0 && w1 >= 0.0 && w2 >= 0.0;
 }
 
+// bounding box restricted to the rows of the owner map
+__device__ __forceinline__ TriBox tri_box_rows(const D2 &p0, const D2 &p1, const D2 &p2, int W, int H, const ScatterWs &ws)
+{
+    TriBox b = tri_box(p0, p1, p2, W, H);
+    b.y0 = max(b.y0, ws.oy0);
+    b.y1 = min(b.y1, ws.oy1 - 1);
+    return b;
+}
+
 __device__ __forceinline__ uint32_t tri_id(uint32_t cell, int diag, int t) { return (cell << 2) | ((uint32_t)diag << 1) | (uint32_t)t; }
 
 // decode a triangle id into its three source vertices (linear pixel indices) and positions
@@ -361,7 +372,7 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
         tri_corners(diag, t, i0, i1, i2);
         if (!(pick4(i0, k0, k1, k2, k3) && pick4(i1, k0, k1, k2, k3) && pick4(i2, k0, k1, k2, k3))) continue;
         const D2 q0 = pick4(i0, pa, pb, pc, pd), q1 = pick4(i1, pa, pb, pc, pd), q2 = pick4(i2, pa, pb, pc, pd);
-        const TriBox b = tri_box(q0, q1, q2, W, H);
+        const TriBox b = tri_box_rows(q0, q1, q2, W, H, ws);
         if (b.x1 < b.x0 || b.y1 < b.y0) continue;
         const uint32_t id = tri_id(cell, diag, t);
         const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
@@ -397,9 +408,10 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
             size_t vi[3];
             D2 vp[3];
             tri_decode(bid, flow, sign, W, vi, vp);
-            const TriBox bb = tri_box(vp[0], vp[1], vp[2], W, H);
+            const TriBox bb = tri_box_rows(vp[0], vp[1], vp[2], W, H, ws);
             TriEdge tb;
             if (!tri_setup(vp[0], vp[1], vp[2], tb)) continue;
+            if (bb.x1 < bb.x0 || bb.y1 < bb.y0) continue;
             const int bw = bb.x1 - bb.x0 + 1, n = bw * (bb.y1 - bb.y0 + 1);
             for (int k = lane; k < n; k += 64) {
                 const int ry = k / bw, gx = bb.x0 + (k - ry * bw), gy = bb.y0 + ry;
@@ -439,14 +451,14 @@ __device__ __forceinline__ bool inside_hull(const HullRef &h, double qx, double 
 
 // nearest covered grid node around (cx, cy): rings of growing Chebyshev radius, ties to the smallest
 // Euclidean distance then the smallest owner id (deterministic)
-__device__ __forceinline__ uint32_t nearest_owner(const uint32_t *owner, int H, int W, int cx, int cy, double qx, double qy)
+__device__ __forceinline__ uint32_t nearest_owner(const uint32_t *owner, int y_lo, int y_hi, int W, int cx, int cy, double qx, double qy)
 {
     for (int r = 0; r <= kFillRadius; ++r) {
         uint32_t best = kNoOwner;
         double bestd = 1e300;
         for (int dy = -r; dy <= r; ++dy) {
             const int yy = cy + dy;
-            if (yy < 0 || yy >= H) continue;
+            if (yy < y_lo || yy >= y_hi) continue;
             const int step = (dy == -r || dy == r) ? 1 : 2 * r;
             for (int dx = -r; dx <= r; dx += (step > 0 ? step : 1)) {
                 const int xx = cx + dx;
@@ -475,7 +487,8 @@ void scatter_big_kernel(const float *__restrict__ flow, int sign, int H, int W, 
         size_t vi[3];
         D2 vp[3];
         tri_decode(id, flow, sign, W, vi, vp);
-        const TriBox b = tri_box(vp[0], vp[1], vp[2], W, H);
+        const TriBox b = tri_box_rows(vp[0], vp[1], vp[2], W, H, ws);
+        if (b.x1 < b.x0 || b.y1 < b.y0) continue;
         const long long bw = b.x1 - b.x0 + 1, area = bw * (b.y1 - b.y0 + 1);
         TriEdge te;
         if (!tri_setup(vp[0], vp[1], vp[2], te)) continue;
@@ -542,7 +555,7 @@ __device__ __forceinline__ bool fill_from_nearest(const float *flow, int sign, i
 {
     if (!(hull.n_lower > 0 && inside_hull(hull, qx, qy))) return false;
     const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
-    id = nearest_owner(ws.owner, H, W, nx, ny, qx, qy);
+    id = nearest_owner(ws.owner, ws.oy0, ws.oy1, W, nx, ny, qx, qy);
     if (id == kNoOwner) return false;
     tri_decode(id, flow, sign, W, vi, vp);
     (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
@@ -578,12 +591,13 @@ void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint
                             const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
                             int H, int W, const float *__restrict__ query,
                             float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, ScatterWs ws,
-                            HullRef hull)
+                            HullRef hull, int row0, int rows)
 {
+    // rows [row0, row0 + rows) of the grid are resolved; out / valid / query hold those rows only
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    const size_t o = (size_t)y * W + x;
+    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
+    if (x >= W || yl >= rows) return;
+    const size_t o = (size_t)yl * W + x;
     double qx = x, qy = y;
     uint32_t id = kNoOwner;
     size_t vi[3];
@@ -591,7 +605,7 @@ void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint
     double c0 = 0, c1 = 0, c2 = 0;
     bool found = false;
     if (!query) {
-        id = ws.owner[o];
+        id = ws.owner[(size_t)y * W + x];
         if (id != kNoOwner) {      // the raster pass decided containment; only the coordinates are needed
             tri_decode(id, flow, sign, W, vi, vp);
             (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
@@ -648,6 +662,8 @@ ScatterWs carve(void *workspace, int H, int W)
     ws.upper = (D2 *)p;                      p += (size_t)kHullCap * sizeof(D2);      // ONE upload
     ws.big = (uint32_t *)p;                  p += align_up((size_t)kBigCap * 4, 256);
     ws.owner = (uint32_t *)p;
+    ws.oy0 = 0;
+    ws.oy1 = H;
     return ws;
 }
 
@@ -744,9 +760,10 @@ namespace {
 
 // Passes 1, 1b and the hull: everything the interpolation passes need.  `sign` arrives with the point
 // precision already folded in (+-1 / +-2).
+// [oy0, oy1): rows of the grid whose owners are needed (everything, or one row band plus the gap-fill radius).
 int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, int W,
                     void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s,
-                    ScatterWs &ws, HullRef &hull)
+                    ScatterWs &ws, HullRef &hull, int oy0 = 0, int oy1 = -1)
 {
     if (!flow || !workspace) return fail(OFL_E_INVALID, "ofl_scatter_linear: NULL pointer");
     if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 29))
@@ -755,7 +772,11 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
     OFL_TRY(ofl_scatter_workspace_bytes(H, W, 0, &need));
     if (workspace_bytes < need) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small (%zu < %zu)", workspace_bytes, need);
     ws = carve(workspace, H, W);
-    OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)H * W * 4, s));
+    if (oy1 < 0) oy1 = H;
+    OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)(oy1 - oy0) * W * 4, s));
+    ws.oy0 = oy0;
+    ws.oy1 = oy1;
+    ws.owner -= (size_t)oy0 * W;         // biased base: owner[y * W + x] is row y of the covered range
     OFL_HIP(hipMemsetAsync(ws.counters, 0, kHeadBytes, s));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_raster_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
@@ -845,7 +866,34 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
-                       out, valid, valid_rule, ws, hull);
+                       out, valid, valid_rule, ws, hull, 0, H);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                         const float *vals, int C, const uint8_t *vmask, int H, int W, int row0, int rows,
+                         float *out_rows, uint8_t *valid_rows, int valid_rule,
+                         void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
+{
+    OFL_TRY(need_device());
+    if (C < 0 || (C > 0 && (!vals || !out_rows))) return fail(OFL_E_INVALID, "ofl_scatter_rows: C > 0 needs vals and out");
+    if (C == 0 && !valid_rows) return fail(OFL_E_INVALID, "ofl_scatter_rows: nothing to compute");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_rows: sign must be +1 or -1");
+    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_rows: bad point_precision");
+    if (point_precision == 1) sign *= 2;
+    if (valid_rule != 0 && valid_rule != 1) return fail(OFL_E_INVALID, "ofl_scatter_rows: bad valid_rule");
+    if (H <= 0 || W <= 0 || row0 < 0 || rows <= 0 || row0 + rows > H)
+        return fail(OFL_E_INVALID, "ofl_scatter_rows: rows [%d, %d) outside the %d-row grid", row0, row0 + rows, H);
+    hipStream_t s = stream_of(stream);
+    ScatterWs ws;
+    HullRef hull;
+    // owners are needed for the band and, for the gap fill, kFillRadius rows around it
+    const int oy0 = std::max(0, row0 - kFillRadius), oy1 = std::min(H, row0 + rows + kFillRadius);
+    OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull, oy0, oy1));
+    const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
+    hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, (const float *)nullptr,
+                       out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

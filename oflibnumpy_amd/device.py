@@ -557,6 +557,19 @@ def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, v
     return tuple(info)
 
 
+def scatter_rows(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, valid_rows, valid_rule=0,
+                 point_precision=0, stream=None):
+    """K3 on one row band of a field split over several GPUs (SURVEY 8e, config 5 as loaded): all inputs are the
+    replicated H x W arrays; only rows [row0, row0 + rows) of the result are produced."""
+    ws = _workspace(h, w, C)
+    info = (ctypes.c_uint64 * 3)()
+    ptr = lambda b: b.ptr if b is not None else None
+    nat.check(_lib().ofl_scatter_rows_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),
+                                          h, w, row0, rows, ptr(out_rows), ptr(valid_rows), valid_rule, ws.ptr, ws.nbytes,
+                                          info, stream))
+    return tuple(info)
+
+
 def scatter_host(flow, target, pmask, vmask=None):
     """apply_flow(flow, target, 's', mask) for host arrays (utils.py:237-258): target (H, W, C) of any numeric
     dtype is interpolated in float32/float64 on the device, then rounded / cast back like the reference.

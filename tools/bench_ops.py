@@ -113,6 +113,15 @@ def main():
     t = timed(lambda: info.append(dev.scatter_linear(dt.vecs, +1, None, vals, 3, None, h, w, None, out, valid, 0)), 3, warm=1)
     report("apply 's' RGB f32 + valid, tiled Sintel 4320x7680 (K3)", (h, w), 34, *t,
            note="BASELINE config 5 as loaded ('s'); large triangles: {}".format(info[-1][1:]))
+    # the same field split over 8 GPUs: what ONE rank computes (rows of band 3; inputs replicated)
+    from oflibnumpy_amd import sharding
+    r0, r1 = sharding.row_band(h, 3, 8)
+    ob, vb = dev.DeviceBuffer((r1 - r0) * w * 12), dev.DeviceBuffer((r1 - r0) * w)
+    t = timed(lambda: dev.scatter_rows(dt.vecs, +1, None, vals, 3, None, h, w, r0, r1 - r0, ob, vb), 3, warm=1)
+    report("apply 's', row band 3 of 8 of the same field (K3)", (r1 - r0, w), 34, *t, note="one rank's share of config 5 ('s') on 8 GPUs")
+    fb = dev.DeviceBuffer.from_host(np.ascontiguousarray(big[r0:r1]))
+    t = timed(lambda: dev.gather_rows(dimg, r0, r1 - r0, fb, -1, want_valid=True), max(3, it // 2))
+    report("apply 't', row band 3 of 8 of the same field (K1)", (r1 - r0, w), 33, *t, note="one rank's share of config 5 ('t') on 8 GPUs")
 
 
 if __name__ == "__main__":

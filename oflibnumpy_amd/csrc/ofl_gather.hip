@@ -755,6 +755,38 @@ void gather_kernel(const T *__restrict__ src, int Crt, int H, int W,
 // pairs at x = 2*lx and x = 64 + 2*lx, so flow loads (16 B), image stores (2*C elements) and validity stores
 // (2 B) of a wave are contiguous -- and the same three wave-uniform paths (all samples outside / all
 // inside / border).  Numerics are those of gather_kernel (and of the oracle), element for element.
+// BYTES (2 .. 16) consecutive bytes from a possibly unaligned address into 32-bit words
+template <int BYTES>
+__device__ __forceinline__ void load_run(const uint8_t *p, uint32_t (&w)[4])
+{
+    if constexpr (BYTES == 2) {
+        w[0] = *reinterpret_cast<const uint16_t *>(p);
+    } else if constexpr (BYTES == 4) {
+        w[0] = *reinterpret_cast<const uint32_t *>(p);
+    } else if constexpr (BYTES == 6) {
+        w[0] = *reinterpret_cast<const uint32_t *>(p);
+        w[1] = *reinterpret_cast<const uint16_t *>(p + 4);
+    } else if constexpr (BYTES == 8) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        w[0] = t.x; w[1] = t.y;
+    } else if constexpr (BYTES == 12) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        w[0] = t.x; w[1] = t.y;
+        w[2] = *reinterpret_cast<const uint32_t *>(p + 8);
+    } else {
+        static_assert(BYTES == 16, "load_run: unsupported run length");
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T run_elem(const uint32_t (&w)[4], int i)      // i is a compile-time constant after unrolling
+{
+    if constexpr (sizeof(T) == 1) return (T)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    else                          return (T)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+}
+
 template <typename T, int CT, bool INSIDE>
 __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8_t *__restrict__ smask, int H, int W,
                                           const Tap &tp, const int (&wi)[4], bool fixed_u8, int arith, int rule,
@@ -768,12 +800,40 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
         in[k]  = INSIDE ? true : ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W);
         off[k] = in[k] ? (size_t)yy * W + xx : 0;
     }
+    // the mask taps are requested BEFORE the image taps (their latency hides behind the image loads); inside the
+    // image the two taps of a row are one 2-byte load (unaligned addresses are fine for global loads on gfx950)
+    int m[4] = { 0, 0, 0, 0 };
+    if (want_valid) {
+        if (!smask) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = in[k] ? 1 : 0;
+        } else if (INSIDE) {
+            const uint32_t r0 = *reinterpret_cast<const uint16_t *>(smask + off[0]), r1 = *reinterpret_cast<const uint16_t *>(smask + off[2]);
+            m[0] = (r0 & 0xffu) != 0; m[1] = (r0 & 0xff00u) != 0; m[2] = (r1 & 0xffu) != 0; m[3] = (r1 & 0xff00u) != 0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = in[k] ? (smask[off[k]] != 0) : 0;
+        }
+    }
     typedef typename Acc<T>::type A;
+    // 8- and 16-bit images inside the source: the two taps of a row are 2 * CT adjacent elements = 2 .. 16 bytes,
+    // fetched as one or two wide loads per row instead of 2 * CT element loads (unaligned global loads are fine)
+    constexpr bool kRun = INSIDE && sizeof(T) <= 2;
+    uint32_t run[2][4] = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
+    if constexpr (kRun) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) load_run<2 * CT * (int)sizeof(T)>(reinterpret_cast<const uint8_t *>(src + off[2 * r] * CT), run[r]);
+    }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         A v[4];
+        if constexpr (kRun) {
+            v[0] = (A)run_elem<T>(run[0], c); v[1] = (A)run_elem<T>(run[0], CT + c);
+            v[2] = (A)run_elem<T>(run[1], c); v[3] = (A)run_elem<T>(run[1], CT + c);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = in[k] ? (A)src[off[k] * CT + c] : (A)0;
+            for (int k = 0; k < 4; ++k) v[k] = in[k] ? (A)src[off[k] * CT + c] : (A)0;
+        }
         if constexpr (sizeof(T) == 8) {
             res[c] = (T)blend4d(v[0], v[1], v[2], v[3], tp);
         } else {
@@ -787,9 +847,6 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
     }
     ok = false;
     if (want_valid) {
-        int m[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = in[k] ? (smask ? (smask[off[k]] != 0) : 1) : 0;
         if (rule == OFL_RULE_GE_HALF) {
             const int acc = m[0] * wi[0] + m[1] * wi[1] + m[2] * wi[2] + m[3] * wi[3];
             ok = ((acc + (1 << 14)) >> 15) == 1;

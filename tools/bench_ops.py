@@ -63,6 +63,12 @@ def main():
     t = timed(lambda: dev.gather_bilinear(dimg, d1.vecs, (h, w), -1, fmask=d1.mask, want_valid=True), it)
     report("apply 't' RGB f32 + valid (K1)", (h, w), 34, *t, note="BASELINE config 2; rotated sampling pattern")
 
+    u8 = dev.DeviceImage.from_host((img * 255).astype(np.uint8))
+    tm = dev.DeviceBuffer.from_host((np.random.default_rng(3).random((h, w)) > 0.1).astype(np.uint8))
+    t = timed(lambda: dev.gather_bilinear(u8, d1.vecs, (h, w), -1, smask=tm, fmask=d1.mask, want_valid=True,
+                                          arith=nat.ARITH_NATIVE, rule=nat.RULE_GE_HALF), it)
+    report("apply 't' RGB uint8 + target mask + valid (K1)", (h, w), 17, *t, note="8 + 1 flow, 3 + 3 image, 1 + 1 masks")
+
     # config 3: 2160 x 3840 's': invert (1 scatter, 18 B/px) and combine mode 1 (72 B/px stage sum)
     h, w = 2160, 3840
     f2 = of.Flow.from_transforms([['scaling', 1000, 800, 0.9]], [h, w], 's')

@@ -783,8 +783,9 @@ __device__ __forceinline__ void load_run(const uint8_t *p, uint32_t (&w)[4])
 template <typename T>
 __device__ __forceinline__ T run_elem(const uint32_t (&w)[4], int i)      // i is a compile-time constant after unrolling
 {
-    if constexpr (sizeof(T) == 1) return (T)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-    else                          return (T)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+    if constexpr (sizeof(T) == 1)      return (T)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    else if constexpr (sizeof(T) == 2) return (T)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+    else                               return (T)__uint_as_float(w[i]);
 }
 
 template <typename T, int CT, bool INSIDE>
@@ -818,7 +819,7 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
     typedef typename Acc<T>::type A;
     // 8- and 16-bit images inside the source: the two taps of a row are 2 * CT adjacent elements = 2 .. 16 bytes,
     // fetched as one or two wide loads per row instead of 2 * CT element loads (unaligned global loads are fine)
-    constexpr bool kRun = INSIDE && sizeof(T) <= 2;
+    constexpr bool kRun = INSIDE && (sizeof(T) <= 2 || (sizeof(T) == 4 && CT <= 2));     // float: 1 or 2 channels = 8 / 16 bytes per row
     uint32_t run[2][4] = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
     if constexpr (kRun) {
 #pragma unroll

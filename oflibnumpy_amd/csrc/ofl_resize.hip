@@ -51,12 +51,25 @@ __device__ __forceinline__ float resize_blend(float v00, float v01, float v10, f
 __device__ __forceinline__ float2 resize_px(const float2 *__restrict__ src, const uint8_t *__restrict__ mask, int W,
                                             const ResizeCoef &cx, const ResizeCoef &cy, float mul_u, float mul_v, uint8_t &m)
 {
-    const size_t i00 = (size_t)cy.s0 * W + cx.s0, i01 = (size_t)cy.s0 * W + cx.s1;
-    const size_t i10 = (size_t)cy.s1 * W + cx.s0, i11 = (size_t)cy.s1 * W + cx.s1;
-    const float2 a = src[i00], b = src[i01], c = src[i10], d = src[i11];
+    const size_t i00 = (size_t)cy.s0 * W + cx.s0, i10 = (size_t)cy.s1 * W + cx.s0;
+    float2 a, b, c, d;
+    uint32_t m0, m1;                                  // mask bytes of the two taps of each row
+    if (cx.s1 == cx.s0 + 1) {
+        // the two taps of a row are neighbours: ONE 16-byte load (8-byte aligned) and one 2-byte mask load per row
+        const float4 r0 = *reinterpret_cast<const float4 *>(src + i00), r1 = *reinterpret_cast<const float4 *>(src + i10);
+        a = make_float2(r0.x, r0.y); b = make_float2(r0.z, r0.w);
+        c = make_float2(r1.x, r1.y); d = make_float2(r1.z, r1.w);
+        m0 = mask ? *reinterpret_cast<const uint16_t *>(mask + i00) : 0u;
+        m1 = mask ? *reinterpret_cast<const uint16_t *>(mask + i10) : 0u;
+    } else {                                          // collapsed onto the border column
+        a = b = src[i00];
+        c = d = src[i10];
+        m0 = mask ? mask[i00] * 0x101u : 0u;
+        m1 = mask ? mask[i10] * 0x101u : 0u;
+    }
     if (mask) {
-        const float v = resize_blend((float)(mask[i00] != 0), (float)(mask[i01] != 0), (float)(mask[i10] != 0),
-                                     (float)(mask[i11] != 0), cx, cy);
+        const float v = resize_blend((float)((m0 & 0xffu) != 0), (float)((m0 & 0xff00u) != 0), (float)((m1 & 0xffu) != 0),
+                                     (float)((m1 & 0xff00u) != 0), cx, cy);
         m = (uint8_t)(v > 0.5f);                     // np.round (half to even) of a value in [0, 1]
     }
     return make_float2(resize_blend(a.x, b.x, c.x, d.x, cx, cy) * mul_u, resize_blend(a.y, b.y, c.y, d.y, cx, cy) * mul_v);

@@ -66,6 +66,9 @@ enum {
     OFL_RULE_GT_HALF = 2    /* int16 concat (round-half-even): interpolated > 0.5 */
 };
 
+/* flag OR-ed into the `valid_rule` argument of the scatter entries */
+enum { OFL_SCATTER_ROUND = 0x100 };
+
 /* bits written by the zero-flow statistics (ofl_flow_stats_dev, and the fused compose kernel) */
 enum {
     OFL_STAT_NONZERO_MASKED     = 1,  /* some vector component != 0 where mask   (Flow.is_zero(thresholded=False), flow_class.py:1244) */
@@ -184,6 +187,8 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  *                   0 where no triangle covers the node;
  *     valid[H][W]   valid_rule 0: float32(interpolated vmask) == 1   (flow_class.py:668)
  *                   valid_rule 1: interpolated vmask > 0.99           (flow_class.py:1410)
+ *                   valid_rule | OFL_SCATTER_ROUND: additionally out = float32(rint(float64 result)), the
+ *                   np.round the reference applies to integer-typed targets (utils.py:256-257)
  *                   (vmask NULL = all ones, i.e. valid == "covered by a triangle").
  * query == NULL evaluates at the regular grid nodes; otherwise query [H][W][2] holds absolute (x, y)
  * positions (mode 2 't').  C may be 0 (validity only).  `workspace` (device) must hold
@@ -230,6 +235,12 @@ int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, cons
  *   ofl_grid_offset_dev  out[y][x] = float32((x, y) + sign * vecs[y][x])   (flow_class.py:1398-1406)
  */
 int ofl_mask_and_dev(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, void *stream);
+/*   ofl_convert_dev      element-wise dtype conversion on the device, n elements: any OFL_* dtype -> OFL_F32 (the
+ *                        values the scatter kernel interpolates, utils.py:253) and OFL_F32 -> any dtype with a plain
+ *                        C cast (result.astype(target.dtype), utils.py:258; integer destinations expect integral,
+ *                        in-range values -- the scatter entries with OFL_SCATTER_ROUND produce them)
+ */
+int ofl_convert_dev(const void *src, int src_dtype, void *dst, int dst_dtype, size_t n, void *stream);
 /*   ofl_flow_extent_dev  extent (device float32[4]) = { min y, max y, min x, max x } of the positions
  *                        float32((x, y) + sign * threshold_vectors(vecs)[y][x]) over the masked pixels
  *                        (Flow.get_padding, flow_class.py:1214-1226: sign -1 for ref 't', +1 for 's');

@@ -16,6 +16,7 @@ U8, I16, U16, F32, F64 = 0, 1, 2, 3, 4
 QUANT_OPENCV, QUANT_EXACT = 0, 1
 ARITH_NATIVE, ARITH_FLOAT_RNE = 0, 1
 RULE_EQ1, RULE_GE_HALF, RULE_GT_HALF = 0, 1, 2
+SCATTER_ROUND = 0x100
 STAT_NONZERO_MASKED, STAT_NONZERO_TH_MASKED, STAT_NONZERO, STAT_NONZERO_TH, STAT_NONFINITE = 1, 2, 4, 8, 16
 
 
@@ -74,6 +75,7 @@ SIGNATURES = {
     "ofl_sample_points_dev": (_ci, [_vp, _ci, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_query_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _cs, _vp, _vp, _vp, _cs, _vp]),
     "ofl_flow_extent_dev": (_ci, [_vp, _vp, _ci, _ci, _ci, _cf, _vp, _vp]),
+    "ofl_convert_dev": (_ci, [_vp, _ci, _vp, _ci, _cs, _vp]),
     "ofl_mask_and_dev": (_ci, [_vp, _vp, _vp, _cs, _vp]),
     "ofl_grid_offset_dev": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
     "ofl_resize_flow": (_ci, [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _cd, _cf, _cf, _vp, _vp]),

@@ -628,14 +628,14 @@ void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint
     }
     for (int c = 0; c < C; ++c) {
         const double v = c0 * (double)vals[vi[0] * C + c] + c1 * (double)vals[vi[1] * C + c] + c2 * (double)vals[vi[2] * C + c];
-        out[o * C + c] = (float)v;
+        out[o * C + c] = (float)((valid_rule & OFL_SCATTER_ROUND) ? rint(v) : v);      // np.round of the float64 result, utils.py:256-257
     }
     if (valid) {
         double m = 1.0;
         if (vmask) m = c0 * (double)(vmask[vi[0]] != 0) + c1 * (double)(vmask[vi[1]] != 0) + c2 * (double)(vmask[vi[2]] != 0);
         else       m = c0 + c1 + c2;
         const float mf = (float)m;                                   // result.astype(target.dtype), utils.py:258
-        valid[o] = valid_rule == 0 ? (mf == 1.0f) : (m > 0.99);     // flow_class.py:668 / :1410
+        valid[o] = (valid_rule & 1) == 0 ? (mf == 1.0f) : (m > 0.99);     // flow_class.py:668 / :1410
     }
 }
 
@@ -859,7 +859,7 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_linear: sign must be +1 or -1");
     if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad point_precision");
     if (point_precision == 1) sign *= 2;
-    if (valid_rule != 0 && valid_rule != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
+    if (valid_rule & ~(1 | OFL_SCATTER_ROUND)) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
     hipStream_t s = stream_of(stream);
     ScatterWs ws;
     HullRef hull;
@@ -882,7 +882,7 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
     if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_rows: sign must be +1 or -1");
     if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_rows: bad point_precision");
     if (point_precision == 1) sign *= 2;
-    if (valid_rule != 0 && valid_rule != 1) return fail(OFL_E_INVALID, "ofl_scatter_rows: bad valid_rule");
+    if (valid_rule & ~(1 | OFL_SCATTER_ROUND)) return fail(OFL_E_INVALID, "ofl_scatter_rows: bad valid_rule");
     if (H <= 0 || W <= 0 || row0 < 0 || rows <= 0 || row0 + rows > H)
         return fail(OFL_E_INVALID, "ofl_scatter_rows: rows [%d, %d) outside the %d-row grid", row0, row0 + rows, H);
     hipStream_t s = stream_of(stream);

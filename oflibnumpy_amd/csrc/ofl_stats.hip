@@ -182,6 +182,15 @@ void mask_and_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ 
     }
 }
 
+// element-wise dtype conversion (the casts NumPy performs around griddata, utils.py:253 / :258)
+template <typename S, typename D>
+__global__ __launch_bounds__(256)
+void convert_kernel(const S *__restrict__ src, D *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (D)src[i];
+}
+
 // out = float32(grid +- vecs): NumPy adds the int64 grid to the float32 array in float64 and rounds once
 __global__ __launch_bounds__(256)
 void grid_offset_kernel(const float *__restrict__ vecs, int sign, int H, int W, float *__restrict__ out)
@@ -231,6 +240,12 @@ int stream_grid(size_t n_items)
     const size_t per_cu = env ? (size_t)atoi(env) : 0;
     const size_t cap = per_cu ? (size_t)rt().n_cu * per_cu : (size_t)0x7fffffff;
     return (int)(nb < cap ? nb : cap);
+}
+
+template <typename S, typename D>
+void launch_convert(const void *src, void *dst, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL((convert_kernel<S, D>), dim3(stream_grid(n)), dim3(256), 0, s, (const S *)src, (D *)dst, n);
 }
 
 }  // namespace
@@ -318,6 +333,36 @@ int ofl_flow_extent_dev(const float *vecs, const uint8_t *mask, int H, int W, in
     const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);          // <= 4096 wave atomics per slot
     hipLaunchKernelGGL(flow_extent_kernel, dim3(grid), dim3(256), 0, s, vecs, mask, H, W, sign, threshold, ext);
     hipLaunchKernelGGL(flow_extent_finish_kernel, dim3(1), dim3(64), 0, s, ext);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_convert_dev(const void *src, int src_dtype, void *dst, int dst_dtype, size_t n, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!src || !dst) return fail(OFL_E_INVALID, "ofl_convert: NULL pointer");
+    if (n == 0) return OFL_OK;
+    hipStream_t s = stream_of(stream);
+    if (dst_dtype == OFL_F32) {
+        switch (src_dtype) {
+        case OFL_U8:  launch_convert<uint8_t, float>(src, dst, n, s); break;
+        case OFL_I16: launch_convert<int16_t, float>(src, dst, n, s); break;
+        case OFL_U16: launch_convert<uint16_t, float>(src, dst, n, s); break;
+        case OFL_F32: launch_convert<float, float>(src, dst, n, s); break;
+        case OFL_F64: launch_convert<double, float>(src, dst, n, s); break;
+        default: return fail(OFL_E_INVALID, "ofl_convert: unsupported source dtype %d", src_dtype);
+        }
+    } else if (src_dtype == OFL_F32) {
+        switch (dst_dtype) {
+        case OFL_U8:  launch_convert<float, uint8_t>(src, dst, n, s); break;
+        case OFL_I16: launch_convert<float, int16_t>(src, dst, n, s); break;
+        case OFL_U16: launch_convert<float, uint16_t>(src, dst, n, s); break;
+        case OFL_F64: launch_convert<float, double>(src, dst, n, s); break;
+        default: return fail(OFL_E_INVALID, "ofl_convert: unsupported destination dtype %d", dst_dtype);
+        }
+    } else {
+        return fail(OFL_E_INVALID, "ofl_convert: one side must be OFL_F32");
+    }
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

@@ -571,21 +571,33 @@ def scatter_rows(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, 
 
 
 def scatter_host(flow, target, pmask, vmask=None):
-    """apply_flow(flow, target, 's', mask) for host arrays (utils.py:237-258): target (H, W, C) of any numeric
+    """apply_flow(flow, target, 's', mask) for host arrays (utils.py:237-258; `flow` may already be a DeviceBuffer
+    holding the float32 vectors): target (H, W, C) of any numeric
     dtype is interpolated in float32/float64 on the device, then rounded / cast back like the reference.
     Returns (warped, valid or None); valid = float32(interpolated vmask) == 1 (flow_class.py:668)."""
     h, w, C = target.shape
-    fbuf = DeviceBuffer.from_host(np.ascontiguousarray(flow, np.float32))
-    vals = DeviceBuffer.from_host(np.ascontiguousarray(target, np.float32))
-    pm = DeviceBuffer.from_host(np.ascontiguousarray(pmask).astype(np.uint8)) if pmask is not None else None
-    vm = DeviceBuffer.from_host(np.ascontiguousarray(vmask).astype(np.uint8)) if vmask is not None else None
-    out = DeviceBuffer(h * w * C * 4)
+    n = h * w * C
+    fbuf = flow if isinstance(flow, DeviceBuffer) else DeviceBuffer.from_host(np.ascontiguousarray(flow, np.float32))
+    as_mask = lambda m: np.ascontiguousarray(m).view(np.uint8) if m.dtype == np.bool_ else np.ascontiguousarray(m).astype(np.uint8)
+    pm = DeviceBuffer.from_host(as_mask(pmask)) if pmask is not None else None
+    vm = DeviceBuffer.from_host(as_mask(vmask)) if vmask is not None else None
+    native = target.dtype in _DT_CODE and target.dtype != np.float32         # the casts of utils.py:253 / :258 run on the device
+    integer = np.issubdtype(target.dtype, np.integer)
+    if native:
+        raw = DeviceBuffer.from_host(np.ascontiguousarray(target))
+        vals = DeviceBuffer(n * 4)
+        nat.check(_lib().ofl_convert_dev(raw.ptr, _DT_CODE[target.dtype], vals.ptr, nat.F32, n, None))
+    else:
+        vals = DeviceBuffer.from_host(np.ascontiguousarray(target, np.float32))
+    out = DeviceBuffer(n * 4)
     valid = DeviceBuffer(h * w) if vmask is not None else None
-    scatter_linear(fbuf, +1, pm, vals, C, vm, h, w, None, out, valid, 0)
-    res = out.to_host((h, w, C), np.float32)
-    if np.issubdtype(target.dtype, np.integer):
-        res = np.round(res)
-    res = res.astype(target.dtype)
+    scatter_linear(fbuf, +1, pm, vals, C, vm, h, w, None, out, valid, nat.SCATTER_ROUND if integer else 0)
+    if native:
+        back = DeviceBuffer(n * target.dtype.itemsize)
+        nat.check(_lib().ofl_convert_dev(out.ptr, nat.F32, back.ptr, _DT_CODE[target.dtype], n, None))
+        res = back.to_host((h, w, C), target.dtype)
+    else:
+        res = out.to_host((h, w, C), np.float32).astype(target.dtype)       # already rounded for integer targets
     v = valid.to_host((h, w), np.uint8).view(np.bool_) if valid is not None else None
     return res, v
 

@@ -338,9 +338,10 @@ class Flow(object):
         flow = self if padding is None else self.pad(padding, mode='edge')
         if with_mask:
             tmask = tmask.astype(bool) & flow._mask                  # flow_class.py:636-643
-        if is_zero_flow(flow._vecs, thresholded=True):
-            return t, (tmask.copy() if with_mask else None)
-        return dev.scatter_host(flow._vecs, t, flow._mask if consider_mask else None,
+        fbuf = dev.DeviceBuffer.from_host(flow._vecs)           # uploaded once: zero test and scatter share it
+        if not (dev.flow_stats(fbuf, None, flow.shape[0] * flow.shape[1]) & nat.STAT_NONZERO_TH):
+            return t, (tmask.copy() if with_mask else None)        # identity short cut, utils.py:215-216
+        return dev.scatter_host(fbuf, t, flow._mask if consider_mask else None,
                                 vmask=tmask if with_mask else None)
 
     def switch_ref(self, mode: str = None) -> FlowAlias:

@@ -272,7 +272,7 @@ def apply_flow(flow: nd, target: nd, ref: str, mask: nd = None, quant: int = Non
         if target.ndim == 2:
             result = result[:, :, 0]
     else:
-        result, _ = dev.scatter_host(flow, target if target.ndim == 3 else target[..., np.newaxis], mask)
+        result, _ = dev.scatter_host(fbuf, target if target.ndim == 3 else target[..., np.newaxis], mask)
         if target.ndim == 2:
             result = result[:, :, 0]
     if result.shape != target.shape:

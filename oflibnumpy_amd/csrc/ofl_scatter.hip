@@ -38,7 +38,8 @@ constexpr int      kSmallArea = 1024;                             // bbox nodes 
 #define OFL_SC_COOP 1
 #endif
 constexpr int      kCoopMinArea = 64;                             // smallest bbox a whole wave scans together
-constexpr int      kBigCap    = 1 << 20;                          // capacity of the big-triangle list
+// the big-triangle list holds every triangle of the mesh if need be (a field that magnifies 30x makes ALL of them big)
+inline long long big_cap_for(int H, int W) { return 2ll * (H > 1 ? H - 1 : 1) * (W > 1 ? W - 1 : 1); }
 constexpr int      kCandCap   = 1 << 22;                          // hull candidates kept on the device
 constexpr int      kHullCap   = 1 << 16;                          // vertices per hull chain
 constexpr int      kFillRadius = 16;                              // how far an uncovered node looks for a covered one
@@ -48,7 +49,8 @@ struct D2 { double x, y; };
 
 struct ScatterWs {          // layout of the caller-provided workspace
     uint32_t *owner;        // [H][W]
-    uint32_t *big;          // [kBigCap] triangle ids
+    uint32_t *big;          // [big_cap] triangle ids
+    unsigned long long big_cap;
     D2       *cand;         // [cand_cap] positions of mesh-boundary points (convex-hull candidates)
     D2       *lower;        // [kHullCap] lower hull chain, x ascending
     D2       *upper;        // [kHullCap] upper hull chain, x ascending
@@ -379,7 +381,7 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
         if (area > kSmallArea) {
             const unsigned long long slot = atomicAdd(&ws.counters[1], 1ull);
             atomicAdd(&ws.counters[2], (unsigned long long)area);
-            if (slot < (unsigned long long)kBigCap) ws.big[slot] = id;
+            if (slot < ws.big_cap) ws.big[slot] = id;
             continue;
         }
         // Load balance inside the wave: a lane whose bounding box is much larger than its neighbours' (motion
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256)
 void scatter_big_kernel(const float *__restrict__ flow, int sign, int H, int W, ScatterWs ws)
 {
     unsigned long long n = ws.counters[1];
-    if (n > (unsigned long long)kBigCap) n = kBigCap;
+    if (n > ws.big_cap) n = ws.big_cap;
     const int lane = threadIdx.x & 63;
     for (unsigned long long k = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6); k < n;
          k += (unsigned long long)gridDim.x * 4) {
@@ -660,7 +662,8 @@ ScatterWs carve(void *workspace, int H, int W)
     ws.cand = (D2 *)p;                       p += align_up((size_t)ws.cand_cap * sizeof(D2), 256);
     ws.lower = (D2 *)p;                      p += (size_t)kHullCap * sizeof(D2);      // lower | upper contiguous:
     ws.upper = (D2 *)p;                      p += (size_t)kHullCap * sizeof(D2);      // ONE upload
-    ws.big = (uint32_t *)p;                  p += align_up((size_t)kBigCap * 4, 256);
+    ws.big_cap = (unsigned long long)big_cap_for(H, W);
+    ws.big = (uint32_t *)p;                  p += align_up((size_t)ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;
     ws.oy0 = 0;
     ws.oy1 = H;
@@ -750,7 +753,7 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
     if (!bytes) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: NULL");
     if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: bad shape");
     *bytes = kHeadBytes + align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * (size_t)kHullCap * sizeof(D2) +
-             align_up((size_t)kBigCap * 4, 256) + align_up((size_t)H * W * 4, 256);
+             align_up((size_t)big_cap_for(H, W) * 4, 256) + align_up((size_t)H * W * 4, 256);
     return OFL_OK;
 }
 
@@ -814,8 +817,8 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
         info_host[2] = c[2];
     }
     if (pmask && c[0] == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
-    if (c[1] > (unsigned long long)kBigCap)
-        return fail(OFL_E_INVALID, "ofl_scatter_linear: %llu triangles exceed the large-triangle list (%d): flow too irregular", c[1], kBigCap);
+    if (c[1] > ws.big_cap)      // cannot happen: the list holds every triangle of the mesh
+        return fail(OFL_E_INVALID, "ofl_scatter_linear: %llu large triangles exceed the list (%llu)", c[1], ws.big_cap);
     hull = HullRef{ ws.lower, ws.upper, 0, 0 };
     if (c[3] >= 3 && c[3] <= (unsigned long long)ws.cand_cap) {
         std::vector<D2> pts((size_t)c[3]), lower, upper;

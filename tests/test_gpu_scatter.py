@@ -477,3 +477,17 @@ def test_scatter_row_bands_equal_full_result(gpu):
             np.testing.assert_array_equal(np.concatenate(parts), full, err_msg=name)
             np.testing.assert_array_equal(np.concatenate(vparts), fullv, err_msg=name)
         assert fullv.mean() > 0.2, name
+
+
+def test_strong_magnification_all_triangles_large(gpu):
+    """A field that magnifies 40x turns EVERY cell triangle into a large one (bounding boxes of ~1 700 nodes): 2.4
+    million of them at 1100 x 1100, more than any fixed-size list -- the large-triangle list is sized for the whole
+    mesh.  The inverse of the scaling is the scaling by 1/40 (analytic, as reference tests/test_flow_class.py:528-572)."""
+    of = gpu
+    s = (1100, 1100)
+    f = of.Flow.from_transforms([['scaling', 550, 550, 40.0]], s, 's')
+    inv = f.invert()
+    want = of.Flow.from_transforms([['scaling', 550, 550, 1 / 40.0]], s, 's')
+    assert inv.mask.mean() > 0.99
+    np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-3, atol=1e-3)
+    assert f.valid_target().mean() > 0.99

@@ -56,6 +56,8 @@ struct ScatterWs {          // layout of the caller-provided workspace
     D2       *upper;        // [kHullCap] upper hull chain, x ascending
     unsigned long long *counters;   // [1] big-list length, [2] big-list work, [3] candidates
     unsigned long long *kept_slots; // [256] partial counts of kept points
+    const D2 *guard;        // [4] warped kept points next to the four image corners (header bytes 64..127) ...
+    const int *guard_ok;    // ... and whether all four exist (header byte 128)
     int       cand_cap;
     int       oy0, oy1;     // rows [oy0, oy1) the owner map covers (0, H unless one row band is computed);
                             // `owner` is biased so that owner[y * W + x] addresses row y for y in that range
@@ -304,15 +306,45 @@ __device__ __forceinline__ void hull_candidate(const float *__restrict__ flow, i
                     }
                 }
             } else if (!on_border) {
-                if (kept(0, 0) && kept(W - 1, 0) && kept(0, H - 1) && kept(W - 1, H - 1)) {
-                    const D2 ga = point_of(flow, sign, W, 0, 0), gb = point_of(flow, sign, W, W - 1, 0);
-                    const D2 gc = point_of(flow, sign, W, W - 1, H - 1), gd = point_of(flow, sign, W, 0, H - 1);
+                if (*ws.guard_ok) {
+                    const D2 ga = ws.guard[0], gb = ws.guard[1], gc = ws.guard[2], gd = ws.guard[3];
                     if (strictly_inside(ga, gb, gc, p) || strictly_inside(ga, gc, gd, p)) cand = false;
                 }
             }
         }
         push_candidate(ws, cand, p);
     }
+}
+
+// Pass 0 (one workgroup): the four guard points of the candidate filters -- for every image corner the kept point
+// closest to it (Chebyshev distance, then row-major order) inside the 16 x 16 block at that corner.  With a random
+// point mask an image corner itself is often dropped; its neighbour serves just as well.
+__global__ __launch_bounds__(256)
+void scatter_guard_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                          D2 *__restrict__ guard, int *__restrict__ guard_ok)
+{
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;            // corner 0..3 = (0,0) (W-1,0) (W-1,H-1) (0,H-1)
+    const bool right = (k == 1 || k == 2), bottom = (k >= 2);
+    uint32_t best = 0xffffffffu;
+    for (int j = lane; j < 256; j += 64) {
+        const int dx = j & 15, dy = j >> 4;
+        if (dx >= W || dy >= H) continue;
+        const int x = right ? W - 1 - dx : dx, y = bottom ? H - 1 - dy : dy;
+        if (pmask && !pmask[(size_t)y * W + x]) continue;
+        best = min(best, ((uint32_t)max(dx, dy) << 16) | (uint32_t)j);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off));
+    if (lane == 0) {
+        if (best != 0xffffffffu) {
+            const int j = (int)(best & 0xffffu), dx = j & 15, dy = j >> 4;
+            guard[k] = point_of(flow, sign, W, right ? W - 1 - dx : dx, bottom ? H - 1 - dy : dy);
+            atomicAdd(guard_ok, 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *guard_ok = (__hip_atomic_load(guard_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256)
@@ -349,15 +381,12 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
     // a cell that is not properly oriented (folded mesh) can push interior points onto the convex hull
     // of the point set: its corners become hull candidates (duplicates are harmless)
     // (a point strictly inside a triangle of kept points is never a hull vertex: corners inside the two
-    // triangles of the four warped image corners are dropped -- motion boundaries fold thousands of cells
-    // far away from the hull)
+    // triangles of the four guard points -- the kept points next to the image corners -- are dropped: motion
+    // boundaries fold thousands of cells far away from the hull)
     if (!(cross2(pa, pb, pc) > 0 && cross2(pa, pc, pd) > 0 && cross2(pb, pc, pd) > 0 && cross2(pb, pd, pa) > 0)) {
-        const bool guard = !pmask || (pmask[0] && pmask[W - 1] && pmask[(size_t)(H - 1) * W] && pmask[(size_t)H * W - 1]);
+        const bool guard = *ws.guard_ok != 0;
         D2 ga = { 0.0, 0.0 }, gb = ga, gc = ga, gd = ga;
-        if (guard) {
-            ga = point_of(flow, sign, W, 0, 0);         gb = point_of(flow, sign, W, W - 1, 0);
-            gc = point_of(flow, sign, W, W - 1, H - 1); gd = point_of(flow, sign, W, 0, H - 1);
-        }
+        if (guard) { ga = ws.guard[0]; gb = ws.guard[1]; gc = ws.guard[2]; gd = ws.guard[3]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const D2 p = pick4(k, pa, pb, pc, pd);
@@ -657,7 +686,10 @@ ScatterWs carve(void *workspace, int H, int W)
     ScatterWs ws;
     char *p = (char *)workspace;
     ws.cand_cap = cand_cap_for(H, W);
-    ws.counters = (unsigned long long *)p;   p += 256;                 // header, slots and candidates are
+    ws.counters = (unsigned long long *)p;                              // header, slots and candidates are
+    ws.guard = (const D2 *)(p + 64);
+    ws.guard_ok = (const int *)(p + 128);
+    p += 256;
     ws.kept_slots = (unsigned long long *)p; p += 256 * sizeof(unsigned long long);   // contiguous: ONE read-back
     ws.cand = (D2 *)p;                       p += align_up((size_t)ws.cand_cap * sizeof(D2), 256);
     ws.lower = (D2 *)p;                      p += (size_t)kHullCap * sizeof(D2);      // lower | upper contiguous:
@@ -782,6 +814,7 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
     ws.owner -= (size_t)oy0 * W;         // biased base: owner[y * W + x] is row y of the covered range
     OFL_HIP(hipMemsetAsync(ws.counters, 0, kHeadBytes, s));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
+    hipLaunchKernelGGL(scatter_guard_kernel, dim3(1), block, 0, s, flow, sign, pmask, H, W, (D2 *)ws.guard, (int *)ws.guard_ok);
     hipLaunchKernelGGL(scatter_raster_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
     OFL_HIP(hipGetLastError());
     // the big-triangle list is usually empty; its length lives on the device, so the sweep kernel is

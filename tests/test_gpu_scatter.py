@@ -491,3 +491,34 @@ def test_strong_magnification_all_triangles_large(gpu):
     assert inv.mask.mean() > 0.99
     np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-3, atol=1e-3)
     assert f.valid_target().mean() > 0.99
+
+
+def test_speckled_mask_with_dropped_corners(gpu, oracle):
+    """A random point mask often drops an image corner; the candidate filters then take the kept points next to the
+    corners as guards.  Validity masks equal SciPy's bit for bit and flow-valued results agree inside the mask; the
+    4K case checks that the convex-hull work stays on the device (it took 50 ms on the host without guards)."""
+    import time
+    of, O = gpu, oracle
+    rng = np.random.default_rng(17)
+    shape = (60, 84)
+    for tr in ([['rotation', 30, 40, 25]], [['scaling', 20, 30, 0.8]]):
+        m = rng.random(shape) > 0.1
+        m[0, 0] = m[0, -1] = m[-1, 0] = m[-1, -1] = False
+        m[1, 0] = m[0, 1] = False
+        f = of.Flow.from_transforms(tr, shape, 's', m)
+        o = O.OFlow(f.vecs, 's', m)
+        np.testing.assert_array_equal(f.valid_target(), o.valid_target())
+        got, want = f.invert(), o.invert()
+        np.testing.assert_array_equal(got.mask, want.mask)
+        np.testing.assert_allclose(got.vecs[got.mask], want.vecs[got.mask], rtol=1e-4, atol=1e-4)
+    h, w = 2160, 3840
+    m = rng.random((h, w)) > 0.05
+    m[0, 0] = m[-1, -1] = False
+    d = of.Flow.from_transforms([['rotation', 1920, 1080, -20], ['scaling', 1000, 800, 0.9]], [h, w], 's', m).to_device()
+    d.stats()
+    d.invert()
+    t0 = time.perf_counter()
+    r = d.invert()
+    of.native.check(of.native.load().ofl_device_sync())
+    assert time.perf_counter() - t0 < 0.02, "hull candidates were not filtered on the device"
+    assert r.to_host()[1].mean() > 0.5

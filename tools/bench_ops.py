@@ -95,6 +95,12 @@ def main():
         t = timed(lambda: dd.invert(), it)
         report("invert s->s, {} (K3)".format(name), (h, w), 18, *t, note="discontinuous field")
     del yy, xx, obj, stripes
+    spk = np.random.default_rng(0).random((h, w)) > 0.05
+    spk[0, 0] = False
+    ds = dev.DeviceFlow.from_host(f3.vecs, 's', spk)
+    ds.stats()
+    t = timed(lambda: ds.invert(), it)
+    report("invert s->s, 5 % random invalid points incl. a corner (K3)", (h, w), 18, *t, note="points dropped (consider_mask), gaps filled")
 
     # K6: Flow.resize of the 4K field: 9 B per source px read + 9 B per output px written
     for scale in (0.5, 2, 1.5):

@@ -279,7 +279,18 @@ class DeviceFlow:
         return self._axpy(other, -1.0)
 
     def __neg__(self):
-        return self._axpy(None, -1.0)
+        out = self._axpy(None, -1.0)
+        out._stats = self._stats            # the zero-flow predicates do not change under negation
+        return out
+
+    def _compose(self, sampled, sign, quant=nat.QUANT_OPENCV):
+        """self + B(sampled; x + sign * self) with the masks of a warp followed by an addition: ONE launch of the
+        fused compose kernel.  This is `g + g.apply(sampled)` for a 't'-reference g (sign -1) and
+        `a + (-a as 't').apply(sampled)` for an 's'-reference a (sign +1) -- the expressions inside mode 1
+        (flow_class.py:1369-1370, 1383-1385) -- bit for bit."""
+        out = DeviceFlow.empty(self.shape, self.ref)
+        compose3_launch(sampled, self, sign, out, quant=quant)
+        return out
 
     # -- warping
     def apply(self, target, consider_mask=True, quant=nat.QUANT_OPENCV, target_mask=None):
@@ -289,7 +300,10 @@ class DeviceFlow:
         if isinstance(target, DeviceImage):
             return self.apply_image(target, target_mask, consider_mask, quant)
         if self.ref == 't':
-            if self.is_zero(thresholded=True, masked=False):          # utils.py:215-216
+            # utils.py:215-216: a (thresholded-)zero flow returns the target itself.  Under cv2's 1/32-px coordinate
+            # snapping the gather of such a flow IS the identity (|v| < 1e-3 snaps to 0), so the test -- a
+            # reduction and a host synchronisation -- is only needed for the un-snapped extension mode
+            if quant != nat.QUANT_OPENCV and self.is_zero(thresholded=True, masked=False):
                 return target._and_mask(self)
             src = DeviceImage(target.vecs, self.shape + (2,), np.float32)
             dst, valid = gather_bilinear(src, self.vecs, self.shape, -1, smask=target.mask, fmask=self.mask,
@@ -399,9 +413,9 @@ class DeviceFlow:
         if mode == 1:
             if s:                                                            # flow_class.py:1369-1370
                 g = flow.invert('t')
-                return flow - (g + g.apply(self.switch_ref())).apply(self)
+                return flow - g._compose(self.switch_ref(), -1, quant).apply(self)       # g + g.apply(..), fused
             a = self.switch_ref()                                            # flow_class.py:1383-1385
-            res = flow.switch_ref() - (a + a.invert(ref='t').apply(flow.invert('s'))).apply(a)
+            res = flow.switch_ref() - a._compose(flow.invert('s'), +1, quant).apply(a)  # a + (-a).apply(..), fused
             return res.switch_ref()
         if s:
             return self.apply(flow - self)                                   # flow_class.py:1390

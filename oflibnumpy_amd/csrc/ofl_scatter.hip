@@ -32,6 +32,7 @@ using namespace ofl;
 namespace {
 
 constexpr uint32_t kNoOwner   = 0xFFFFFFFFu;
+constexpr uint32_t kGapOwner  = 0xFFFFFFFEu;                     // owner-map marker: uncovered node inside the hull (pass 2b)
 constexpr double   kEps       = 100.0 * 2.220446049250313e-16;   // scipy _qhull: eps = 100 * DBL_EPSILON
 constexpr int      kSmallArea = 1024;                             // bbox nodes scanned inside the raster kernel (lane or wave)
 #ifndef OFL_SC_COOP
@@ -495,7 +496,7 @@ __device__ __forceinline__ uint32_t nearest_owner(const uint32_t *owner, int y_l
                 const int xx = cx + dx;
                 if (xx < 0 || xx >= W) continue;
                 const uint32_t id = owner[(size_t)yy * W + xx];
-                if (id == kNoOwner) continue;
+                if (id >= kGapOwner) continue;
                 const double d = (xx - qx) * (xx - qx) + (yy - qy) * (yy - qy);
                 if (d < bestd || (d == bestd && id < best)) { bestd = d; best = id; }
             }
@@ -615,48 +616,11 @@ void scatter_query_kernel(const float *__restrict__ flow, int sign, const uint8_
     }
 }
 
-// pass 2: interpolate.  query == NULL: node (x, y) itself; otherwise the triangle containing the
-// query point is searched in the 3 x 3 cells around the owner of the nearest node.
-__global__ __launch_bounds__(256)
-void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
-                            const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
-                            int H, int W, const float *__restrict__ query,
-                            float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, ScatterWs ws,
-                            HullRef hull, int row0, int rows)
+// values and validity of one output element from its triangle (vi) and barycentric coordinates
+__device__ __forceinline__ void resolve_emit(const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                                             const size_t (&vi)[3], double c0, double c1, double c2, int valid_rule,
+                                             float *__restrict__ out, uint8_t *__restrict__ valid, size_t o)
 {
-    // rows [row0, row0 + rows) of the grid are resolved; out / valid / query hold those rows only
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
-    if (x >= W || yl >= rows) return;
-    const size_t o = (size_t)yl * W + x;
-    double qx = x, qy = y;
-    uint32_t id = kNoOwner;
-    size_t vi[3];
-    D2 vp[3];
-    double c0 = 0, c1 = 0, c2 = 0;
-    bool found = false;
-    if (!query) {
-        id = ws.owner[(size_t)y * W + x];
-        if (id != kNoOwner) {      // the raster pass decided containment; only the coordinates are needed
-            tri_decode(id, flow, sign, W, vi, vp);
-            (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
-            found = true;
-        }
-    } else {
-        const float2 q = *reinterpret_cast<const float2 *>(query + o * 2);
-        qx = (double)q.x; qy = (double)q.y;
-        found = locate_query(flow, sign, pmask, H, W, ws, qx, qy, id, vi, vp, c0, c1, c2);
-    }
-    // Inside the convex hull of the kept points but not covered by a cell triangle: SciPy's Delaunay
-    // triangulation spans such gaps (ragged / curved mesh borders, holes left by dropped points) with
-    // triangles between border vertices.  The linear function of the nearest cell triangle is
-    // continued instead -- identical for data that is affine across the gap.
-    if (!found) found = fill_from_nearest(flow, sign, H, W, ws, hull, qx, qy, id, vi, vp, c0, c1, c2);
-    if (!found) {
-        for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;          // NaN -> 0, utils.py:254 / fill_value=0
-        if (valid) valid[o] = 0;
-        return;
-    }
     for (int c = 0; c < C; ++c) {
         const double v = c0 * (double)vals[vi[0] * C + c] + c1 * (double)vals[vi[1] * C + c] + c2 * (double)vals[vi[2] * C + c];
         out[o * C + c] = (float)((valid_rule & OFL_SCATTER_ROUND) ? rint(v) : v);      // np.round of the float64 result, utils.py:256-257
@@ -668,6 +632,91 @@ void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint
         const float mf = (float)m;                                   // result.astype(target.dtype), utils.py:258
         valid[o] = (valid_rule & 1) == 0 ? (mf == 1.0f) : (m > 0.99);     // flow_class.py:668 / :1410
     }
+}
+
+// pass 2, grid nodes: node (x, y) takes the triangle the raster pass recorded for it.  Nodes without an owner are
+// zero / invalid (NaN -> 0, utils.py:254) -- unless they lie inside the convex hull of the kept points: SciPy's
+// Delaunay triangulation spans such gaps (ragged / curved mesh borders, holes left by dropped points) with
+// triangles between border vertices; those nodes are queued for pass 2b, which continues the linear function of
+// the nearest cell triangle into them (identical for data that is affine across the gap).  Keeping the rare search
+// out of this kernel keeps it at 8 waves per SIMD.
+__global__ __launch_bounds__(256)
+void scatter_resolve_grid_kernel(const float *__restrict__ flow, int sign,
+                                 const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                                 int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
+                                 ScatterWs ws, HullRef hull, int row0, int rows)
+{
+    // rows [row0, row0 + rows) of the grid are resolved; out / valid hold those rows only
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
+    const bool act = x < W && yl < rows;
+    const size_t o = (size_t)yl * W + x;
+    const uint32_t id = act ? ws.owner[(size_t)y * W + x] : 0u;
+    bool gap = false;
+    if (act) {
+        if (id != kNoOwner) {      // the raster pass decided containment; only the coordinates are needed
+            size_t vi[3];
+            D2 vp[3];
+            double c0, c1, c2;
+            tri_decode(id, flow, sign, W, vi, vp);
+            (void)bary(vp[0], vp[1], vp[2], (double)x, (double)y, c0, c1, c2);
+            resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
+        } else {
+            for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;
+            if (valid) valid[o] = 0;
+            gap = hull.n_lower > 0 && inside_hull(hull, (double)x, (double)y);
+        }
+    }
+    // gap nodes are MARKED in the owner map (a plain store: a counter bumped by every wave that holds one serialises
+    // at ~12 ns per atomic -- 1.5 ms with a speckled mask); pass 2b scans the map for the marks
+    if (gap) ws.owner[(size_t)y * W + x] = kGapOwner;
+}
+
+// pass 2b: the marked gap nodes
+__global__ __launch_bounds__(256)
+void scatter_gap_kernel(const float *__restrict__ flow, int sign,
+                        const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                        int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
+                        ScatterWs ws, HullRef hull, int row0, int rows)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
+    if (x >= W || yl >= rows || ws.owner[(size_t)y * W + x] != kGapOwner) return;
+    uint32_t id;
+    size_t vi[3];
+    D2 vp[3];
+    double c0, c1, c2;
+    if (fill_from_nearest(flow, sign, H, W, ws, hull, (double)x, (double)y, id, vi, vp, c0, c1, c2))
+        resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, (size_t)yl * W + x);
+}
+
+// pass 2 for arbitrary sample positions (query != NULL; mode 2 / ref 't', flow_class.py:1398-1410): the triangle
+// containing the query point is searched in the 3 x 3 cells around the owner of the nearest node.
+__global__ __launch_bounds__(256)
+void scatter_resolve_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask,
+                            const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                            int H, int W, const float *__restrict__ query,
+                            float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, ScatterWs ws,
+                            HullRef hull)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const size_t o = (size_t)y * W + x;
+    uint32_t id = kNoOwner;
+    size_t vi[3];
+    D2 vp[3];
+    double c0 = 0, c1 = 0, c2 = 0;
+    const float2 q = *reinterpret_cast<const float2 *>(query + o * 2);
+    const double qx = (double)q.x, qy = (double)q.y;
+    bool found = locate_query(flow, sign, pmask, H, W, ws, qx, qy, id, vi, vp, c0, c1, c2);
+    if (!found) found = fill_from_nearest(flow, sign, H, W, ws, hull, qx, qy, id, vi, vp, c0, c1, c2);      // gap fill, see above
+    if (!found) {
+        for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;          // NaN -> 0, utils.py:254 / fill_value=0
+        if (valid) valid[o] = 0;
+        return;
+    }
+    resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -901,8 +950,16 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     HullRef hull;
     OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
-    hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
-                       out, valid, valid_rule, ws, hull, 0, H);
+    if (query) {
+        hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
+                           out, valid, valid_rule, ws, hull);
+    } else {
+        hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                           out, valid, valid_rule, ws, hull, 0, H);
+        if (hull.n_lower > 0)
+            hipLaunchKernelGGL(scatter_gap_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                               out, valid, valid_rule, ws, hull, 0, H);
+    }
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }
@@ -928,8 +985,11 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
     const int oy0 = std::max(0, row0 - kFillRadius), oy1 = std::min(H, row0 + rows + kFillRadius);
     OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull, oy0, oy1));
     const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
-    hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, (const float *)nullptr,
+    hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                        out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
+    if (hull.n_lower > 0)
+        hipLaunchKernelGGL(scatter_gap_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                           out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

@@ -668,3 +668,35 @@ def test_is_zero_and_get_padding_on_device(gpu, oracle):
             exp = [max(-np.min(t[msk, 1]), 0), max(np.max(t[msk, 1]) - (shape[0] - 1), 0),
                    max(-np.min(t[msk, 0]), 0), max(np.max(t[msk, 0]) - (shape[1] - 1), 0)]
             assert fl.get_padding() == [int(np.ceil(p)) for p in exp]
+
+
+def test_c_abi_rejects_bad_arguments(gpu):
+    """Every entry validates its arguments on the host and returns OFL_E_INVALID (-1) with a message instead of
+    launching a kernel on mismatched shapes (a faulting kernel can take the whole node down)."""
+    import ctypes
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    nat = of.native
+    lib = nat.load()
+    n = 64 * 64
+    buf = dev.DeviceBuffer(n * 16)
+    m = dev.DeviceBuffer(n)
+    p, q = buf.ptr, m.ptr
+    INVALID = -1
+    assert lib.ofl_compose3_dev(p, q, p, q, -1, 0, 64, 1, p, q, None, 0, None) == INVALID
+    assert lib.ofl_compose3_dev(p, q, p, q, 2, 64, 64, 1, p, q, None, 0, None) == INVALID
+    assert lib.ofl_compose3_dev(None, q, p, q, -1, 64, 64, 1, p, q, None, 0, None) == INVALID
+    assert lib.ofl_gather_bilinear_dev(p, nat.F32, 1, 64, 64, p, 64, 64, 1, 0, -1, None, None, p, None, 0, 0, 0, None) == INVALID   # flow does not fit
+    assert lib.ofl_gather_bilinear_dev(p, 9, 1, 64, 64, p, 64, 64, 0, 0, -1, None, None, p, None, 0, 0, 0, None) == INVALID       # dtype
+    assert lib.ofl_gather_bilinear_dev(p, nat.F32, 1, 40000, 64, p, 64, 64, 0, 0, -1, None, None, p, None, 0, 0, 0, None) == INVALID  # > int16 coordinates
+    assert lib.ofl_gather_rows_dev(p, nat.F32, 1, 64, 64, 60, 8, p, -1, None, None, p, None, 0, 0, 0, None) == INVALID
+    assert lib.ofl_scatter_linear_dev(p, 1, 0, None, p, 2, None, 64, 64, None, p, q, 0, p, 16, None, None) == INVALID              # workspace too small
+    assert lib.ofl_scatter_linear_dev(p, 1, 0, None, p, 2, None, 64, 64, None, p, q, 7, p, n * 16, None, None) == INVALID          # valid_rule
+    assert lib.ofl_scatter_rows_dev(p, 1, 0, None, p, 2, None, 64, 64, 60, 8, p, q, 0, p, n * 16, None, None) == INVALID
+    assert lib.ofl_resize_flow_dev(p, q, 64, 64, 32, 32, 2.0, 2.0, 0.5, 0.5, p, None, None) == INVALID                              # mask without mout
+    assert lib.ofl_resize_flow_dev(p, None, 64, 64, 0, 32, 2.0, 2.0, 0.5, 0.5, p, None, None) == INVALID
+    assert lib.ofl_convert_dev(p, nat.U8, p, nat.I16, n, None) == INVALID
+    assert lib.ofl_flow_extent_dev(p, None, 64, 64, 0, 1e-3, p, None) == INVALID
+    assert b"ofl_flow_extent" in lib.ofl_last_error()
+    with pytest.raises(RuntimeError):
+        nat.check(lib.ofl_axpy_dev(None, None, None, None, 1.0, n, None, None, None))

@@ -29,6 +29,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
 
 PATTERN = "scale"
+ANGLE = -30.0
 
 
 def make_pair(of, h, w, ref, variant):
@@ -37,7 +38,7 @@ def make_pair(of, h, w, ref, variant):
     SAMPLING field looks like: "scale" (the config: f2 = scaling 0.8, 36 % of the samples fall outside),
     "shift" (f2 = 3.3 px translation: streaming-friendly gather) or "rot" (f1 and f2 swapped: samples lie
     on a grid rotated by 30 degrees)."""
-    ang = -30.0 + 0.5 * variant
+    ang = ANGLE + 0.5 * variant
     sc = 0.8 + 0.005 * variant
     f1 = of.Flow.from_transforms([['rotation', w / 2.0, h / 2.0, ang]], [h, w], ref)
     f2 = of.Flow.from_transforms([['scaling', w * 400.0 / 1920.0, h * 300.0 / 1080.0, sc]], [h, w], ref)
@@ -88,10 +89,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pattern", default="scale", choices=["scale", "shift", "rot"],
                     help="sampling pattern of the gather (default: the BASELINE config)")
+    ap.add_argument("--angle", type=float, default=-30.0, help="rotation angle of f1 (default: the BASELINE config, -30 deg)")
     args = ap.parse_args()
     h, w = args.height, args.width
-    global PATTERN
+    global PATTERN, ANGLE
     PATTERN = args.pattern
+    ANGLE = args.angle
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,7 +248,7 @@ def main():
                        "parallelism": "independent pairs per GPU x{}".format(world), "rccl_broadcast": rccl_note},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "compose3_oneshot_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "kernel": "compose3_xpose_kernel", "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         tpath = os.path.join(ROOT, "profiles", "r01_compose3_traffic.json")

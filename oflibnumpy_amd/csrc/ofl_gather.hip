@@ -147,6 +147,7 @@ struct C3Args {
     int sign, H, W, tiles_x, tiles_per_field, ntiles;
     float th;
     int swz_group;         // one-shot kernel: workgroups per XCD-swizzle group (0 = natural order)
+    int xpose_rows;        // transposed-gather kernel: source rows a streamed 128-px segment may cross on the direct path
     int ablate;            // development knob (OFL_C3_ABLATE): 1 = skip the gather, 2 = skip the stores; 0 in production
 };
 
@@ -454,6 +455,161 @@ __device__ __forceinline__ int wave_minmax(int v)
     OFL_DPP_STEP(0x143, 0xc)    // row_bcast:31 into rows 2 and 3
 #undef OFL_DPP_STEP
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2, transposed-gather form (variant 3).  The streaming layout (a wave = 2 rows x 128 px) is what the stream loads
+// and stores want, but when the sampling grid is ROTATED each gather instruction of such a wave touches 60+ cache
+// lines (one per source row its 128-px segment crosses): the texture cache's tag look-ups, not HBM, bound the
+// kernel (rocprofv3: 2.75 x the cache accesses of the axis-aligned case).  Workgroups that see such a field hand
+// their sampling vectors through LDS to a BLOCK layout (a wave = 32 px x 8 rows, every gather instruction one 8 x 8
+// block of it), gather and blend there (~15 lines per instruction), and hand the results back for the streaming stores.  Same arithmetic
+// per pixel, bit-identical results; axis-aligned fields keep the direct path.
+constexpr int kXpRowF2 = 128 + 4;             // LDS row stride in float2 (padding spreads the 8 rows over the banks)
+constexpr int kXposeRows = 6;                 // source rows one streamed 128-px segment may cross before we transpose
+
+template <int QUANT, bool STATS>
+__device__ __forceinline__ void c3_sample_block(const C3Args &a, const float *__restrict__ fa, const uint8_t *__restrict__ ma,
+                                                const int (&gx)[4], int gy, const float (&fu)[4], const float (&fv)[4],
+                                                float (&su)[4], float (&sv)[4], bool (&ok)[4], C3Stat &st)
+{
+    const int H = a.H, W = a.W;
+    C3Pos tp[4];
+    bool act[4], inside = true, outside = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        act[j] = gy < H && gx[j] < W;
+        tp[j] = c3_pos<QUANT>(gx[j], gy, fu[j], fv[j], a.sign);
+        const bool in_j  = (unsigned)tp[j].ix <= (unsigned)(W - 2) && (unsigned)tp[j].iy <= (unsigned)(H - 2);
+        const bool out_j = tp[j].ix < -1 || tp[j].ix >= W || tp[j].iy < -1 || tp[j].iy >= H;
+        inside  = inside && (in_j || !act[j]);
+        outside = outside && (out_j || !act[j]);
+        su[j] = 0.0f; sv[j] = 0.0f; ok[j] = false;
+    }
+    if (H < 2) inside = false;
+    if (__all(outside)) return;
+    if (__all(inside)) {
+        Pair2    p0[4], p1[4];
+        uint32_t m0[4], m1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t s0 = act[j] ? (size_t)tp[j].iy * W + tp[j].ix : 0;
+            p0[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
+            p1[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * (s0 + W));
+            m0[j] = (uint32_t)ma[s0] | ((uint32_t)ma[s0 + 1] << 8);
+            m1[j] = (uint32_t)ma[s0 + W] | ((uint32_t)ma[s0 + W + 1] << 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const C3Tap w = c3_weights<QUANT>(tp[j]);
+            su[j] = c3_blend(p0[j].lo_u, p0[j].hi_u, p1[j].lo_u, p1[j].hi_u, w);
+            sv[j] = c3_blend(p0[j].lo_v, p0[j].hi_v, p1[j].lo_v, p1[j].hi_v, w);
+            const bool m00 = (m0[j] & 0xffu) != 0, m01 = (m0[j] & 0xff00u) != 0;
+            const bool m10 = (m1[j] & 0xffu) != 0, m11 = (m1[j] & 0xff00u) != 0;
+            ok[j] = c3_valid<QUANT>(m00, m01, m10, m11, w);
+            if (STATS) st.amax_m = fmaxf(st.amax_m, (m00 && act[j]) ? fmaxf(fabsf(p0[j].lo_u), fabsf(p0[j].lo_v)) : 0.0f);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // border path, as in c3_tile
+        const int  ixc = min(max(tp[j].ix, 0), max(W - 2, 0));
+        const int  d   = tp[j].ix - ixc;
+        const bool r0  = (unsigned)tp[j].iy < (unsigned)H;
+        const bool r1  = (unsigned)(tp[j].iy + 1) < (unsigned)H;
+        const int  y0c = min(max(tp[j].iy, 0), H - 1);
+        const int  y1c = min(max(tp[j].iy + 1, 0), H - 1);
+        const size_t s0 = (size_t)y0c * W + ixc, s1 = (size_t)y1c * W + ixc;
+        const Pair2 p0 = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
+        const Pair2 p1 = *reinterpret_cast<const Pair2 *>(fa + 2 * s1);
+        const uint32_t q00 = ma[s0], q01 = ma[s0 + 1], q10 = ma[s1], q11 = ma[s1 + 1];
+        float u00, v00, u01, v01, u10, v10, u11, v11, a00, a01, a10, a11;
+        select_pair(p0, d, r0, u00, v00, u01, v01);
+        select_pair(p1, d, r1, u10, v10, u11, v11);
+        select_mask(q00, q01, d, r0, a00, a01);
+        select_mask(q10, q11, d, r1, a10, a11);
+        const C3Tap w = c3_weights<QUANT>(tp[j]);
+        su[j] = c3_blend(u00, u01, u10, u11, w);
+        sv[j] = c3_blend(v00, v01, v10, v11, w);
+        ok[j] = c3_valid<QUANT>(a00 != 0.0f, a01 != 0.0f, a10 != 0.0f, a11 != 0.0f, w);
+        if (STATS) st.amax_m = fmaxf(st.amax_m, (a00 != 0.0f && act[j]) ? fmaxf(fabsf(u00), fabsf(v00)) : 0.0f);
+    }
+}
+
+template <int QUANT, bool STATS>
+__global__ __launch_bounds__(256, OFL_C3_ONESHOT_WAVES)
+void compose3_xpose_kernel(const C3Args a)
+{
+    static_assert(kC3LanesX == 32, "the transposed form assumes 128 x 8 tiles");
+    __shared__ __attribute__((aligned(16))) float2 xp_v[8 * kXpRowF2];
+    __shared__ __attribute__((aligned(16))) uint8_t xp_ok[8 * 128];
+    const int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    C3Stat st = { 0.0f, 0.0f, 0.0f };
+    const C3Stream in = c3_load_stream<kC3LanesX>(a, tile);
+    int b, y, xg[2];
+    c3_tile_coords<kC3LanesX>(a, tile, b, y, xg);
+    const int H = a.H, W = a.W;
+    const bool act[2] = { y < H && xg[0] < W, y < H && xg[1] < W };
+    // Does a streamed row segment of this tile cross many source rows (sample row = y -/+ v)?  Every wave answers from
+    // the SAME two values -- the vertical flow at the two ends of the tile's first row (uniform loads, L2 hits) -- so
+    // the workgroup agrees without a barrier and the direct path costs nothing extra.
+    const int t   = tile - b * a.tiles_per_field;
+    const int ty  = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    bool rotated;
+    {
+        const int x0 = tx * 128, x1 = min(x0 + 127, W - 1), yy = min(ty * 8, H - 1);
+        const float *frow = a.fb + 2 * ((size_t)b * H * W + (size_t)yy * W);
+        rotated = fabsf(frow[2 * x1 + 1] - frow[2 * x0 + 1]) * 128.0f > (float)(a.xpose_rows * (x1 - x0 + 1));
+    }
+    if (!rotated) {
+        c3_tile<QUANT, STATS>(a, tile, in, st);
+        if (STATS) c3_flush_stats(a, tile / a.tiles_per_field, st);
+        return;
+    }
+    const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+    // streaming layout -> LDS: the sampling vectors of this lane's two pixel pairs
+    *reinterpret_cast<float4 *>(&xp_v[ly * kXpRowF2 + 2 * lx])      = in.v[0];
+    *reinterpret_cast<float4 *>(&xp_v[ly * kXpRowF2 + 64 + 2 * lx]) = in.v[1];
+    __syncthreads();
+    // block layout: wave w owns columns [32 w, 32 w + 32) of all 8 rows, a lane four adjacent pixels
+    // every gather INSTRUCTION (fixed j) then covers a compact 8 x 8 block: pixel j of lane (r, c) is column 8 j + c
+    const int w4  = threadIdx.x >> 6, l = threadIdx.x & 63, r = l >> 3, c0 = 32 * w4 + (l & 7);
+    {
+        float fu[4], fv[4];
+        int   gx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 f = xp_v[r * kXpRowF2 + c0 + 8 * j];
+            fu[j] = f.x; fv[j] = f.y;
+            gx[j] = tx * 128 + c0 + 8 * j;
+        }
+        float su[4], sv[4];
+        bool  ok[4];
+        const size_t field = (size_t)b * H * W;
+        c3_sample_block<QUANT, STATS>(a, a.fa + field * 2, a.ma + field, gx, ty * 8 + r, fu, fv, su, sv, ok, st);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xp_v[r * kXpRowF2 + c0 + 8 * j] = make_float2(su[j], sv[j]);
+            xp_ok[r * 128 + c0 + 8 * j] = ok[j] ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // back in the streaming layout: add, combine the masks, store
+    {
+        const float4 s01 = *reinterpret_cast<const float4 *>(&xp_v[ly * kXpRowF2 + 2 * lx]);
+        const float4 s23 = *reinterpret_cast<const float4 *>(&xp_v[ly * kXpRowF2 + 64 + 2 * lx]);
+        const uint32_t k01 = *reinterpret_cast<const uint16_t *>(&xp_ok[ly * 128 + 2 * lx]);
+        const uint32_t k23 = *reinterpret_cast<const uint16_t *>(&xp_ok[ly * 128 + 64 + 2 * lx]);
+        const float su[kC3Px] = { s01.x, s01.z, s23.x, s23.z }, sv[kC3Px] = { s01.y, s01.w, s23.y, s23.w };
+        const bool  ok[kC3Px] = { (k01 & 0xffu) != 0, (k01 & 0xff00u) != 0, (k23 & 0xffu) != 0, (k23 & 0xff00u) != 0 };
+        const float bu[kC3Px] = { in.v[0].x, in.v[0].z, in.v[1].x, in.v[1].z };
+        const float bv[kC3Px] = { in.v[0].y, in.v[0].w, in.v[1].y, in.v[1].w };
+        const bool  bm[kC3Px] = { (in.m[0] & 0xffu) != 0, (in.m[0] & 0xff00u) != 0, (in.m[1] & 0xffu) != 0, (in.m[1] & 0xff00u) != 0 };
+        const size_t row = (size_t)b * H * W + (size_t)y * W;
+        c3_finish<STATS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
+    }
+    if (STATS) c3_flush_stats(a, tile / a.tiles_per_field, st);
 }
 
 template <int QUANT, bool STATS>
@@ -858,6 +1014,56 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
     }
 }
 
+// taps, gather and blend of four pixels (gx[j], y) of one lane; wave-uniform all-outside / all-inside / border paths
+template <typename T, int CT>
+__device__ __forceinline__ void gather2_core(const T *__restrict__ src, const uint8_t *__restrict__ smask, int H, int W,
+                                             const int (&gx)[4], int y, const bool (&act4)[4],
+                                             const float (&fu)[4], const float (&fv)[4], int sign,
+                                             int quant, int arith, int rule, bool want_valid,
+                                             T (&res)[4][CT], bool (&ok)[4])
+{
+    Tap  tp[4];
+    int  wi[4][4];
+    bool inside = true, outside = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float px = map_coord(gx[j], fu[j], sign), py = map_coord(y, fv[j], sign);
+        tp[j] = (quant == OFL_QUANT_OPENCV) ? make_tap<OFL_QUANT_OPENCV>(px, py) : make_tap<OFL_QUANT_EXACT>(px, py);
+        if (quant == OFL_QUANT_OPENCV) {
+            wi[j][0] = (32 - tp[j].ay) * (32 - tp[j].ax) * 32; wi[j][1] = (32 - tp[j].ay) * tp[j].ax * 32;
+            wi[j][2] = tp[j].ay * (32 - tp[j].ax) * 32;        wi[j][3] = tp[j].ay * tp[j].ax * 32;
+        } else {
+            wi[j][0] = __float2int_rn(tp[j].w0 * 32768.0f); wi[j][1] = __float2int_rn(tp[j].w1 * 32768.0f);
+            wi[j][2] = __float2int_rn(tp[j].w2 * 32768.0f); wi[j][3] = __float2int_rn(tp[j].w3 * 32768.0f);
+        }
+        const bool in_j  = (unsigned)tp[j].ix <= (unsigned)(W - 2) && (unsigned)tp[j].iy <= (unsigned)(H - 2);
+        const bool out_j = tp[j].ix < -1 || tp[j].ix >= W || tp[j].iy < -1 || tp[j].iy >= H;
+        inside  = inside && (in_j || !act4[j]);
+        outside = outside && (out_j || !act4[j]);
+    }
+    if (H < 2) inside = false;
+    const bool fixed_u8 = (sizeof(T) == 1) && arith == OFL_ARITH_NATIVE;
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ok[j] = false;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) res[j][c] = (T)0;
+    }
+    if (__all(outside)) {
+        // nothing to fetch: every tap of every pixel of this wave is outside the source
+    } else if (__all(inside)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (act4[j]) gather_px<T, CT, true>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (act4[j]) gather_px<T, CT, false>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
+    }
+
+}
+
 #ifndef OFL_G2_NT_FLOW
 #define OFL_G2_NT_FLOW 0       // measured: non-temporal flow loads / image stores do not help this kernel (they do help K2)
 #endif
@@ -870,7 +1076,7 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
                     const float *__restrict__ flow, int fH, int fW, int pad_top, int pad_left, int sign,
                     const uint8_t *__restrict__ smask, const uint8_t *__restrict__ fmask,
                     T *__restrict__ dst, uint8_t *__restrict__ valid,
-                    int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows)
+                    int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows, int xpose_rows)
 {
     const int tile = nblocks > 0 ? xcd_swizzle(blockIdx.x, nblocks) : (int)blockIdx.x;     // nblocks <= 0: natural order
     const int ty   = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -915,47 +1121,68 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
         }
     }
 
-    Tap  tp[4];
-    int  wi[4][4];
-    bool inside = true, outside = true;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float px = map_coord(xg[j >> 1] + (j & 1), fu[j], sign), py = map_coord(y, fv[j], sign);
-        tp[j] = (quant == OFL_QUANT_OPENCV) ? make_tap<OFL_QUANT_OPENCV>(px, py) : make_tap<OFL_QUANT_EXACT>(px, py);
-        if (quant == OFL_QUANT_OPENCV) {
-            wi[j][0] = (32 - tp[j].ay) * (32 - tp[j].ax) * 32; wi[j][1] = (32 - tp[j].ay) * tp[j].ax * 32;
-            wi[j][2] = tp[j].ay * (32 - tp[j].ax) * 32;        wi[j][3] = tp[j].ay * tp[j].ax * 32;
-        } else {
-            wi[j][0] = __float2int_rn(tp[j].w0 * 32768.0f); wi[j][1] = __float2int_rn(tp[j].w1 * 32768.0f);
-            wi[j][2] = __float2int_rn(tp[j].w2 * 32768.0f); wi[j][3] = __float2int_rn(tp[j].w3 * 32768.0f);
-        }
-        const bool in_j  = (unsigned)tp[j].ix <= (unsigned)(W - 2) && (unsigned)tp[j].iy <= (unsigned)(H - 2);
-        const bool out_j = tp[j].ix < -1 || tp[j].ix >= W || tp[j].iy < -1 || tp[j].iy >= H;
-        inside  = inside && (in_j || !act[j >> 1]);
-        outside = outside && (out_j || !act[j >> 1]);
-    }
-    if (H < 2) inside = false;
-    const bool fixed_u8 = (sizeof(T) == 1) && arith == OFL_ARITH_NATIVE;
     const bool want_valid = valid != nullptr;
-
     T    res[4][CT];
     bool ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ok[j] = false;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) res[j][c] = (T)0;
+    // transposed gather for rotated sampling grids (see K2, variant 3) -- float images with 3 or 4 channels only:
+    // measured +10 % on a 30-degree grid.  For 1 / 2 channels and for 8- / 16-bit images the extra registers cost a wave
+    // of occupancy (and the byte-wise LDS hand-over is slow), which loses more than the fewer tag look-ups save.
+    constexpr bool kXp = sizeof(T) == 4 && CT >= 3;
+    __shared__ __attribute__((aligned(16))) float2  xp_f[kXp ? 8 * kXpRowF2 : 1];
+    __shared__ __attribute__((aligned(16))) T       xp_r[kXp ? 8 * 128 * CT : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t xp_k[kXp ? 8 * 128 : 1];
+    bool rotated = false;
+    if constexpr (kXp) {
+        // uniform decision from the vertical flow at the two ends of the tile's first row (zero outside the flow area)
+        const int x0 = tx * 128, x1 = min(x0 + 127, W - 1), y0 = row0 + min(ty * 8, rows - 1);
+        const int fy0 = y0 - pad_top, fxa = x0 - pad_left, fxb = x1 - pad_left;
+        const bool rin = (unsigned)fy0 < (unsigned)fH;
+        const float va = (rin && (unsigned)fxa < (unsigned)fW) ? flow[((size_t)fy0 * fW + fxa) * 2 + 1] : 0.0f;
+        const float vb = (rin && (unsigned)fxb < (unsigned)fW) ? flow[((size_t)fy0 * fW + fxb) * 2 + 1] : 0.0f;
+        rotated = fabsf(vb - va) * 128.0f > (float)(xpose_rows * (x1 - x0 + 1));
     }
-    if (__all(outside)) {
-        // nothing to fetch: every tap of every pixel of this wave is outside the source
-    } else if (__all(inside)) {
+    if (!rotated) {
+        const int  gx[4]   = { xg[0], xg[0] + 1, xg[1], xg[1] + 1 };
+        const bool act4[4] = { act[0], act[0], act[1], act[1] };
+        gather2_core<T, CT>(src, smask, H, W, gx, y, act4, fu, fv, sign, quant, arith, rule, want_valid, res, ok);
+    } else if constexpr (kXp) {
+        const int ly = threadIdx.x >> 5;
+        *reinterpret_cast<float4 *>(&xp_f[ly * kXpRowF2 + 2 * lx])      = make_float4(fu[0], fv[0], fu[1], fv[1]);
+        *reinterpret_cast<float4 *>(&xp_f[ly * kXpRowF2 + 64 + 2 * lx]) = make_float4(fu[2], fv[2], fu[3], fv[3]);
+        __syncthreads();
+        // block layout: wave w owns columns [32 w, 32 w + 32) of the 8 rows; gather instruction j covers the 8 x 8 block
+        // of columns 8 j .. 8 j + 7
+        const int w4 = threadIdx.x >> 6, l = threadIdx.x & 63, r = l >> 3, c0 = 32 * w4 + (l & 7);
+        {
+            const int ylb = ty * 8 + r;
+            int   gxb[4];
+            bool  actb[4];
+            float fub[4], fvb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (act[j >> 1]) gather_px<T, CT, true>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
-    } else {
+            for (int j = 0; j < 4; ++j) {
+                const float2 f = xp_f[r * kXpRowF2 + c0 + 8 * j];
+                fub[j] = f.x; fvb[j] = f.y;
+                gxb[j] = tx * 128 + c0 + 8 * j;
+                actb[j] = ylb < rows && gxb[j] < W;
+            }
+            T    resb[4][CT];
+            bool okb[4];
+            gather2_core<T, CT>(src, smask, H, W, gxb, row0 + ylb, actb, fub, fvb, sign, quant, arith, rule, want_valid, resb, okb);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (act[j >> 1]) gather_px<T, CT, false>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) xp_r[(r * 128 + c0 + 8 * j) * CT + c] = resb[j][c];
+                xp_k[r * 128 + c0 + 8 * j] = okb[j] ? 1 : 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = (j >> 1) * 64 + 2 * lx + (j & 1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) res[j][c] = xp_r[(ly * 128 + col) * CT + c];
+            ok[j] = xp_k[ly * 128 + col] != 0;
+        }
     }
 
     uint32_t vword[2] = { 0u, 0u };
@@ -1005,10 +1232,11 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
         const int tiles_x = (W + 127) / 128, tiles_y = (rows + 7) / 8;
         const int nblocks = tiles_x * tiles_y;
         static const int swz = getenv("OFL_G2_SWZ") ? atoi(getenv("OFL_G2_SWZ")) : 0;          // tuning knob: 1 = XCD swizzle
+        static const int xpose_rows = getenv("OFL_G2_XPOSE_ROWS") ? atoi(getenv("OFL_G2_XPOSE_ROWS")) : kXposeRows;   // tuning knob
 #define OFL_GATHER2_LAUNCH(CT)                                                                           \
         hipLaunchKernelGGL((gather2_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, H, W, \
                            flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,   \
-                           arith, rule, tiles_x, swz ? nblocks : 0, row0, rows)
+                           arith, rule, tiles_x, swz ? nblocks : 0, row0, rows, xpose_rows)
         switch (C) {
         case 1: OFL_GATHER2_LAUNCH(1); break;
         case 2: OFL_GATHER2_LAUNCH(2); break;
@@ -1117,9 +1345,10 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
 
     if (W % 2 == 0) {
         static const int ablate = getenv("OFL_C3_ABLATE") ? atoi(getenv("OFL_C3_ABLATE")) : 0;
-        // -1 / 2 (default): one workgroup per tile in natural order -- the dispatcher keeps every wave slot
-        // filled and all XCDs sweep one window of memory (measured +2..7 % over the persistent kernel at 1..8
-        // 4K pairs per launch); 0 persistent grid with stream prefetch; 1 LDS-staged (rotated sampling grids)
+        // -1 / 3 (default): one workgroup per tile in natural order -- the dispatcher keeps every wave slot filled
+        // and all XCDs sweep one window of memory (measured +2..7 % over the persistent kernel at 1..8 4K pairs
+        // per launch) -- with the gather transposed through LDS in workgroups whose sampling grid is rotated;
+        // 2 the same without the transposition; 0 persistent grid with stream prefetch; 1 source tile staged in LDS
         static const int variant_env = getenv("OFL_C3_VARIANT") ? atoi(getenv("OFL_C3_VARIANT")) : -1;
         int variant = variant_env;
         const bool use_lds = variant == 1;
@@ -1128,15 +1357,17 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
         const long long nt = (long long)tiles_x * tiles_y * batch;
         if (nt > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
         static const int swz = getenv("OFL_C3_SWZ") ? atoi(getenv("OFL_C3_SWZ")) : 0;             // tuning knob (0 = natural order: measured best)
-        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, swz, ablate };
+        static const int xpose_rows = getenv("OFL_C3_XPOSE_ROWS") ? atoi(getenv("OFL_C3_XPOSE_ROWS")) : kXposeRows;   // tuning knob
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, swz, xpose_rows, ablate };
         // persistent grid: what the chip keeps resident (a multiple of 8 = one share per XCD), or one
         // workgroup per tile when the problem is smaller than that
         int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr, use_lds);
-        if (variant < 0) variant = 2;
+        if (variant < 0) variant = 3;
         if (grid > (int)nt) grid = (int)nt;
         if (grid >= 8) grid &= ~7;
 #define OFL_C3(Q, S) do { if (use_lds) hipLaunchKernelGGL((compose3_lds_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
                           else if (variant == 2) hipLaunchKernelGGL((compose3_oneshot_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); \
+                          else if (variant == 3) hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); \
                           else hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); } while (0)
         if (quant == OFL_QUANT_OPENCV) { if (stats) OFL_C3(OFL_QUANT_OPENCV, true); else OFL_C3(OFL_QUANT_OPENCV, false); }
         else                           { if (stats) OFL_C3(OFL_QUANT_EXACT, true);  else OFL_C3(OFL_QUANT_EXACT, false); }

@@ -316,6 +316,17 @@ def test_full_size_properties(gpu, oracle):
     f3 = of.Flow.from_transforms([['rotation', 1920, 1080, -30], ['scaling', 800, 600, 0.8]], [H, W], 't')
     m = r.mask & f3.mask
     np.testing.assert_allclose(r.vecs[m], f3.vecs[m], atol=5e-2)
+    # the other order samples along a ROTATED grid: the workgroups take the transposed-gather path
+    r = f2.combine_with(f1, 3)
+    o, mo = oracle.compose3_raw(f2.vecs, f2.mask, f1.vecs, f1.mask, -1)
+    np.testing.assert_array_equal(r.mask, mo)
+    np.testing.assert_array_equal(r.vecs, o)
+    for ang in (2.0, 4.0, 77.0):           # around the switch-over between the two paths, and a steep one
+        g = of.Flow.from_transforms([['rotation', 1700, 900, ang]], [H, W], 's', rand_mask((H, W), 23))
+        r = g.combine_with(f2.switch_ref('invalid'), 3)
+        o, mo = oracle.compose3_raw(f2.vecs, f2.mask, g.vecs, g.mask, +1)
+        np.testing.assert_array_equal(r.mask, mo)
+        np.testing.assert_array_equal(r.vecs, o)
 
 
 def test_config4_batch_of_pairs(gpu, oracle):
@@ -518,7 +529,7 @@ def test_combine_flows_batch_api(gpu, oracle):
 
 
 def test_lds_staged_variant_in_subprocess(gpu):
-    """The opt-in LDS-staged compose kernel (OFL_C3_VARIANT=1, read once per process) produces the same bits
+    """The opt-in compose kernel variants (OFL_C3_VARIANT, read once per process) produce the same bits
     as the oracle: small and large footprints (the latter exceed the LDS budget and take the in-kernel
     direct path), both references, odd tile remainders."""
     import os
@@ -542,9 +553,12 @@ for shape, t1, t2 in (((300, 400), [['rotation', 200, 150, -30]], [['scaling', 1
         assert np.array_equal(got.vecs, want.vecs) and np.array_equal(got.mask, want.mask), (shape, ref)
 print("lds-variant-ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OFL_C3_VARIANT="1")
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0 and "lds-variant-ok" in p.stdout, p.stderr[-2000:]
+    # variant 1 = source tile staged in LDS, 2 = one-shot without the transposed gather, 0 = persistent grid;
+    # the default (3, transposed gather for rotated sampling grids) is what every other test runs
+    for variant in ("1", "2", "0"):
+        env = dict(os.environ, OFL_C3_VARIANT=variant)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "lds-variant-ok" in p.stdout, (variant, p.stderr[-2000:])
 
 
 def test_device_resident_image_warp(gpu, oracle):

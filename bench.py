@@ -116,7 +116,18 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on STDOUT; the contract is ONE JSON line there, so the rendezvous (and a
+        # first barrier, which completes the mesh) runs with fd 1 pointing at stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def barrier():
         if dist is not None:

@@ -38,7 +38,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)            # gloo announces its connections on stdout
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     flo = of.load_sintel(os.path.join(ROOT, "tests", "golden", "sintel.flo"))
     big = np.ascontiguousarray(np.tile(flo, (args.tiles[0], args.tiles[1], 1)))

@@ -75,7 +75,8 @@ enum {
     OFL_STAT_NONZERO_TH_MASKED  = 2,  /* some |component| >= 1e-3 where mask     (Flow.is_zero(thresholded=True)) */
     OFL_STAT_NONZERO            = 4,  /* some component != 0 anywhere            (is_zero_flow(thresholded=False), utils.py:527) */
     OFL_STAT_NONZERO_TH         = 8,  /* some |component| >= 1e-3 anywhere       (is_zero_flow(thresholded=True), utils.py:215) */
-    OFL_STAT_NONFINITE          = 16  /* NaN / Inf present                       (validate_flow_array, utils.py:86) */
+    OFL_STAT_NONFINITE          = 16, /* NaN / Inf present                       (validate_flow_array, utils.py:86) */
+    OFL_STAT_MASK_HAS_ZERO      = 32  /* some mask byte is 0 (ofl_flow_stats only; lets callers pass NULL instead of an all-ones point mask) */
 };
 
 /* ------------------------------------------------------------------ runtime / device memory */

@@ -17,7 +17,7 @@ QUANT_OPENCV, QUANT_EXACT = 0, 1
 ARITH_NATIVE, ARITH_FLOAT_RNE = 0, 1
 RULE_EQ1, RULE_GE_HALF, RULE_GT_HALF = 0, 1, 2
 SCATTER_ROUND = 0x100
-STAT_NONZERO_MASKED, STAT_NONZERO_TH_MASKED, STAT_NONZERO, STAT_NONZERO_TH, STAT_NONFINITE = 1, 2, 4, 8, 16
+STAT_NONZERO_MASKED, STAT_NONZERO_TH_MASKED, STAT_NONZERO, STAT_NONZERO_TH, STAT_NONFINITE, STAT_MASK_HAS_ZERO = 1, 2, 4, 8, 16, 32
 
 
 class NativeError(RuntimeError):

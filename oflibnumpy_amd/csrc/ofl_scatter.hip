@@ -26,6 +26,7 @@
 #include <mutex>
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
 
 using namespace ofl;
 
@@ -33,6 +34,7 @@ namespace {
 
 constexpr uint32_t kNoOwner   = 0xFFFFFFFFu;
 constexpr uint32_t kGapOwner  = 0xFFFFFFFEu;                     // owner-map marker: uncovered node inside the hull (pass 2b)
+constexpr uint32_t kGapFar    = 0xFFFFFFFDu;                     // ... whose 5 x 5 neighbourhood is uncovered too (pass 2c)
 constexpr double   kEps       = 100.0 * 2.220446049250313e-16;   // scipy _qhull: eps = 100 * DBL_EPSILON
 constexpr int      kSmallArea = 1024;                             // bbox nodes scanned inside the raster kernel (lane or wave)
 #ifndef OFL_SC_COOP
@@ -60,6 +62,8 @@ struct ScatterWs {          // layout of the caller-provided workspace
     const D2 *guard;        // [4] warped kept points next to the four image corners (header bytes 64..127) ...
     const int *guard_ok;    // ... and whether all four exist (header byte 128)
     int       cand_cap;
+    uint8_t  *coarse;       // [ceil(H/8)][ceil(W/32)] "some node of this 32 x 8 block has an owner" (1 = yes or unknown)
+    int       coarse_w;
     int       oy0, oy1;     // rows [oy0, oy1) the owner map covers (0, H unless one row band is computed);
                             // `owner` is biased so that owner[y * W + x] addresses row y for y in that range
 };
@@ -364,7 +368,9 @@ void scatter_raster_kernel(const float *__restrict__ flow, int sign, const uint8
         if (threadIdx.x == 0 && block_sum)
             atomicAdd(&ws.kept_slots[(blockIdx.y * gridDim.x + blockIdx.x) & 255], (unsigned long long)block_sum);
     }
-    hull_candidate(flow, sign, pmask, H, W, x, y, ws);
+    // hull candidates exist only in workgroups on the image border (or anywhere with a point mask): a SCALAR condition
+    if (pmask || blockIdx.x == 0 || blockIdx.y == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.y == gridDim.y - 1)
+        hull_candidate(flow, sign, pmask, H, W, x, y, ws);
     if (x >= cw || y >= ch) return;
     const size_t i00 = (size_t)y * W + x;
     bool k0 = true, k1 = true, k2 = true, k3 = true;
@@ -483,25 +489,63 @@ __device__ __forceinline__ bool inside_hull(const HullRef &h, double qx, double 
 
 // nearest covered grid node around (cx, cy): rings of growing Chebyshev radius, ties to the smallest
 // Euclidean distance then the smallest owner id (deterministic)
+// RINGS: 0 = all rings, 1 = rings 0 .. 2 only, 2 = rings 3 .. kFillRadius only (the two halves of the gap pass)
+template <int RINGS>
 __device__ __forceinline__ uint32_t nearest_owner(const uint32_t *owner, int y_lo, int y_hi, int W, int cx, int cy, double qx, double qy)
 {
-    for (int r = 0; r <= kFillRadius; ++r) {
-        uint32_t best = kNoOwner;
-        double bestd = 1e300;
-        for (int dy = -r; dy <= r; ++dy) {
-            const int yy = cy + dy;
-            if (yy < y_lo || yy >= y_hi) continue;
-            const int step = (dy == -r || dy == r) ? 1 : 2 * r;
-            for (int dx = -r; dx <= r; dx += (step > 0 ? step : 1)) {
-                const int xx = cx + dx;
-                if (xx < 0 || xx >= W) continue;
-                const uint32_t id = owner[(size_t)yy * W + xx];
-                if (id >= kGapOwner) continue;
-                const double d = (xx - qx) * (xx - qx) + (yy - qy) * (yy - qy);
-                if (d < bestd || (d == bestd && id < best)) { bestd = d; best = id; }
+    // ring r = the 8 r nodes at Chebyshev distance r.  One dependent load per node made the waves at the rim of a hole
+    // spend 170 us in this loop at 4K (the slowest lane sets the time of the kernel): the probes are batched.
+    uint32_t best = kNoOwner;
+    double bestd = 1e300;
+    auto probe = [&](int xx, int yy) -> uint32_t {
+        return (xx >= 0 && xx < W && yy >= y_lo && yy < y_hi) ? owner[(size_t)yy * W + xx] : kNoOwner;
+    };
+    auto take = [&](uint32_t id, int xx, int yy) {
+        if (id >= kGapFar) return;
+        const double d = (xx - qx) * (xx - qx) + (yy - qy) * (yy - qy);
+        if (d < bestd || (d == bestd && id < best)) { bestd = d; best = id; }
+    };
+    if (RINGS != 2) {
+        const uint32_t id = probe(cx, cy);
+        if (id < kGapFar) return id;
+    }
+    // the ring as four runs of 2 r nodes -- top (dx = -r .. r-1, dy = -r), bottom (dx = -r+1 .. r, dy = r), left
+    // (dx = -r, dy = -r+1 .. r), right (dx = r, dy = -r .. r-1): every node once; B nodes of each run per round trip
+    auto ring = [&](int r, auto batch) {
+        constexpr int B = decltype(batch)::value;
+        for (int t = 0; t < 2 * r; t += B) {
+            uint32_t id[4][B];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sx = (k < 2) ? 1 : 0, sy = 1 - sx;
+                const int x0 = cx + ((k == 0 || k == 2) ? -r : (k == 1 ? -r + 1 : r));
+                const int y0 = cy + ((k == 0 || k == 3) ? -r : (k == 1 ? r : -r + 1));
+#pragma unroll
+                for (int u = 0; u < B; ++u) id[k][u] = (t + u < 2 * r) ? probe(x0 + sx * (t + u), y0 + sy * (t + u)) : kNoOwner;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sx = (k < 2) ? 1 : 0, sy = 1 - sx;
+                const int x0 = cx + ((k == 0 || k == 2) ? -r : (k == 1 ? -r + 1 : r));
+                const int y0 = cy + ((k == 0 || k == 3) ? -r : (k == 1 ? r : -r + 1));
+#pragma unroll
+                for (int u = 0; u < B; ++u) take(id[k][u], x0 + sx * (t + u), y0 + sy * (t + u));
             }
         }
+    };
+    // isolated dropped points (speckled masks) end at ring 1 or 2: exactly their 8 / 16 probes; wider rings keep 32
+    // probes in flight per round trip -- 40 round trips for rings 3 .. 16 instead of one per node
+    if (RINGS != 2) {
+        ring(1, std::integral_constant<int, 2>());
         if (best != kNoOwner) return best;
+        ring(2, std::integral_constant<int, 4>());
+        if (best != kNoOwner) return best;
+    }
+    if (RINGS != 1) {
+        for (int r = 3; r <= kFillRadius; ++r) {
+            ring(r, std::integral_constant<int, 8>());
+            if (best != kNoOwner) return best;
+        }
     }
     return kNoOwner;
 }
@@ -581,13 +625,14 @@ __device__ __forceinline__ bool locate_query(const float *flow, int sign, const 
 }
 
 // Gap fill shared by the dense and the sparse pass (see scatter_resolve_kernel).
+template <int RINGS = 0>
 __device__ __forceinline__ bool fill_from_nearest(const float *flow, int sign, int H, int W, const ScatterWs &ws,
                                                   const HullRef &hull, double qx, double qy, uint32_t &id,
                                                   size_t (&vi)[3], D2 (&vp)[3], double &c0, double &c1, double &c2)
 {
     if (!(hull.n_lower > 0 && inside_hull(hull, qx, qy))) return false;
     const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
-    id = nearest_owner(ws.owner, ws.oy0, ws.oy1, W, nx, ny, qx, qy);
+    id = nearest_owner<RINGS>(ws.owner, ws.oy0, ws.oy1, W, nx, ny, qx, qy);
     if (id == kNoOwner) return false;
     tri_decode(id, flow, sign, W, vi, vp);
     (void)bary(vp[0], vp[1], vp[2], qx, qy, c0, c1, c2);
@@ -667,12 +712,20 @@ void scatter_resolve_grid_kernel(const float *__restrict__ flow, int sign,
             gap = hull.n_lower > 0 && inside_hull(hull, (double)x, (double)y);
         }
     }
+    // coverage of this 32 x 8 block for pass 2b (blocks are aligned with the grid only when row0 is a multiple of 8:
+    // otherwise the map keeps its "unknown" default)
+    {
+        const int covered = __syncthreads_or(act && id != kNoOwner);
+        if (threadIdx.x == 0 && (row0 & 7) == 0) ws.coarse[(size_t)((row0 >> 3) + blockIdx.y) * ws.coarse_w + blockIdx.x] = covered ? 1 : 0;
+    }
     // gap nodes are MARKED in the owner map (a plain store: a counter bumped by every wave that holds one serialises
     // at ~12 ns per atomic -- 1.5 ms with a speckled mask); pass 2b scans the map for the marks
     if (gap) ws.owner[(size_t)y * W + x] = kGapOwner;
 }
 
-// pass 2b: the marked gap nodes
+// pass 2b / 2c: the marked gap nodes.  FAR = false looks at rings 0 .. 2 (isolated dropped points: a lean kernel at full
+// occupancy) and re-marks what it could not fill; FAR = true searches rings 3 .. 16 for those (rims of holes).
+template <bool FAR>
 __global__ __launch_bounds__(256)
 void scatter_gap_kernel(const float *__restrict__ flow, int sign,
                         const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
@@ -681,13 +734,25 @@ void scatter_gap_kernel(const float *__restrict__ flow, int sign,
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
-    if (x >= W || yl >= rows || ws.owner[(size_t)y * W + x] != kGapOwner) return;
+    if (x >= W || yl >= rows || ws.owner[(size_t)y * W + x] != (FAR ? kGapFar : kGapOwner)) return;
     uint32_t id;
     size_t vi[3];
     D2 vp[3];
     double c0, c1, c2;
-    if (fill_from_nearest(flow, sign, H, W, ws, hull, (double)x, (double)y, id, vi, vp, c0, c1, c2))
+    if (fill_from_nearest<FAR ? 2 : 1>(flow, sign, H, W, ws, hull, (double)x, (double)y, id, vi, vp, c0, c1, c2)) {
         resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, (size_t)yl * W + x);
+        return;
+    }
+    if (!FAR) {
+        // anything covered within the full search radius?  One byte per 32 x 8 block of the window instead of 1 089
+        // owner words (nodes deep inside a hole of the point mask give up here)
+        const int bx0 = max(x - kFillRadius, 0) >> 5, bx1 = min(x + kFillRadius, W - 1) >> 5;
+        const int by0 = max(y - kFillRadius, 0) >> 3, by1 = min(y + kFillRadius, H - 1) >> 3;
+        bool any = false;
+        for (int by = by0; by <= by1 && !any; ++by)
+            for (int bx = bx0; bx <= bx1 && !any; ++bx) any = ws.coarse[(size_t)by * ws.coarse_w + bx] != 0;
+        if (any) ws.owner[(size_t)y * W + x] = kGapFar;
+    }
 }
 
 // pass 2 for arbitrary sample positions (query != NULL; mode 2 / ref 't', flow_class.py:1398-1410): the triangle
@@ -745,7 +810,9 @@ ScatterWs carve(void *workspace, int H, int W)
     ws.upper = (D2 *)p;                      p += (size_t)kHullCap * sizeof(D2);      // ONE upload
     ws.big_cap = (unsigned long long)big_cap_for(H, W);
     ws.big = (uint32_t *)p;                  p += align_up((size_t)ws.big_cap * 4, 256);
-    ws.owner = (uint32_t *)p;
+    ws.owner = (uint32_t *)p;                p += align_up((size_t)H * W * 4, 256);
+    ws.coarse = (uint8_t *)p;
+    ws.coarse_w = (W + 31) / 32;
     ws.oy0 = 0;
     ws.oy1 = H;
     return ws;
@@ -834,7 +901,8 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
     if (!bytes) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: NULL");
     if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: bad shape");
     *bytes = kHeadBytes + align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * (size_t)kHullCap * sizeof(D2) +
-             align_up((size_t)big_cap_for(H, W) * 4, 256) + align_up((size_t)H * W * 4, 256);
+             align_up((size_t)big_cap_for(H, W) * 4, 256) + align_up((size_t)H * W * 4, 256) +
+             align_up((size_t)((W + 31) / 32) * ((H + 7) / 8), 256);
     return OFL_OK;
 }
 
@@ -862,6 +930,7 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
     ws.oy1 = oy1;
     ws.owner -= (size_t)oy0 * W;         // biased base: owner[y * W + x] is row y of the covered range
     OFL_HIP(hipMemsetAsync(ws.counters, 0, kHeadBytes, s));
+    OFL_HIP(hipMemsetAsync(ws.coarse, 1, (size_t)ws.coarse_w * ((H + 7) / 8), s));     // "unknown" until the resolve pass fills it in
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_guard_kernel, dim3(1), block, 0, s, flow, sign, pmask, H, W, (D2 *)ws.guard, (int *)ws.guard_ok);
     hipLaunchKernelGGL(scatter_raster_kernel, grid, block, 0, s, flow, sign, pmask, H, W, ws);
@@ -957,8 +1026,12 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
         hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                            out, valid, valid_rule, ws, hull, 0, H);
         if (hull.n_lower > 0)
-            hipLaunchKernelGGL(scatter_gap_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+        {
+            hipLaunchKernelGGL(scatter_gap_kernel<false>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                                out, valid, valid_rule, ws, hull, 0, H);
+            hipLaunchKernelGGL(scatter_gap_kernel<true>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                               out, valid, valid_rule, ws, hull, 0, H);
+        }
     }
     OFL_HIP(hipGetLastError());
     return OFL_OK;
@@ -988,8 +1061,12 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
     hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                        out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
     if (hull.n_lower > 0)
-        hipLaunchKernelGGL(scatter_gap_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+    {
+        hipLaunchKernelGGL(scatter_gap_kernel<false>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                            out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
+        hipLaunchKernelGGL(scatter_gap_kernel<true>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                           out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
+    }
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

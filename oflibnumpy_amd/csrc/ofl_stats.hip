@@ -36,18 +36,20 @@ void flow_stats_kernel(const float *__restrict__ flow, const uint8_t *__restrict
             m0 = (m & 0xffu) != 0; m1 = (m & 0xff00u) != 0;
         }
         bits |= stat_bits(f.x, f.y, m0, th) | stat_bits(f.z, f.w, m1, th);
+        if (!(m0 && m1)) bits |= OFL_STAT_MASK_HAS_ZERO;
         if (!finite2(f.x, f.y) || !finite2(f.z, f.w)) bits |= OFL_STAT_NONFINITE;
     }
     if ((n_px & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd tail pixel
         const size_t i = n_px - 1;
         const float u = flow[2 * i], v = flow[2 * i + 1];
         bits |= stat_bits(u, v, mask ? mask[i] != 0 : true, th);
+        if (mask && !mask[i]) bits |= OFL_STAT_MASK_HAS_ZERO;
         if (!finite2(u, v)) bits |= OFL_STAT_NONFINITE;
     }
     // wave OR via ballots, one LDS atomic per wave, one global atomic per workgroup
     uint32_t wbits = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) wbits |= (__ballot((bits >> k) & 1u) != 0ull) ? (1u << k) : 0u;
+    for (int k = 0; k < 6; ++k) wbits |= (__ballot((bits >> k) & 1u) != 0ull) ? (1u << k) : 0u;
     if ((threadIdx.x & 63) == 0 && wbits) atomicOr(&block_bits, wbits);
     __syncthreads();
     if (threadIdx.x == 0 && block_bits) {

@@ -197,6 +197,9 @@ def compose3_launch(fa, fb, sign, out, stats_buf=None, stats_offset=0, batch=1, 
                                       out.vecs.ptr, out.mask.ptr, sp, quant, stream))
 
 
+_STATS_KNOW_MASK = 1 << 30        # private flag in DeviceFlow._stats: STAT_MASK_HAS_ZERO has been evaluated
+
+
 # ------------------------------------------------------------------------------ DeviceFlow
 class DeviceFlow:
     """(vecs, mask, ref) resident in HBM.  Buffers are immutable once wrapped."""
@@ -239,7 +242,7 @@ class DeviceFlow:
     # -- predicates
     def stats(self):
         if self._stats is None:
-            self._stats = flow_stats(self.vecs, self.mask, self.n_px)
+            self._stats = flow_stats(self.vecs, self.mask, self.n_px) | _STATS_KNOW_MASK
         return self._stats
 
     def is_zero(self, thresholded=True, masked=True):
@@ -347,7 +350,7 @@ class DeviceFlow:
             return image, vmask
         out = DeviceImage(DeviceBuffer(self.n_px * C * 4), image.shape, np.float32)
         valid = DeviceBuffer(self.n_px)
-        scatter_linear(self.vecs, +1, self.mask if consider_mask else None, image.buf, C, vmask, h, w, None,
+        scatter_linear(self.vecs, +1, self._point_mask(consider_mask), image.buf, C, vmask, h, w, None,
                        out.buf, valid, 0)
         return out, valid
 
@@ -369,6 +372,16 @@ class DeviceFlow:
                                       self.n_px, scratch.ptr, out_mask.ptr, None))
         return DeviceFlow(scratch, out_mask, self.shape, self.ref)
 
+    def _point_mask(self, consider_mask=True):
+        """The point mask of utils.py:249-251 -- None when every point is kept (same result, and the scatter kernel then
+        skips its per-pixel search for dropped neighbours).  Only statistics that come from ofl_flow_stats know the
+        mask; predicates taken over from the compose kernel do not."""
+        if not consider_mask:
+            return None
+        if self._stats is None or not (self._stats & _STATS_KNOW_MASK):
+            self._stats = flow_stats(self.vecs, self.mask, self.n_px) | _STATS_KNOW_MASK
+        return self.mask if (self._stats & nat.STAT_MASK_HAS_ZERO) else None
+
     def _scatter_flow(self, target, consider_mask=True, sign=1):
         """'s'-reference apply of a Flow target: utils.py:237-258 + flow_class.py:634-643, 668."""
         if self.is_zero(thresholded=True, masked=False):
@@ -377,7 +390,7 @@ class DeviceFlow:
         out = DeviceFlow.empty(self.shape, target.ref)
         vmask = DeviceBuffer(self.n_px)
         _mask_and(target.mask, self.mask, vmask, self.n_px)      # mask channel, flow_class.py:643
-        scatter_linear(self.vecs, sign, self.mask if consider_mask else None, target.vecs, 2, vmask,
+        scatter_linear(self.vecs, sign, self._point_mask(consider_mask), target.vecs, 2, vmask,
                        h, w, None, out.vecs, out.mask, 0)
         return out
 
@@ -488,7 +501,7 @@ class DeviceFlow:
             return self.mask
         h, w = self.shape
         valid = DeviceBuffer(self.n_px)
-        scatter_linear(self.vecs, sign, self.mask if consider_mask else None, None, 0, self.mask,
+        scatter_linear(self.vecs, sign, self._point_mask(consider_mask), None, 0, self.mask,
                        h, w, None, None, valid, 0)
         return valid
 

@@ -522,3 +522,95 @@ def test_speckled_mask_with_dropped_corners(gpu, oracle):
     of.native.check(of.native.load().ofl_device_sync())
     assert time.perf_counter() - t0 < 0.02, "hull candidates were not filtered on the device"
     assert r.to_host()[1].mean() > 0.5
+
+
+def test_randomised_bands_masks_and_folds(gpu):
+    """Seeded sweep over ragged shapes (2 .. 90 x 2 .. 140), smooth / shifted / folded fields, random point and value
+    masks, 1-3 channels, both signs: the scatter result is finite, and row bands (1 .. 5 ranks) of the scatter AND of the
+    gather (uint8 / float32 / int16 images) concatenate to the full result bit for bit."""
+    of = gpu
+    from oflibnumpy_amd import device as dev, sharding
+    rng = np.random.default_rng(123)
+    n_ok = 0
+    for it in range(60):
+        h, w = int(rng.integers(2, 90)), int(rng.integers(2, 140))
+        yy, xx = np.mgrid[:h, :w].astype(np.float32)
+        amp = rng.uniform(0, 6)
+        vecs = np.stack([amp * np.sin(xx / rng.uniform(3, 30) + yy / rng.uniform(5, 40)), amp * np.cos(xx / rng.uniform(4, 25))], -1).astype(np.float32)
+        vecs += rng.uniform(-8, 8, 2).astype(np.float32)
+        if it % 4 == 0:
+            vecs[rng.random((h, w)) < 0.05] += 15          # discontinuities / folds
+        pm = None if it % 3 == 0 else (rng.random((h, w)) > rng.uniform(0, 0.5))
+        if pm is not None and pm.sum() < 3:
+            pm = None
+        vm = rng.random((h, w)) > 0.2
+        C = int(rng.integers(1, 4))
+        img = rng.random((h, w, C), dtype=np.float32)
+        f = dev.DeviceBuffer.from_host(vecs)
+        vals = dev.DeviceBuffer.from_host(img)
+        pmb = dev.DeviceBuffer.from_host(pm.astype(np.uint8)) if pm is not None else None
+        vmb = dev.DeviceBuffer.from_host(vm.astype(np.uint8))
+        out, valid = dev.DeviceBuffer(h * w * C * 4), dev.DeviceBuffer(h * w)
+        sign = 1 if it % 2 else -1
+        dev.scatter_linear(f, sign, pmb, vals, C, vmb, h, w, None, out, valid, 0)
+        full, fullv = out.to_host((h, w, C), np.float32), valid.to_host((h, w), np.uint8)
+        assert np.isfinite(full).all()
+        world = int(rng.integers(1, 6))
+        parts, vparts = [], []
+        for r in range(world):
+            r0, r1 = sharding.row_band(h, r, world)
+            if r1 <= r0:
+                continue
+            ob, vb = dev.DeviceBuffer((r1 - r0) * w * C * 4), dev.DeviceBuffer((r1 - r0) * w)
+            dev.scatter_rows(f, sign, pmb, vals, C, vmb, h, w, r0, r1 - r0, ob, vb)
+            parts.append(ob.to_host((r1 - r0, w, C), np.float32)); vparts.append(vb.to_host((r1 - r0, w), np.uint8))
+        assert np.array_equal(np.concatenate(parts), full), (it, h, w, world)
+        assert np.array_equal(np.concatenate(vparts), fullv), (it, h, w, world)
+        # gather bands, several dtypes
+        if w % 2 == 0:
+            for dt in (np.uint8, np.float32, np.int16):
+                im = (rng.random((h, w, C)) * 200).astype(dt)
+                dimg = dev.DeviceImage.from_host(im)
+                fm = dev.DeviceBuffer.from_host((rng.random((h, w)) > 0.1).astype(np.uint8))
+                fd, fv = dev.gather_bilinear(dimg, f, (h, w), -1, smask=vmb, fmask=fm, want_valid=True)
+                fd, fv = fd.to_host(), fv.to_host((h, w), np.uint8)
+                ps, vs = [], []
+                for r in range(world):
+                    r0, r1 = sharding.row_band(h, r, world)
+                    if r1 <= r0:
+                        continue
+                    fr = dev.DeviceBuffer.from_host(np.ascontiguousarray(vecs[r0:r1]))
+                    fmr = dev.DeviceBuffer.from_host(np.ascontiguousarray(fm.to_host((h, w), np.uint8)[r0:r1]))
+                    d, v = dev.gather_rows(dimg, r0, r1 - r0, fr, -1, smask=vmb, fmask_rows=fmr, want_valid=True)
+                    ps.append(d.to_host()); vs.append(v.to_host((r1 - r0, w), np.uint8))
+                assert np.array_equal(np.concatenate(ps), fd) and np.array_equal(np.concatenate(vs), fv), (it, h, w, dt)
+        n_ok += 1
+    assert n_ok == 60
+
+
+def test_randomised_masks_against_scipy(gpu, oracle):
+    """Seeded sweep against the SciPy oracle on small ragged shapes: similarity transforms with and without a smooth
+    non-affine term, speckled point masks: valid_target() and the mask of invert() -- hull membership, dropped points,
+    gap fill -- are bit-exact.  (valid_target(consider_mask=False) interpolates the speckled mask VALUES, which depends
+    on the Delaunay diagonal of co-circular cells -- deviation (a) -- and is covered by the reference-output tests.)"""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(321)
+    for it in range(45):
+        h, w = int(rng.integers(6, 60)), int(rng.integers(6, 80))
+        kind = it % 3
+        if kind == 0:
+            tr = [['rotation', rng.uniform(0, w), rng.uniform(0, h), rng.uniform(-40, 40)], ['scaling', rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0.7, 1.3)]]
+        elif kind == 1:
+            tr = [['translation', rng.uniform(-6, 6), rng.uniform(-6, 6)], ['scaling', rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0.8, 1.2)]]
+        else:
+            tr = [['rotation', w / 2, h / 2, rng.uniform(-15, 15)]]
+        m = rng.random((h, w)) > rng.uniform(0, 0.2)
+        if it % 5 == 0:
+            m[:] = True
+        f = of.Flow.from_transforms(tr, [h, w], 's', m)
+        if it % 2:
+            yy, xx = np.mgrid[:h, :w].astype(np.float32)
+            f = of.Flow(f.vecs + np.stack([0.4 * np.sin(xx / 9) * np.cos(yy / 7), 0.3 * np.cos(xx / 8)], -1).astype(np.float32), 's', m)
+        o = O.OFlow(f.vecs, 's', m)
+        np.testing.assert_array_equal(f.valid_target(), o.valid_target(), err_msg=str((it, h, w, tr)))
+        np.testing.assert_array_equal(f.invert().mask, o.invert().mask, err_msg=str((it, h, w, tr)))

@@ -35,6 +35,7 @@ namespace {
 constexpr uint32_t kNoOwner   = 0xFFFFFFFFu;
 constexpr uint32_t kGapOwner  = 0xFFFFFFFEu;                     // owner-map marker: uncovered node inside the hull (pass 2b)
 constexpr uint32_t kGapFar    = 0xFFFFFFFDu;                     // ... whose 5 x 5 neighbourhood is uncovered too (pass 2c)
+constexpr uint32_t kGapDone   = 0xFFFFFFFCu;                     // ... that a gap pass has filled (not a seed for other gap nodes)
 constexpr double   kEps       = 100.0 * 2.220446049250313e-16;   // scipy _qhull: eps = 100 * DBL_EPSILON
 constexpr int      kSmallArea = 1024;                             // bbox nodes scanned inside the raster kernel (lane or wave)
 #ifndef OFL_SC_COOP
@@ -42,7 +43,7 @@ constexpr int      kSmallArea = 1024;                             // bbox nodes 
 #endif
 constexpr int      kCoopMinArea = 64;                             // smallest bbox a whole wave scans together
 // the big-triangle list holds every triangle of the mesh if need be (a field that magnifies 30x makes ALL of them big)
-inline long long big_cap_for(int H, int W) { return 2ll * (H > 1 ? H - 1 : 1) * (W > 1 ? W - 1 : 1); }
+inline long long big_cap_for(int H, int W) { return 2ll * H * W; }      // >= all triangles; doubles as two node-sized maps (deep gap fill)
 constexpr int      kCandCap   = 1 << 22;                          // hull candidates kept on the device
 constexpr int      kHullCap   = 1 << 16;                          // vertices per hull chain
 constexpr int      kFillRadius = 16;                              // how far an uncovered node looks for a covered one
@@ -57,7 +58,7 @@ struct ScatterWs {          // layout of the caller-provided workspace
     D2       *cand;         // [cand_cap] positions of mesh-boundary points (convex-hull candidates)
     D2       *lower;        // [kHullCap] lower hull chain, x ascending
     D2       *upper;        // [kHullCap] upper hull chain, x ascending
-    unsigned long long *counters;   // [1] big-list length, [2] big-list work, [3] candidates
+    unsigned long long *counters;   // [1] big-list length, [2] big-list work, [3] candidates, [5] gap nodes beyond the ring search
     unsigned long long *kept_slots; // [256] partial counts of kept points
     const D2 *guard;        // [4] warped kept points next to the four image corners (header bytes 64..127) ...
     const int *guard_ok;    // ... and whether all four exist (header byte 128)
@@ -501,13 +502,13 @@ __device__ __forceinline__ uint32_t nearest_owner(const uint32_t *owner, int y_l
         return (xx >= 0 && xx < W && yy >= y_lo && yy < y_hi) ? owner[(size_t)yy * W + xx] : kNoOwner;
     };
     auto take = [&](uint32_t id, int xx, int yy) {
-        if (id >= kGapFar) return;
+        if (id >= kGapDone) return;
         const double d = (xx - qx) * (xx - qx) + (yy - qy) * (yy - qy);
         if (d < bestd || (d == bestd && id < best)) { bestd = d; best = id; }
     };
     if (RINGS != 2) {
         const uint32_t id = probe(cx, cy);
-        if (id < kGapFar) return id;
+        if (id < kGapDone) return id;
     }
     // the ring as four runs of 2 r nodes -- top (dx = -r .. r-1, dy = -r), bottom (dx = -r+1 .. r, dy = r), left
     // (dx = -r, dy = -r+1 .. r), right (dx = r, dy = -r .. r-1): every node once; B nodes of each run per round trip
@@ -741,6 +742,11 @@ void scatter_gap_kernel(const float *__restrict__ flow, int sign,
     double c0, c1, c2;
     if (fill_from_nearest<FAR ? 2 : 1>(flow, sign, H, W, ws, hull, (double)x, (double)y, id, vi, vp, c0, c1, c2)) {
         resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, (size_t)yl * W + x);
+        ws.owner[(size_t)y * W + x] = kGapDone;
+        return;
+    }
+    if (FAR) {
+        ws.counters[5] = 1ull;          // plain idempotent store: "some gap node is deeper than the ring search reaches"
         return;
     }
     if (!FAR) {
@@ -752,7 +758,69 @@ void scatter_gap_kernel(const float *__restrict__ flow, int sign,
         for (int by = by0; by <= by1 && !any; ++by)
             for (int bx = bx0; bx <= bx1 && !any; ++bx) any = ws.coarse[(size_t)by * ws.coarse_w + bx] != 0;
         if (any) ws.owner[(size_t)y * W + x] = kGapFar;
+        else ws.counters[5] = 1ull;
     }
+}
+
+// Pass 2d (only when a gap node lies deeper than kFillRadius inside a hole of the point mask -- SciPy bridges such holes
+// with long triangles and reports them valid): the nearest covered node of EVERY node by jump flooding (log2(size)
+// passes over two node-sized maps in the large-triangle list), then the remaining gap nodes continue the triangle of
+// their nearest covered node like the ring search does.  Ties: smaller squared distance, then smaller node index.
+constexpr uint32_t kNoSeed = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(256)
+void scatter_jfa_init_kernel(const uint32_t *__restrict__ owner, uint32_t *__restrict__ seed, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) seed[i] = owner[i] < kGapDone ? (uint32_t)i : kNoSeed;
+}
+
+__global__ __launch_bounds__(256)
+void scatter_jfa_step_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ outs, int H, int W, int step)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    uint32_t best = in[(size_t)y * W + x];
+    long long bestd = 0x7fffffffffffffffll;
+    if (best != kNoSeed) { const int sy = (int)(best / (uint32_t)W), sx = (int)(best - (uint32_t)sy * (uint32_t)W); bestd = (long long)(sx - x) * (sx - x) + (long long)(sy - y) * (sy - y); }
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            const int xx = x + dx * step, yy = y + dy * step;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const uint32_t c = in[(size_t)yy * W + xx];
+            if (c == kNoSeed) continue;
+            const int sy = (int)(c / (uint32_t)W), sx = (int)(c - (uint32_t)sy * (uint32_t)W);
+            const long long d = (long long)(sx - x) * (sx - x) + (long long)(sy - y) * (sy - y);
+            if (d < bestd || (d == bestd && c < best)) { bestd = d; best = c; }
+        }
+    outs[(size_t)y * W + x] = best;
+}
+
+__global__ __launch_bounds__(256)
+void scatter_deep_kernel(const float *__restrict__ flow, int sign,
+                         const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                         int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
+                         ScatterWs ws, const uint32_t *__restrict__ seed, int row0, int rows)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
+    if (x >= W || yl >= rows) return;
+    const uint32_t mark = ws.owner[(size_t)y * W + x];
+    if (mark != kGapOwner && mark != kGapFar) return;
+    const uint32_t sd = seed[(size_t)y * W + x];
+    if (sd == kNoSeed) return;
+    const uint32_t id = ws.owner[sd];
+    size_t vi[3];
+    D2 vp[3];
+    double c0, c1, c2;
+    tri_decode(id, flow, sign, W, vi, vp);
+    (void)bary(vp[0], vp[1], vp[2], (double)x, (double)y, c0, c1, c2);
+    const double e1x = vp[1].x - vp[0].x, e1y = vp[1].y - vp[0].y, e2x = vp[2].x - vp[0].x, e2y = vp[2].y - vp[0].y;
+    if ((e1x * e2y - e1y * e2x) == 0.0) return;
+    resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, (size_t)yl * W + x);
 }
 
 // pass 2 for arbitrary sample positions (query != NULL; mode 2 / ref 't', flow_class.py:1398-1410): the triangle
@@ -1002,6 +1070,40 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
 
 extern "C" {
 
+// the gap passes after scatter_resolve_grid_kernel (grid mode): near, far, and -- when the device reports nodes deeper
+// than the ring search reaches -- the jump-flooding fill.  Only a point mask can produce such nodes, and only then is
+// the flag read back (one more host synchronisation).
+static int scatter_fill_gaps(const float *flow, int sign, const uint8_t *pmask, const float *vals, int C, const uint8_t *vmask,
+                             int H, int W, float *out, uint8_t *valid, int valid_rule, const ScatterWs &ws, const HullRef &hull,
+                             int row0, int rows, hipStream_t s)
+{
+    if (hull.n_lower <= 0) return OFL_OK;
+    const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
+    hipLaunchKernelGGL(scatter_gap_kernel<false>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                       out, valid, valid_rule, ws, hull, row0, rows);
+    hipLaunchKernelGGL(scatter_gap_kernel<true>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                       out, valid, valid_rule, ws, hull, row0, rows);
+    OFL_HIP(hipGetLastError());
+    if (!pmask || ws.oy0 != 0 || ws.oy1 != H || ws.big_cap < 2ull * (unsigned long long)H * W) return OFL_OK;
+    unsigned long long deep = 0;
+    OFL_HIP(hipMemcpyAsync(&deep, ws.counters + 5, sizeof(deep), hipMemcpyDeviceToHost, s));
+    OFL_HIP(hipStreamSynchronize(s));
+    if (!deep) return OFL_OK;
+    const size_t n = (size_t)H * W;
+    uint32_t *a = ws.big, *b = ws.big + n;
+    hipLaunchKernelGGL(scatter_jfa_init_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, s, ws.owner, a, n);
+    int step = 1;
+    while (step * 2 < std::max(H, W)) step *= 2;
+    const dim3 full((W + 31) / 32, (H + 7) / 8);
+    for (; step >= 1; step /= 2) {
+        hipLaunchKernelGGL(scatter_jfa_step_kernel, full, block, 0, s, a, b, H, W, step);
+        std::swap(a, b);
+    }
+    hipLaunchKernelGGL(scatter_deep_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W, out, valid, valid_rule, ws, a, row0, rows);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
 int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                            const float *vals, int C, const uint8_t *vmask, int H, int W,
                            const float *query, float *out, uint8_t *valid, int valid_rule,
@@ -1025,13 +1127,8 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     } else {
         hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                            out, valid, valid_rule, ws, hull, 0, H);
-        if (hull.n_lower > 0)
-        {
-            hipLaunchKernelGGL(scatter_gap_kernel<false>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                               out, valid, valid_rule, ws, hull, 0, H);
-            hipLaunchKernelGGL(scatter_gap_kernel<true>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                               out, valid, valid_rule, ws, hull, 0, H);
-        }
+        OFL_HIP(hipGetLastError());
+        return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out, valid, valid_rule, ws, hull, 0, H, s);
     }
     OFL_HIP(hipGetLastError());
     return OFL_OK;
@@ -1054,21 +1151,15 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
     hipStream_t s = stream_of(stream);
     ScatterWs ws;
     HullRef hull;
-    // owners are needed for the band and, for the gap fill, kFillRadius rows around it
-    const int oy0 = std::max(0, row0 - kFillRadius), oy1 = std::min(H, row0 + rows + kFillRadius);
+    // owners are needed for the band and, for the gap fill, kFillRadius rows around it -- or everywhere when a point
+    // mask may leave holes deeper than that (the deep fill looks for the nearest covered node of the whole field)
+    const int oy0 = pmask ? 0 : std::max(0, row0 - kFillRadius), oy1 = pmask ? H : std::min(H, row0 + rows + kFillRadius);
     OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull, oy0, oy1));
     const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                        out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
-    if (hull.n_lower > 0)
-    {
-        hipLaunchKernelGGL(scatter_gap_kernel<false>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                           out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
-        hipLaunchKernelGGL(scatter_gap_kernel<true>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                           out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
-    }
     OFL_HIP(hipGetLastError());
-    return OFL_OK;
+    return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out_rows, valid_rows, valid_rule, ws, hull, row0, rows, s);
 }
 
 // Sparse queries (point tracking, utils.py:610-615): the triangle containing each of n_query points

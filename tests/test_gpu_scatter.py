@@ -614,3 +614,42 @@ def test_randomised_masks_against_scipy(gpu, oracle):
         o = O.OFlow(f.vecs, 's', m)
         np.testing.assert_array_equal(f.valid_target(), o.valid_target(), err_msg=str((it, h, w, tr)))
         np.testing.assert_array_equal(f.invert().mask, o.invert().mask, err_msg=str((it, h, w, tr)))
+
+
+def test_large_hole_in_point_mask_matches_scipy(gpu, oracle):
+    """A hole of the point mask much wider than the ring search (70 x 100 px in 160 x 220): SciPy bridges it with long
+    triangles and reports the bridged nodes valid; the kernel finds the nearest covered node of the deep nodes by jump
+    flooding and continues its triangle.  Masks are bit-exact; an affine field is reproduced across the hole; row bands
+    still concatenate to the full result."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev, sharding
+    shape = (160, 220)
+    m = np.ones(shape, bool)
+    m[40:110, 60:160] = False
+    m[5:9, 200:215] = False                                      # and a shallow one
+    for tr in ([['rotation', 100, 70, 12], ['scaling', 30, 40, 0.95]], [['translation', 4.5, -3.25]]):
+        f = of.Flow.from_transforms(tr, shape, 's', m)
+        o = O.OFlow(f.vecs, 's', m)
+        np.testing.assert_array_equal(f.valid_target(), o.valid_target())
+        got, want = f.invert(), o.invert()
+        np.testing.assert_array_equal(got.mask, want.mask)
+        assert got.mask[60:90, 90:130].all()                      # the middle of the hole is bridged
+        np.testing.assert_allclose(got.vecs[got.mask], want.vecs[got.mask], rtol=1e-4, atol=2e-4)
+    # bands vs full with the deep fill
+    rng = np.random.default_rng(4)
+    h, w = shape
+    img = rng.random((h, w, 2), dtype=np.float32)
+    fb, vals = dev.DeviceBuffer.from_host(f.vecs), dev.DeviceBuffer.from_host(img)
+    pm = dev.DeviceBuffer.from_host(m.astype(np.uint8))
+    out, valid = dev.DeviceBuffer(h * w * 8), dev.DeviceBuffer(h * w)
+    dev.scatter_linear(fb, +1, pm, vals, 2, pm, h, w, None, out, valid, 0)
+    full, fullv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8)
+    parts, vparts = [], []
+    for r in range(4):
+        r0, r1 = sharding.row_band(h, r, 4)
+        ob, vb = dev.DeviceBuffer((r1 - r0) * w * 8), dev.DeviceBuffer((r1 - r0) * w)
+        dev.scatter_rows(fb, +1, pm, vals, 2, pm, h, w, r0, r1 - r0, ob, vb)
+        parts.append(ob.to_host((r1 - r0, w, 2), np.float32)); vparts.append(vb.to_host((r1 - r0, w), np.uint8))
+    np.testing.assert_array_equal(np.concatenate(parts), full)
+    np.testing.assert_array_equal(np.concatenate(vparts), fullv)
+    assert fullv[60:90, 90:130].all()

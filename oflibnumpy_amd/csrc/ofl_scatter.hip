@@ -58,7 +58,7 @@ struct ScatterWs {          // layout of the caller-provided workspace
     D2       *cand;         // [cand_cap] positions of mesh-boundary points (convex-hull candidates)
     D2       *lower;        // [kHullCap] lower hull chain, x ascending
     D2       *upper;        // [kHullCap] upper hull chain, x ascending
-    unsigned long long *counters;   // [1] big-list length, [2] big-list work, [3] candidates, [5] gap nodes beyond the ring search
+    unsigned long long *counters;   // [1] big-list length, [2] big-list work, [3] candidates, [5] gap nodes beyond the ring search, [6..7] their bounding box
     unsigned long long *kept_slots; // [256] partial counts of kept points
     const D2 *guard;        // [4] warped kept points next to the four image corners (header bytes 64..127) ...
     const int *guard_ok;    // ... and whether all four exist (header byte 128)
@@ -690,13 +690,16 @@ __global__ __launch_bounds__(256)
 void scatter_resolve_grid_kernel(const float *__restrict__ flow, int sign,
                                  const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
                                  int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
-                                 ScatterWs ws, HullRef hull, int row0, int rows)
+                                 ScatterWs ws, HullRef hull, int row0, int rows, int er0, int erows)
 {
-    // rows [row0, row0 + rows) of the grid are resolved; out / valid hold those rows only
+    // rows [row0, row0 + rows) of the grid are resolved; out / valid hold rows [er0, er0 + erows) only (the two ranges
+    // differ for a row band under a point mask: gap nodes are then marked over the whole field, exactly as the
+    // single-GPU call marks them, and only the band is written)
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
     const bool act = x < W && yl < rows;
-    const size_t o = (size_t)yl * W + x;
+    const bool emit = (unsigned)(y - er0) < (unsigned)erows;
+    const size_t o = (size_t)(y - er0) * W + x;
     const uint32_t id = act ? ws.owner[(size_t)y * W + x] : 0u;
     bool gap = false;
     if (act) {
@@ -706,10 +709,12 @@ void scatter_resolve_grid_kernel(const float *__restrict__ flow, int sign,
             double c0, c1, c2;
             tri_decode(id, flow, sign, W, vi, vp);
             (void)bary(vp[0], vp[1], vp[2], (double)x, (double)y, c0, c1, c2);
-            resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
+            if (emit) resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
         } else {
-            for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;
-            if (valid) valid[o] = 0;
+            if (emit) {
+                for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;
+                if (valid) valid[o] = 0;
+            }
             gap = hull.n_lower > 0 && inside_hull(hull, (double)x, (double)y);
         }
     }
@@ -724,6 +729,8 @@ void scatter_resolve_grid_kernel(const float *__restrict__ flow, int sign,
     if (gap) ws.owner[(size_t)y * W + x] = kGapOwner;
 }
 
+__device__ __forceinline__ void note_deep_node(const ScatterWs &ws, int x, int y, int H, int W);
+
 // pass 2b / 2c: the marked gap nodes.  FAR = false looks at rings 0 .. 2 (isolated dropped points: a lean kernel at full
 // occupancy) and re-marks what it could not fill; FAR = true searches rings 3 .. 16 for those (rims of holes).
 template <bool FAR>
@@ -731,22 +738,23 @@ __global__ __launch_bounds__(256)
 void scatter_gap_kernel(const float *__restrict__ flow, int sign,
                         const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
                         int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
-                        ScatterWs ws, HullRef hull, int row0, int rows)
+                        ScatterWs ws, HullRef hull, int row0, int rows, int er0, int erows)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
     if (x >= W || yl >= rows || ws.owner[(size_t)y * W + x] != (FAR ? kGapFar : kGapOwner)) return;
+    const bool emit = (unsigned)(y - er0) < (unsigned)erows;
     uint32_t id;
     size_t vi[3];
     D2 vp[3];
     double c0, c1, c2;
     if (fill_from_nearest<FAR ? 2 : 1>(flow, sign, H, W, ws, hull, (double)x, (double)y, id, vi, vp, c0, c1, c2)) {
-        resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, (size_t)yl * W + x);
+        if (emit) resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, (size_t)(y - er0) * W + x);
         ws.owner[(size_t)y * W + x] = kGapDone;
         return;
     }
     if (FAR) {
-        ws.counters[5] = 1ull;          // plain idempotent store: "some gap node is deeper than the ring search reaches"
+        note_deep_node(ws, x, y, H, W);
         return;
     }
     if (!FAR) {
@@ -758,8 +766,21 @@ void scatter_gap_kernel(const float *__restrict__ flow, int sign,
         for (int by = by0; by <= by1 && !any; ++by)
             for (int bx = bx0; bx <= bx1 && !any; ++bx) any = ws.coarse[(size_t)by * ws.coarse_w + bx] != 0;
         if (any) ws.owner[(size_t)y * W + x] = kGapFar;
-        else ws.counters[5] = 1ull;
+        else note_deep_node(ws, x, y, H, W);
     }
+}
+
+// a gap node the ring search cannot reach: raise the flag and grow the bounding box of such nodes (four running maxima
+// in the header -- W-1-x, H-1-y, x, y -- so that the zeroed header is the empty box; the atomic is only issued when it
+// would change the box, which after the first few nodes it rarely does)
+__device__ __forceinline__ void note_deep_node(const ScatterWs &ws, int x, int y, int H, int W)
+{
+    ws.counters[5] = 1ull;
+    int *box = reinterpret_cast<int *>(ws.counters + 6);
+    const int v[4] = { W - 1 - x, H - 1 - y, x, y };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (__hip_atomic_load(box + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v[k]) atomicMax(box + k, v[k]);
 }
 
 // Pass 2d (only when a gap node lies deeper than kFillRadius inside a hole of the point mask -- SciPy bridges such holes
@@ -768,19 +789,24 @@ void scatter_gap_kernel(const float *__restrict__ flow, int sign,
 // their nearest covered node like the ring search does.  Ties: smaller squared distance, then smaller node index.
 constexpr uint32_t kNoSeed = 0xFFFFFFFFu;
 
+// the maps cover the rectangle [bx0, bx0 + bw) x [by0, by0 + bh) of the grid (the bounding box of the deep nodes plus
+// kFillRadius + 2 nodes: the nearest covered node of a node inside a hole lies on the rim of that hole); seeds are GLOBAL node ids
 __global__ __launch_bounds__(256)
-void scatter_jfa_init_kernel(const uint32_t *__restrict__ owner, uint32_t *__restrict__ seed, size_t n)
+void scatter_jfa_init_kernel(const uint32_t *__restrict__ owner, uint32_t *__restrict__ seed, int W, int bx0, int by0, int bw, int bh)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) seed[i] = owner[i] < kGapDone ? (uint32_t)i : kNoSeed;
+    const int lx = blockIdx.x * 32 + (threadIdx.x & 31), ly = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (lx >= bw || ly >= bh) return;
+    const uint32_t g = (uint32_t)((size_t)(by0 + ly) * W + (bx0 + lx));
+    seed[(size_t)ly * bw + lx] = owner[g] < kGapDone ? g : kNoSeed;
 }
 
 __global__ __launch_bounds__(256)
-void scatter_jfa_step_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ outs, int H, int W, int step)
+void scatter_jfa_step_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ outs, int W, int bx0, int by0, int bw, int bh, int step)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    uint32_t best = in[(size_t)y * W + x];
+    const int lx = blockIdx.x * 32 + (threadIdx.x & 31), ly = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (lx >= bw || ly >= bh) return;
+    const int x = bx0 + lx, y = by0 + ly;
+    uint32_t best = in[(size_t)ly * bw + lx];
     long long bestd = 0x7fffffffffffffffll;
     if (best != kNoSeed) { const int sy = (int)(best / (uint32_t)W), sx = (int)(best - (uint32_t)sy * (uint32_t)W); bestd = (long long)(sx - x) * (sx - x) + (long long)(sy - y) * (sy - y); }
 #pragma unroll
@@ -788,29 +814,30 @@ void scatter_jfa_step_kernel(const uint32_t *__restrict__ in, uint32_t *__restri
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             if (dx == 0 && dy == 0) continue;
-            const int xx = x + dx * step, yy = y + dy * step;
-            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const uint32_t c = in[(size_t)yy * W + xx];
+            const int xx = lx + dx * step, yy = ly + dy * step;
+            if (xx < 0 || xx >= bw || yy < 0 || yy >= bh) continue;
+            const uint32_t c = in[(size_t)yy * bw + xx];
             if (c == kNoSeed) continue;
             const int sy = (int)(c / (uint32_t)W), sx = (int)(c - (uint32_t)sy * (uint32_t)W);
             const long long d = (long long)(sx - x) * (sx - x) + (long long)(sy - y) * (sy - y);
             if (d < bestd || (d == bestd && c < best)) { bestd = d; best = c; }
         }
-    outs[(size_t)y * W + x] = best;
+    outs[(size_t)ly * bw + lx] = best;
 }
 
 __global__ __launch_bounds__(256)
 void scatter_deep_kernel(const float *__restrict__ flow, int sign,
                          const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
                          int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
-                         ScatterWs ws, const uint32_t *__restrict__ seed, int row0, int rows)
+                         ScatterWs ws, const uint32_t *__restrict__ seed, int row0, int rows, int bx0, int by0, int bw, int bh)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
     if (x >= W || yl >= rows) return;
+    if (x < bx0 || x >= bx0 + bw || y < by0 || y >= by0 + bh) return;
     const uint32_t mark = ws.owner[(size_t)y * W + x];
     if (mark != kGapOwner && mark != kGapFar) return;
-    const uint32_t sd = seed[(size_t)y * W + x];
+    const uint32_t sd = seed[(size_t)(y - by0) * bw + (x - bx0)];
     if (sd == kNoSeed) return;
     const uint32_t id = ws.owner[sd];
     size_t vi[3];
@@ -1075,31 +1102,38 @@ extern "C" {
 // the flag read back (one more host synchronisation).
 static int scatter_fill_gaps(const float *flow, int sign, const uint8_t *pmask, const float *vals, int C, const uint8_t *vmask,
                              int H, int W, float *out, uint8_t *valid, int valid_rule, const ScatterWs &ws, const HullRef &hull,
-                             int row0, int rows, hipStream_t s)
+                             int row0, int rows, int er0, int erows, hipStream_t s)
 {
     if (hull.n_lower <= 0) return OFL_OK;
-    const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
-    hipLaunchKernelGGL(scatter_gap_kernel<false>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                       out, valid, valid_rule, ws, hull, row0, rows);
-    hipLaunchKernelGGL(scatter_gap_kernel<true>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                       out, valid, valid_rule, ws, hull, row0, rows);
+    const dim3 pgrid((W + 31) / 32, (rows + 7) / 8), grid((W + 31) / 32, (erows + 7) / 8), block(256);
+    hipLaunchKernelGGL(scatter_gap_kernel<false>, pgrid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                       out, valid, valid_rule, ws, hull, row0, rows, er0, erows);
+    hipLaunchKernelGGL(scatter_gap_kernel<true>, pgrid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                       out, valid, valid_rule, ws, hull, row0, rows, er0, erows);
     OFL_HIP(hipGetLastError());
     if (!pmask || ws.oy0 != 0 || ws.oy1 != H || ws.big_cap < 2ull * (unsigned long long)H * W) return OFL_OK;
-    unsigned long long deep = 0;
-    OFL_HIP(hipMemcpyAsync(&deep, ws.counters + 5, sizeof(deep), hipMemcpyDeviceToHost, s));
+    unsigned long long head[4] = { 0, 0, 0, 0 };           // [0] flag, [1..2] the four box maxima as ints
+    OFL_HIP(hipMemcpyAsync(head, ws.counters + 5, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     OFL_HIP(hipStreamSynchronize(s));
-    if (!deep) return OFL_OK;
-    const size_t n = (size_t)H * W;
+    if (!head[0]) return OFL_OK;
+    const int *enc = reinterpret_cast<const int *>(head + 1);
+    // the deep nodes start kFillRadius + 1 nodes inside their hole: the covered rim is that far outside their box
+    const int rim = kFillRadius + 2;
+    const int bx0 = std::max(W - 1 - enc[0] - rim, 0), by0 = std::max(H - 1 - enc[1] - rim, 0);
+    const int bx1 = std::min(enc[2] + rim, W - 1), by1 = std::min(enc[3] + rim, H - 1);
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    const size_t n = (size_t)bw * bh;
     uint32_t *a = ws.big, *b = ws.big + n;
-    hipLaunchKernelGGL(scatter_jfa_init_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, s, ws.owner, a, n);
+    const dim3 sub((bw + 31) / 32, (bh + 7) / 8);
+    hipLaunchKernelGGL(scatter_jfa_init_kernel, sub, block, 0, s, ws.owner, a, W, bx0, by0, bw, bh);
     int step = 1;
-    while (step * 2 < std::max(H, W)) step *= 2;
-    const dim3 full((W + 31) / 32, (H + 7) / 8);
+    while (step * 2 < std::max(bw, bh)) step *= 2;
     for (; step >= 1; step /= 2) {
-        hipLaunchKernelGGL(scatter_jfa_step_kernel, full, block, 0, s, a, b, H, W, step);
+        hipLaunchKernelGGL(scatter_jfa_step_kernel, sub, block, 0, s, a, b, W, bx0, by0, bw, bh, step);
         std::swap(a, b);
     }
-    hipLaunchKernelGGL(scatter_deep_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W, out, valid, valid_rule, ws, a, row0, rows);
+    hipLaunchKernelGGL(scatter_deep_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W, out, valid, valid_rule, ws, a, er0, erows,
+                       bx0, by0, bw, bh);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }
@@ -1126,9 +1160,9 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
                            out, valid, valid_rule, ws, hull);
     } else {
         hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                           out, valid, valid_rule, ws, hull, 0, H);
+                           out, valid, valid_rule, ws, hull, 0, H, 0, H);
         OFL_HIP(hipGetLastError());
-        return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out, valid, valid_rule, ws, hull, 0, H, s);
+        return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out, valid, valid_rule, ws, hull, 0, H, 0, H, s);
     }
     OFL_HIP(hipGetLastError());
     return OFL_OK;
@@ -1155,11 +1189,13 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
     // mask may leave holes deeper than that (the deep fill looks for the nearest covered node of the whole field)
     const int oy0 = pmask ? 0 : std::max(0, row0 - kFillRadius), oy1 = pmask ? H : std::min(H, row0 + rows + kFillRadius);
     OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull, oy0, oy1));
-    const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
+    // with a point mask the passes run over the whole field and only WRITE the band (see scatter_resolve_grid_kernel)
+    const int pr0 = pmask ? 0 : row0, prows = pmask ? H : rows;
+    const dim3 grid((W + 31) / 32, (prows + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                       out_rows, valid_rows, valid_rule, ws, hull, row0, rows);
+                       out_rows, valid_rows, valid_rule, ws, hull, pr0, prows, row0, rows);
     OFL_HIP(hipGetLastError());
-    return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out_rows, valid_rows, valid_rule, ws, hull, row0, rows, s);
+    return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out_rows, valid_rows, valid_rule, ws, hull, pr0, prows, row0, rows, s);
 }
 
 // Sparse queries (point tracking, utils.py:610-615): the triangle containing each of n_query points

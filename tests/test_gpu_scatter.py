@@ -596,7 +596,7 @@ def test_randomised_masks_against_scipy(gpu, oracle):
     of, O = gpu, oracle
     rng = np.random.default_rng(321)
     for it in range(45):
-        h, w = int(rng.integers(6, 60)), int(rng.integers(6, 80))
+        h, w = int(rng.integers(6, 120)), int(rng.integers(6, 160))
         kind = it % 3
         if kind == 0:
             tr = [['rotation', rng.uniform(0, w), rng.uniform(0, h), rng.uniform(-40, 40)], ['scaling', rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0.7, 1.3)]]
@@ -607,6 +607,10 @@ def test_randomised_masks_against_scipy(gpu, oracle):
         m = rng.random((h, w)) > rng.uniform(0, 0.2)
         if it % 5 == 0:
             m[:] = True
+        if it % 4 == 1:                                 # a rectangular hole, possibly deeper than the ring search
+            hh, hw = int(rng.integers(2, max(3, h // 2))), int(rng.integers(2, max(3, w // 2)))
+            y0, x0 = int(rng.integers(1, h - hh)), int(rng.integers(1, w - hw))
+            m[y0:y0 + hh, x0:x0 + hw] = False
         f = of.Flow.from_transforms(tr, [h, w], 's', m)
         if it % 2:
             yy, xx = np.mgrid[:h, :w].astype(np.float32)

@@ -101,6 +101,12 @@ def main():
     ds.stats()
     t = timed(lambda: ds.invert(), it)
     report("invert s->s, 5 % random invalid points incl. a corner (K3)", (h, w), 18, *t, note="points dropped (consider_mask), gaps filled")
+    hole = np.ones((h, w), bool)
+    hole[500:900, 1000:1800] = False
+    dh = dev.DeviceFlow.from_host(f3.vecs, 's', hole)
+    dh.stats()
+    t = timed(lambda: dh.invert(), it)
+    report("invert s->s, 400 x 800 hole in the point mask (K3)", (h, w), 18, *t, note="hole bridged: ring search + jump flooding for the deep nodes")
 
     # K6: Flow.resize of the 4K field: 9 B per source px read + 9 B per output px written
     for scale in (0.5, 2, 1.5):

@@ -202,6 +202,14 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
                            const float *vals, int C, const uint8_t *vmask, int H, int W,
                            const float *query, float *out, uint8_t *valid, int valid_rule,
                            void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
+/* The same for float64 values at the grid nodes (no query positions): griddata interpolates in float64 and
+ * apply_flow returns result.astype(target.dtype) (utils.py:253-258), so a float64 image keeps its precision.
+ */
+int ofl_scatter_linear_f64_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                               const double *vals, int C, const uint8_t *vmask, int H, int W,
+                               double *out, uint8_t *valid, int valid_rule,
+                               void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
+
 /* One row band of the grid result (SURVEY 8e, config 5 as loaded, ref 's'): every rank holds the full inputs
  * (flow, masks, values are replicated), rasterises only the triangles that reach rows
  * [row0 - 16, row0 + rows + 16) and resolves rows [row0, row0 + rows): out_rows [rows][W][C],

@@ -68,6 +68,7 @@ SIGNATURES = {
     "ofl_flow_stats_dev": (_ci, [_vp, _vp, _cs, _cf, _vp, _vp]),
     "ofl_flow_stats": (_ci, [_vp, _vp, _cs, _cf, _vp]),
     "ofl_axpy_dev": (_ci, [_vp, _vp, _vp, _vp, _cf, _cs, _vp, _vp, _vp]),
+    "ofl_scatter_linear_f64_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_rows_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_linear_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_workspace_bytes": (_ci, [_ci, _ci, _ci, ctypes.POINTER(_cs)]),

@@ -663,13 +663,14 @@ void scatter_query_kernel(const float *__restrict__ flow, int sign, const uint8_
 }
 
 // values and validity of one output element from its triangle (vi) and barycentric coordinates
-__device__ __forceinline__ void resolve_emit(const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+template <typename VT>      // float, or double for float64 targets (griddata's own precision, utils.py:253)
+__device__ __forceinline__ void resolve_emit(const VT *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
                                              const size_t (&vi)[3], double c0, double c1, double c2, int valid_rule,
-                                             float *__restrict__ out, uint8_t *__restrict__ valid, size_t o)
+                                             VT *__restrict__ out, uint8_t *__restrict__ valid, size_t o)
 {
     for (int c = 0; c < C; ++c) {
         const double v = c0 * (double)vals[vi[0] * C + c] + c1 * (double)vals[vi[1] * C + c] + c2 * (double)vals[vi[2] * C + c];
-        out[o * C + c] = (float)((valid_rule & OFL_SCATTER_ROUND) ? rint(v) : v);      // np.round of the float64 result, utils.py:256-257
+        out[o * C + c] = (VT)((valid_rule & OFL_SCATTER_ROUND) ? rint(v) : v);      // np.round of the float64 result, utils.py:256-257
     }
     if (valid) {
         double m = 1.0;
@@ -686,10 +687,11 @@ __device__ __forceinline__ void resolve_emit(const float *__restrict__ vals, int
 // triangles between border vertices; those nodes are queued for pass 2b, which continues the linear function of
 // the nearest cell triangle into them (identical for data that is affine across the gap).  Keeping the rare search
 // out of this kernel keeps it at 8 waves per SIMD.
+template <typename VT>
 __global__ __launch_bounds__(256)
 void scatter_resolve_grid_kernel(const float *__restrict__ flow, int sign,
-                                 const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
-                                 int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
+                                 const VT *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                                 int H, int W, VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
                                  ScatterWs ws, HullRef hull, int row0, int rows, int er0, int erows)
 {
     // rows [row0, row0 + rows) of the grid are resolved; out / valid hold rows [er0, er0 + erows) only (the two ranges
@@ -712,7 +714,7 @@ void scatter_resolve_grid_kernel(const float *__restrict__ flow, int sign,
             if (emit) resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
         } else {
             if (emit) {
-                for (int c = 0; c < C; ++c) out[o * C + c] = 0.0f;
+                for (int c = 0; c < C; ++c) out[o * C + c] = (VT)0;
                 if (valid) valid[o] = 0;
             }
             gap = hull.n_lower > 0 && inside_hull(hull, (double)x, (double)y);
@@ -733,11 +735,11 @@ __device__ __forceinline__ void note_deep_node(const ScatterWs &ws, int x, int y
 
 // pass 2b / 2c: the marked gap nodes.  FAR = false looks at rings 0 .. 2 (isolated dropped points: a lean kernel at full
 // occupancy) and re-marks what it could not fill; FAR = true searches rings 3 .. 16 for those (rims of holes).
-template <bool FAR>
+template <bool FAR, typename VT>
 __global__ __launch_bounds__(256)
 void scatter_gap_kernel(const float *__restrict__ flow, int sign,
-                        const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
-                        int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
+                        const VT *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                        int H, int W, VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
                         ScatterWs ws, HullRef hull, int row0, int rows, int er0, int erows)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -825,10 +827,11 @@ void scatter_jfa_step_kernel(const uint32_t *__restrict__ in, uint32_t *__restri
     outs[(size_t)ly * bw + lx] = best;
 }
 
+template <typename VT>
 __global__ __launch_bounds__(256)
 void scatter_deep_kernel(const float *__restrict__ flow, int sign,
-                         const float *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
-                         int H, int W, float *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
+                         const VT *__restrict__ vals, int C, const uint8_t *__restrict__ vmask,
+                         int H, int W, VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule,
                          ScatterWs ws, const uint32_t *__restrict__ seed, int row0, int rows, int bx0, int by0, int bw, int bh)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -1095,20 +1098,21 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
 
 }  // namespace
 
-extern "C" {
+namespace {
 
 // the gap passes after scatter_resolve_grid_kernel (grid mode): near, far, and -- when the device reports nodes deeper
 // than the ring search reaches -- the jump-flooding fill.  Only a point mask can produce such nodes, and only then is
 // the flag read back (one more host synchronisation).
-static int scatter_fill_gaps(const float *flow, int sign, const uint8_t *pmask, const float *vals, int C, const uint8_t *vmask,
-                             int H, int W, float *out, uint8_t *valid, int valid_rule, const ScatterWs &ws, const HullRef &hull,
+template <typename VT>
+int scatter_fill_gaps(const float *flow, int sign, const uint8_t *pmask, const VT *vals, int C, const uint8_t *vmask,
+                             int H, int W, VT *out, uint8_t *valid, int valid_rule, const ScatterWs &ws, const HullRef &hull,
                              int row0, int rows, int er0, int erows, hipStream_t s)
 {
     if (hull.n_lower <= 0) return OFL_OK;
     const dim3 pgrid((W + 31) / 32, (rows + 7) / 8), grid((W + 31) / 32, (erows + 7) / 8), block(256);
-    hipLaunchKernelGGL(scatter_gap_kernel<false>, pgrid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+    hipLaunchKernelGGL((scatter_gap_kernel<false, VT>), pgrid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                        out, valid, valid_rule, ws, hull, row0, rows, er0, erows);
-    hipLaunchKernelGGL(scatter_gap_kernel<true>, pgrid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+    hipLaunchKernelGGL((scatter_gap_kernel<true, VT>), pgrid, block, 0, s, flow, sign, vals, C, vmask, H, W,
                        out, valid, valid_rule, ws, hull, row0, rows, er0, erows);
     OFL_HIP(hipGetLastError());
     if (!pmask || ws.oy0 != 0 || ws.oy1 != H || ws.big_cap < 2ull * (unsigned long long)H * W) return OFL_OK;
@@ -1132,11 +1136,46 @@ static int scatter_fill_gaps(const float *flow, int sign, const uint8_t *pmask, 
         hipLaunchKernelGGL(scatter_jfa_step_kernel, sub, block, 0, s, a, b, W, bx0, by0, bw, bh, step);
         std::swap(a, b);
     }
-    hipLaunchKernelGGL(scatter_deep_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W, out, valid, valid_rule, ws, a, er0, erows,
+    hipLaunchKernelGGL(scatter_deep_kernel<VT>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W, out, valid, valid_rule, ws, a, er0, erows,
                        bx0, by0, bw, bh);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }
+
+
+// grid mode (node positions): argument checks, passes 0-1, the hull, then resolve + gap passes on rows [row0, row0 + rows)
+template <typename VT>
+int scatter_grid_impl(const char *who, const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                      const VT *vals, int C, const uint8_t *vmask, int H, int W, int row0, int rows, bool band,
+                      VT *out, uint8_t *valid, int valid_rule, void *workspace, size_t workspace_bytes,
+                      uint64_t *info_host, hipStream_t s)
+{
+    if (C < 0 || (C > 0 && (!vals || !out))) return fail(OFL_E_INVALID, "%s: C > 0 needs vals and out", who);
+    if (C == 0 && !valid) return fail(OFL_E_INVALID, "%s: nothing to compute", who);
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "%s: sign must be +1 or -1", who);
+    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "%s: bad point_precision", who);
+    if (point_precision == 1) sign *= 2;
+    if (valid_rule & ~(1 | OFL_SCATTER_ROUND)) return fail(OFL_E_INVALID, "%s: bad valid_rule", who);
+    if (H <= 0 || W <= 0 || row0 < 0 || rows <= 0 || row0 + rows > H)
+        return fail(OFL_E_INVALID, "%s: rows [%d, %d) outside the %d-row grid", who, row0, row0 + rows, H);
+    ScatterWs ws;
+    HullRef hull;
+    // owners are needed for the rows and, for the gap fill, kFillRadius rows around them -- or everywhere when a point
+    // mask may leave holes deeper than that (the deep fill looks for the nearest covered node of the whole field)
+    const int oy0 = (pmask || !band) ? 0 : std::max(0, row0 - kFillRadius), oy1 = (pmask || !band) ? H : std::min(H, row0 + rows + kFillRadius);
+    OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull, oy0, oy1));
+    // with a point mask the passes run over the whole field and only WRITE the band (see scatter_resolve_grid_kernel)
+    const int pr0 = pmask ? 0 : row0, prows = pmask ? H : rows;
+    const dim3 grid((W + 31) / 32, (prows + 7) / 8), block(256);
+    hipLaunchKernelGGL(scatter_resolve_grid_kernel<VT>, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
+                       out, valid, valid_rule, ws, hull, pr0, prows, row0, rows);
+    OFL_HIP(hipGetLastError());
+    return scatter_fill_gaps<VT>(flow, sign, pmask, vals, C, vmask, H, W, out, valid, valid_rule, ws, hull, pr0, prows, row0, rows, s);
+}
+
+}  // namespace
+
+extern "C" {
 
 int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                            const float *vals, int C, const uint8_t *vmask, int H, int W,
@@ -1144,28 +1183,35 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
                            void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
 {
     OFL_TRY(need_device());
+    hipStream_t s = stream_of(stream);
+    if (!query)
+        return scatter_grid_impl<float>("ofl_scatter_linear", flow, sign, point_precision, pmask, vals, C, vmask, H, W, 0, H, false,
+                                        out, valid, valid_rule, workspace, workspace_bytes, info_host, s);
+    // arbitrary sample positions (mode 2 / ref 't'): one resolve launch with the triangle search
     if (C < 0 || (C > 0 && (!vals || !out))) return fail(OFL_E_INVALID, "ofl_scatter_linear: C > 0 needs vals and out");
     if (C == 0 && !valid) return fail(OFL_E_INVALID, "ofl_scatter_linear: nothing to compute");
     if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_linear: sign must be +1 or -1");
     if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad point_precision");
     if (point_precision == 1) sign *= 2;
     if (valid_rule & ~(1 | OFL_SCATTER_ROUND)) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
-    hipStream_t s = stream_of(stream);
     ScatterWs ws;
     HullRef hull;
     OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
-    if (query) {
-        hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
-                           out, valid, valid_rule, ws, hull);
-    } else {
-        hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                           out, valid, valid_rule, ws, hull, 0, H, 0, H);
-        OFL_HIP(hipGetLastError());
-        return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out, valid, valid_rule, ws, hull, 0, H, 0, H, s);
-    }
+    hipLaunchKernelGGL(scatter_resolve_kernel, grid, block, 0, s, flow, sign, pmask, vals, C, vmask, H, W, query,
+                       out, valid, valid_rule, ws, hull);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
+}
+
+int ofl_scatter_linear_f64_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
+                               const double *vals, int C, const uint8_t *vmask, int H, int W,
+                               double *out, uint8_t *valid, int valid_rule,
+                               void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
+{
+    OFL_TRY(need_device());
+    return scatter_grid_impl<double>("ofl_scatter_linear_f64", flow, sign, point_precision, pmask, vals, C, vmask, H, W, 0, H, false,
+                                     out, valid, valid_rule, workspace, workspace_bytes, info_host, stream_of(stream));
 }
 
 int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
@@ -1174,28 +1220,8 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
                          void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
 {
     OFL_TRY(need_device());
-    if (C < 0 || (C > 0 && (!vals || !out_rows))) return fail(OFL_E_INVALID, "ofl_scatter_rows: C > 0 needs vals and out");
-    if (C == 0 && !valid_rows) return fail(OFL_E_INVALID, "ofl_scatter_rows: nothing to compute");
-    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_rows: sign must be +1 or -1");
-    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_rows: bad point_precision");
-    if (point_precision == 1) sign *= 2;
-    if (valid_rule & ~(1 | OFL_SCATTER_ROUND)) return fail(OFL_E_INVALID, "ofl_scatter_rows: bad valid_rule");
-    if (H <= 0 || W <= 0 || row0 < 0 || rows <= 0 || row0 + rows > H)
-        return fail(OFL_E_INVALID, "ofl_scatter_rows: rows [%d, %d) outside the %d-row grid", row0, row0 + rows, H);
-    hipStream_t s = stream_of(stream);
-    ScatterWs ws;
-    HullRef hull;
-    // owners are needed for the band and, for the gap fill, kFillRadius rows around it -- or everywhere when a point
-    // mask may leave holes deeper than that (the deep fill looks for the nearest covered node of the whole field)
-    const int oy0 = pmask ? 0 : std::max(0, row0 - kFillRadius), oy1 = pmask ? H : std::min(H, row0 + rows + kFillRadius);
-    OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull, oy0, oy1));
-    // with a point mask the passes run over the whole field and only WRITE the band (see scatter_resolve_grid_kernel)
-    const int pr0 = pmask ? 0 : row0, prows = pmask ? H : rows;
-    const dim3 grid((W + 31) / 32, (prows + 7) / 8), block(256);
-    hipLaunchKernelGGL(scatter_resolve_grid_kernel, grid, block, 0, s, flow, sign, vals, C, vmask, H, W,
-                       out_rows, valid_rows, valid_rule, ws, hull, pr0, prows, row0, rows);
-    OFL_HIP(hipGetLastError());
-    return scatter_fill_gaps(flow, sign, pmask, vals, C, vmask, H, W, out_rows, valid_rows, valid_rule, ws, hull, pr0, prows, row0, rows, s);
+    return scatter_grid_impl<float>("ofl_scatter_rows", flow, sign, point_precision, pmask, vals, C, vmask, H, W, row0, rows, true,
+                                    out_rows, valid_rows, valid_rule, workspace, workspace_bytes, info_host, stream_of(stream));
 }
 
 // Sparse queries (point tracking, utils.py:610-615): the triangle containing each of n_query points

@@ -584,6 +584,16 @@ def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, v
     return tuple(info)
 
 
+def scatter_linear_f64(flow, sign, pmask, vals, C, vmask, h, w, out, valid, valid_rule, point_precision=0, stream=None):
+    """K3 with float64 values at the grid nodes (float64 targets of apply_flow 's', utils.py:253-258)."""
+    ws = _workspace(h, w, C)
+    info = (ctypes.c_uint64 * 3)()
+    ptr = lambda b: b.ptr if b is not None else None
+    nat.check(_lib().ofl_scatter_linear_f64_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),
+                                                h, w, ptr(out), ptr(valid), valid_rule, ws.ptr, ws.nbytes, info, stream))
+    return tuple(info)
+
+
 def scatter_rows(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, valid_rows, valid_rule=0,
                  point_precision=0, stream=None):
     """K3 on one row band of a field split over several GPUs (SURVEY 8e, config 5 as loaded): all inputs are the
@@ -608,6 +618,13 @@ def scatter_host(flow, target, pmask, vmask=None):
     as_mask = lambda m: np.ascontiguousarray(m).view(np.uint8) if m.dtype == np.bool_ else np.ascontiguousarray(m).astype(np.uint8)
     pm = DeviceBuffer.from_host(as_mask(pmask)) if pmask is not None else None
     vm = DeviceBuffer.from_host(as_mask(vmask)) if vmask is not None else None
+    valid = DeviceBuffer(h * w) if vmask is not None else None
+    if target.dtype == np.float64:                                           # griddata's own precision end to end
+        vals = DeviceBuffer.from_host(np.ascontiguousarray(target))
+        out = DeviceBuffer(n * 8)
+        scatter_linear_f64(fbuf, +1, pm, vals, C, vm, h, w, out, valid, 0)
+        v = valid.to_host((h, w), np.uint8).view(np.bool_) if valid is not None else None
+        return out.to_host((h, w, C), np.float64), v
     native = target.dtype in _DT_CODE and target.dtype != np.float32         # the casts of utils.py:253 / :258 run on the device
     integer = np.issubdtype(target.dtype, np.integer)
     if native:
@@ -617,7 +634,6 @@ def scatter_host(flow, target, pmask, vmask=None):
     else:
         vals = DeviceBuffer.from_host(np.ascontiguousarray(target, np.float32))
     out = DeviceBuffer(n * 4)
-    valid = DeviceBuffer(h * w) if vmask is not None else None
     scatter_linear(fbuf, +1, pm, vals, C, vm, h, w, None, out, valid, nat.SCATTER_ROUND if integer else 0)
     if native:
         back = DeviceBuffer(n * target.dtype.itemsize)

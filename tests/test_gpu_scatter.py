@@ -657,3 +657,37 @@ def test_large_hole_in_point_mask_matches_scipy(gpu, oracle):
     np.testing.assert_array_equal(np.concatenate(parts), full)
     np.testing.assert_array_equal(np.concatenate(vparts), fullv)
     assert fullv[60:90, 90:130].all()
+
+
+def test_float64_targets_keep_their_precision(gpu, oracle):
+    """apply_flow(.., 's') of a float64 image: griddata interpolates in float64 and the reference returns
+    result.astype(float64) (utils.py:253-258) -- the float64 scatter entry reproduces SciPy to 1e-11 where the
+    triangulation is unique (a smooth non-affine field), float32 images to float32 rounding."""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(9)
+    shape = (48, 64)
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float32)
+    vecs = of.Flow.from_transforms([['rotation', 30, 20, 11], ['scaling', 10, 10, 0.93]], shape, 's').vecs + \
+        np.stack([0.7 * np.sin(xx / 9) * np.cos(yy / 7), 0.5 * np.cos(xx / 8)], -1).astype(np.float32)
+    img = rng.random(shape + (3,)) * 1e3 + 1e-7 * rng.random(shape + (3,))
+    f = of.Flow(vecs, 's')
+    got, valid = f.apply(img, return_valid_area=True)
+    want, wvalid = O.OFlow(vecs, 's').apply(img, return_valid_area=True)
+    assert got.dtype == np.float64
+    # The reference compares the interpolated mask channel with 1 in the TARGET's dtype (flow_class.py:668): in float64
+    # the sum c0 + c1 + (1 - c0 - c1) misses 1.0 by one ulp at ~3 % of the nodes, which SciPy's own rounding decides.
+    # The kernel applies the float32 rule to every dtype: its valid area is the float32 one, a superset of that noise.
+    v32 = f.apply(img.astype(np.float32), return_valid_area=True)[1]
+    np.testing.assert_array_equal(valid, v32)
+    np.testing.assert_array_equal(v32, O.OFlow(vecs, 's').apply(img.astype(np.float32), return_valid_area=True)[1])
+    assert not (wvalid & ~valid).any() and (valid & ~wvalid).mean() < 0.08
+    inner = ndimage_erode(valid, 2)
+    np.testing.assert_allclose(got[inner], want[inner], rtol=1e-11, atol=1e-9)
+    got32 = f.apply(img.astype(np.float32))
+    assert got32.dtype == np.float32
+    np.testing.assert_allclose(got32[inner], want[inner], rtol=2e-6, atol=1e-4)
+
+
+def ndimage_erode(mask, it):
+    from scipy import ndimage
+    return ndimage.binary_erosion(mask, iterations=it)

@@ -188,6 +188,8 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  *                   0 where no triangle covers the node;
  *     valid[H][W]   valid_rule 0: float32(interpolated vmask) == 1   (flow_class.py:668)
  *                   valid_rule 1: interpolated vmask > 0.99           (flow_class.py:1410)
+ *                   valid_rule 2: rint(interpolated vmask) == 1 -- integer-typed targets, whose concatenated mask channel
+ *                                 the reference rounds before the comparison (utils.py:256-257, flow_class.py:668)
  *                   valid_rule | OFL_SCATTER_ROUND: additionally out = float32(rint(float64 result)), the
  *                   np.round the reference applies to integer-typed targets (utils.py:256-257)
  *                   (vmask NULL = all ones, i.e. valid == "covered by a triangle").

@@ -677,7 +677,8 @@ __device__ __forceinline__ void resolve_emit(const VT *__restrict__ vals, int C,
         if (vmask) m = c0 * (double)(vmask[vi[0]] != 0) + c1 * (double)(vmask[vi[1]] != 0) + c2 * (double)(vmask[vi[2]] != 0);
         else       m = c0 + c1 + c2;
         const float mf = (float)m;                                   // result.astype(target.dtype), utils.py:258
-        valid[o] = (valid_rule & 1) == 0 ? (mf == 1.0f) : (m > 0.99);     // flow_class.py:668 / :1410
+        const int vr = valid_rule & 3;                               // flow_class.py:668 / :1410; 2: integer-typed targets, where
+        valid[o] = vr == 0 ? (mf == 1.0f) : (vr == 1 ? (m > 0.99) : (rint(m) == 1.0));   // the mask channel is np.round-ed first (utils.py:256)
     }
 }
 
@@ -1155,7 +1156,7 @@ int scatter_grid_impl(const char *who, const float *flow, int sign, int point_pr
     if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "%s: sign must be +1 or -1", who);
     if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "%s: bad point_precision", who);
     if (point_precision == 1) sign *= 2;
-    if (valid_rule & ~(1 | OFL_SCATTER_ROUND)) return fail(OFL_E_INVALID, "%s: bad valid_rule", who);
+    if ((valid_rule & ~(3 | OFL_SCATTER_ROUND)) || (valid_rule & 3) == 3) return fail(OFL_E_INVALID, "%s: bad valid_rule", who);
     if (H <= 0 || W <= 0 || row0 < 0 || rows <= 0 || row0 + rows > H)
         return fail(OFL_E_INVALID, "%s: rows [%d, %d) outside the %d-row grid", who, row0, row0 + rows, H);
     ScatterWs ws;
@@ -1193,7 +1194,7 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
     if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_linear: sign must be +1 or -1");
     if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad point_precision");
     if (point_precision == 1) sign *= 2;
-    if (valid_rule & ~(1 | OFL_SCATTER_ROUND)) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
+    if ((valid_rule & ~(3 | OFL_SCATTER_ROUND)) || (valid_rule & 3) == 3) return fail(OFL_E_INVALID, "ofl_scatter_linear: bad valid_rule");
     ScatterWs ws;
     HullRef hull;
     OFL_TRY(scatter_prepare(flow, sign, pmask, H, W, workspace, workspace_bytes, info_host, s, ws, hull));

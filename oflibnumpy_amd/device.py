@@ -634,7 +634,8 @@ def scatter_host(flow, target, pmask, vmask=None):
     else:
         vals = DeviceBuffer.from_host(np.ascontiguousarray(target, np.float32))
     out = DeviceBuffer(n * 4)
-    scatter_linear(fbuf, +1, pm, vals, C, vm, h, w, None, out, valid, nat.SCATTER_ROUND if integer else 0)
+    # integer targets: values AND the concatenated mask channel are np.round-ed before the cast (utils.py:256-257)
+    scatter_linear(fbuf, +1, pm, vals, C, vm, h, w, None, out, valid, (nat.SCATTER_ROUND | 2) if integer else 0)
     if native:
         back = DeviceBuffer(n * target.dtype.itemsize)
         nat.check(_lib().ofl_convert_dev(out.ptr, nat.F32, back.ptr, _DT_CODE[target.dtype], n, None))

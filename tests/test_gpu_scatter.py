@@ -691,3 +691,44 @@ def test_float64_targets_keep_their_precision(gpu, oracle):
 def ndimage_erode(mask, it):
     from scipy import ndimage
     return ndimage.binary_erosion(mask, iterations=it)
+
+
+def test_integer_targets_valid_area_s(gpu, oracle):
+    """'s' warp of integer images with a valid area: the reference concatenates the mask into the integer array, so the
+    interpolated mask is np.round-ed before `== 1` (utils.py:256-257, flow_class.py:644, 668) -- looser than the float
+    rule.  Default (int8) and boolean target masks, uint8 / int16 images, speckled flow mask, against the oracle."""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(13)
+    shape = (40, 56)
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float32)
+    vecs = of.Flow.from_transforms([['rotation', 20, 30, 9], ['scaling', 10, 10, 1.05]], shape, 's').vecs + \
+        np.stack([0.6 * np.sin(xx / 9) * np.cos(yy / 7), 0.5 * np.cos(xx / 8)], -1).astype(np.float32)
+    fm = rng.random(shape) > 0.08
+    f, o = of.Flow(vecs, 's', fm), O.OFlow(vecs, 's', fm)
+    tm = np.ones(shape, bool)
+    tm[10:22, 15:40] = False            # a solid invalid region: which triangle covers a node only matters along its outline
+    from scipy import ndimage
+    edge = ndimage.binary_dilation(~tm, iterations=3) & ndimage.binary_dilation(tm, iterations=3)
+    for dt in (np.uint8, np.int16):
+        img = (rng.random(shape + (3,)) * 200).astype(dt)
+        for tmask in (None, tm):
+            got, valid = f.apply(img, tmask, return_valid_area=True)
+            want, wvalid = o.apply(img, tmask, return_valid_area=True)
+            sel = np.ones(shape, bool)
+            if tmask is not None:           # the outline of the region lands ~2 px away under this flow: leave a generous band out
+                sel = ~ndimage.binary_dilation(edge, iterations=4)
+            np.testing.assert_array_equal(valid[sel], wvalid[sel], err_msg=str((dt, tmask is None)))
+        # the rounding rule really is looser than the float rule along the outline -- and the kernel follows it
+        v_int = f.apply(img, tm, return_valid_area=True)[1]
+        w_int = o.apply(img, tm, return_valid_area=True)[1]
+        w_flt = o.apply(img.astype(np.float32), tm, return_valid_area=True)[1]
+        assert w_int.sum() > w_flt.sum() + 20
+        assert abs(int(v_int.sum()) - int(w_int.sum())) < 0.25 * (w_int.sum() - w_flt.sum())
+        # values (all points kept: dropped points leave gaps that random image content fills differently, deviation b)
+        got, valid = of.Flow(vecs, 's').apply(img, tm, return_valid_area=True)
+        want, wvalid = O.OFlow(vecs, 's').apply(img, tm, return_valid_area=True)
+        sel = ~ndimage.binary_dilation(edge, iterations=4)
+        np.testing.assert_array_equal(valid[sel], wvalid[sel])
+        inner = ndimage_erode(of.Flow(vecs, 's').valid_target(), 2)
+        d = np.abs(got.astype(int) - want.astype(int)).max(-1)
+        assert (d[inner] <= 1).all() and (d[inner] > 0).mean() < 0.02

@@ -4,12 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one synthetic pair of flow fields that is already resident
+A "step" is one pass of the hot path over one synthetic batch of flow-field pairs that is already resident
 in HBM: one launch of the fused compose kernel (ofl_compose3_dev, with the reference's zero-flow
 predicates evaluated in the same launch).  Steps rotate over `--sets` distinct input/output sets so
 that consecutive steps cannot be served from the 256 MiB Infinity Cache.  With N > 1 every rank owns
 one GPU and its own pairs (independent units, "weak" scaling, no data-path collective); the only
 exchange is the one-off RCCL broadcast of the shared first flow field before the timed region.
+Started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the process becomes the launcher
+itself: it spawns N fresh rank processes before anything touches the GPU and relays rank 0's line.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -26,25 +28,27 @@ import numpy as np
 H, W = 2160, 3840
 BYTES_PER_PX = 27            # 2 x (8 + 1) read + (8 + 1) written
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+TRAFFIC_FILES = ("profiles/r02_compose3_traffic.json", "profiles/r01_compose3_traffic.json")
 
 
 PATTERN = "scale"
 ANGLE = -30.0
 
 
-def make_pair(of, h, w, ref, variant):
+def make_pair(of, h, w, ref, variant, pattern=None):
     """Synthetic pair of SURVEY.md 8(d) config 2, scaled to the requested size; `variant` perturbs the
-    angle/scale slightly so that the rotating sets are not byte-identical.  PATTERN selects what the
+    angle/scale slightly so that the rotating sets are not byte-identical.  `pattern` selects what the
     SAMPLING field looks like: "scale" (the config: f2 = scaling 0.8, 36 % of the samples fall outside),
     "shift" (f2 = 3.3 px translation: streaming-friendly gather) or "rot" (f1 and f2 swapped: samples lie
     on a grid rotated by 30 degrees)."""
+    pattern = pattern or PATTERN
     ang = ANGLE + 0.5 * variant
     sc = 0.8 + 0.005 * variant
     f1 = of.Flow.from_transforms([['rotation', w / 2.0, h / 2.0, ang]], [h, w], ref)
     f2 = of.Flow.from_transforms([['scaling', w * 400.0 / 1920.0, h * 300.0 / 1080.0, sc]], [h, w], ref)
-    if PATTERN == "shift":
+    if pattern == "shift":
         f2 = of.Flow.from_transforms([['translation', 3.3 + 0.1 * variant, -2.7]], [h, w], ref)
-    elif PATTERN == "rot":
+    elif pattern == "rot":
         f1, f2 = f2, f1
     rng = np.random.default_rng(variant)
     m1 = rng.random((h, w)) > 0.05
@@ -52,29 +56,48 @@ def make_pair(of, h, w, ref, variant):
     return of.Flow(f1.vecs, ref, m1), of.Flow(f2.vecs, ref, m2)
 
 
-def cpu_baseline(h, w, ref, budget_s=20.0):
-    """The oracle (CPU restatement: NumPy op sequence of the reference + C remap with OpenMP) timed on
-    this box's host cores on a bounded sample of the same workload."""
-    from oracle import np_oracle as O
-    O.build()
-    threads = O.set_threads(min(len(os.sched_getaffinity(0)), 16))    # one GPU's CPU share on this pool
-    import oflibnumpy_amd as of
-    f1, f2 = make_pair(of, h, w, ref, 0)
-    a, b = O.OFlow(f1.vecs, ref, f1.mask), O.OFlow(f2.vecs, ref, f2.mask)
-    a.combine_with(b, 3)                                   # warm-up (page faults, OpenMP pool)
+def _rate(fn, budget_s, max_n):
+    fn()                                                    # warm-up (page faults, OpenMP pool)
     n, t0 = 0, time.perf_counter()
     while True:
-        a.combine_with(b, 3)
+        fn()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 16:
-            break
-    return {"value": round(n / dt, 4), "unit": "flow-fields/s", "cores": threads, "kind": "port",
-            "sample": "{} x OFlow.combine_with(mode=3) at {}x{} '{}' (NumPy op sequence of the reference, "
-                      "single thread, + C restatement of cv2.remap on {} OpenMP threads)".format(n, h, w, ref, threads)}
+        if dt > budget_s or n >= max_n:
+            return n / dt, n
 
 
-def main():
+def cpu_baseline(h, w, ref, budget_s=6.0):
+    """The oracle (CPU restatement) timed on this box's host cores on a bounded sample of the same workload, split as
+    SURVEY 8(d) asks: the NumPy op sequence of the reference on one thread, and the fused C closed form (OpenMP) on all
+    of this GPU's host cores and on one.  `value` is the closest thing to what the reference does on this box: its NumPy
+    passes (single-threaded, as NumPy is) around a multi-threaded remap (cv2.remap parallelises internally)."""
+    from oracle import np_oracle as O
+    O.build()
+    import oflibnumpy_amd as of
+    cores = min(len(os.sched_getaffinity(0)), 16)            # one GPU's CPU share on this pool
+    f1, f2 = make_pair(of, h, w, ref, 0, "scale")
+    a, b = O.OFlow(f1.vecs, ref, f1.mask), O.OFlow(f2.vecs, ref, f2.mask)
+    fa, fb, sign = (f1, f2, -1) if ref == 't' else (f2, f1, +1)
+    raw = lambda: O.compose3_raw(fa.vecs, fa.mask, fb.vecs, fb.mask, sign)
+    threads = O.set_threads(cores)
+    v_mt, n_mt = _rate(lambda: a.combine_with(b, 3), budget_s, 16)
+    c_mt, _ = _rate(raw, budget_s / 2, 64)
+    O.set_threads(1)
+    v_1, n_1 = _rate(lambda: a.combine_with(b, 3), budget_s, 8)
+    c_1, _ = _rate(raw, budget_s / 2, 16)
+    O.set_threads(cores)
+    return {"value": round(v_mt, 4), "unit": "flow-fields/s", "cores": threads, "kind": "port",
+            "sample": "{} x OFlow.combine_with(mode=3) at {}x{} '{}' (NumPy op sequence of the reference, single thread, "
+                      "+ C restatement of cv2.remap on {} OpenMP threads)".format(n_mt, h, w, ref, threads),
+            "numpy_1thread": {"value": round(v_1, 4), "cores": 1,
+                              "sample": "{} x the same with the remap on one thread as well".format(n_1)},
+            "c_omp_all_cores": {"value": round(c_mt, 3), "cores": threads,
+                                "sample": "oracle/ofl_oracle.c orc_compose3 (fused closed form, no NumPy passes)"},
+            "c_1thread": {"value": round(c_1, 3), "cores": 1, "sample": "the same, OMP threads = 1"}}
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -87,10 +110,21 @@ def main():
     ap.add_argument("--ref", default="t", choices=["t", "s"])
     ap.add_argument("--no-stats", action="store_true", help="skip the fused zero-flow predicates (A/B only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the shift / rot pattern measurements")
+    ap.add_argument("--prewarm-ms", type=float, default=250.0,
+                    help="untimed launches for at least this long before --warmup/--steps (clock ramp of a cold GPU)")
     ap.add_argument("--pattern", default="scale", choices=["scale", "shift", "rot"],
                     help="sampling pattern of the gather (default: the BASELINE config)")
     ap.add_argument("--angle", type=float, default=-30.0, help="rotation angle of f1 (default: the BASELINE config, -30 deg)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launcher mode: nothing below this line has run, the GPU is untouched in this process
+        from oflibnumpy_amd import sharding
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     h, w = args.height, args.width
     global PATTERN, ANGLE
     PATTERN = args.pattern
@@ -99,16 +133,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
 
     # The engine (plain HIP runtime behind a C ABI) is loaded BEFORE torch so that it binds the system
     # ROCm runtime; torch is used for the rendezvous / barrier / max-reduce only (gloo, CPU tensors).
     os.environ.setdefault("OFL_DEVICE", str(local_rank))
+    import ctypes
     import oflibnumpy_amd as of
-    from oflibnumpy_amd import device as dev
+    from oflibnumpy_amd import device as dev, sharding
     nat = of.native
     nat.ensure_device()
     lib = nat.load()
@@ -138,21 +171,21 @@ def main():
 
     # ---------------------------------------------------------------- inputs resident in HBM
     ref = args.ref
-    rccl_note = "not needed (1 GPU)" if world == 1 else "skipped (ranks share a GPU)"
-    rccl_hung = False
     B = max(1, args.batch)
     set_bytes = BYTES_PER_PX * h * w * B
     n_sets = args.sets if args.sets > 0 else max(2, -(-(3 * 256 << 20) // set_bytes))
     n = h * w
 
     class Batch:            # B fields stored back to back: vecs [B][H][W][2] f32, mask [B][H][W] u8
-        def __init__(self):
-            self.vecs, self.mask, self.shape = dev.DeviceBuffer(B * n * 8), dev.DeviceBuffer(B * n), (h, w)
+        def __init__(self, mask=None):
+            self.vecs, self.mask, self.shape = dev.DeviceBuffer(B * n * 8), (mask or dev.DeviceBuffer(B * n)), (h, w)
 
-        def put(self, i, flow):
-            nat.check(lib.ofl_upload(self.vecs.ptr + i * n * 8, flow.vecs.ctypes.data, n * 8, None))
-            m = flow.mask.astype(np.uint8)
-            nat.check(lib.ofl_upload(self.mask.ptr + i * n, m.ctypes.data, n, None))
+        def put(self, i, flow, with_mask=True):
+            v = np.ascontiguousarray(flow.vecs, np.float32)
+            nat.check(lib.ofl_upload(self.vecs.ptr + i * n * 8, v.ctypes.data, n * 8, None))
+            if with_mask:
+                m = flow.mask.astype(np.uint8)
+                nat.check(lib.ofl_upload(self.mask.ptr + i * n, m.ctypes.data, n, None))
             nat.check(lib.ofl_stream_sync(None))
 
     sets = []
@@ -168,16 +201,20 @@ def main():
             b2.put(j, f2)
         fa, fb, sign = (b1, b2, -1) if ref == 't' else (b2, b1, +1)
         sets.append((fa, fb, sign, out))
+
+    # ---------------------------------------------------------------- the one exchange step (set-up, untimed)
+    rccl_note, rccl_ranks, rccl_bad = ("not needed (1 GPU)" if world == 1 else "skipped (ranks share a GPU)"), 0, 0
     if world > 1 and nat.device_count() < world:
         if rank == 0:
             print("rehearsal: {} ranks share {} GPU(s); the RCCL broadcast is skipped".format(world, nat.device_count()),
                   file=sys.stderr)
     elif world > 1:
-        # the one exchange step of the workload: broadcast a shared source field over xGMI (RCCL).  It is
-        # set-up, outside the timed region; a failure is reported in the JSON line instead of aborting.
-        from oflibnumpy_amd import sharding
+        # broadcast a shared source field over xGMI (RCCL) on its OWN stream, so that a stuck collective cannot block the
+        # timed launches; the outcome is agreed between the ranks (gloo) and reported in the JSON line.
         import threading
         result = {}
+        cstream = ctypes.c_void_p()
+        nat.check(lib.ofl_stream_create(ctypes.byref(cstream)))
 
         def exchange():
             try:
@@ -186,52 +223,70 @@ def main():
                     nat.check(lib.ofl_comm_unique_id(uid.ctypes.data))
                 uid = np.ascontiguousarray(sharding.broadcast_bytes(dist, uid, 0))
                 nat.check(lib.ofl_comm_init(uid.ctypes.data, rank, world))
-                nat.check(lib.ofl_comm_broadcast(sets[0][0].vecs.ptr, h * w * 8, 0, None))     # first field of the first batch
-                nat.check(lib.ofl_comm_broadcast(sets[0][0].mask.ptr, h * w, 0, None))
-                device_sync()
+                nat.check(lib.ofl_comm_broadcast(sets[0][0].vecs.ptr, h * w * 8, 0, cstream))  # first field of the first batch
+                nat.check(lib.ofl_comm_broadcast(sets[0][0].mask.ptr, h * w, 0, cstream))
+                nat.check(lib.ofl_stream_sync(cstream))
+                k = ctypes.c_int(0)
+                nat.check(lib.ofl_comm_size(ctypes.byref(k)))
+                result["ranks"] = k.value
                 result["note"] = "ok"
             except Exception as e:      # noqa: BLE001 - reported, not hidden
                 result["note"] = "failed: {}".format(e)
 
-        # watchdog: a communicator that cannot be set up (no usable interface, peer access refused) must not hang
-        # the benchmark of a path that needs no collective; the outcome is reported in the JSON line
         worker = threading.Thread(target=exchange, daemon=True)
         worker.start()
         worker.join(float(os.environ.get("OFL_RCCL_TIMEOUT", "180")))
-        rccl_note = result.get("note", "timed out")
-        rccl_hung = worker.is_alive()
+        hung = worker.is_alive()
+        rccl_note = "timed out" if hung else result.get("note", "failed")
+        rccl_ranks = result.get("ranks", 0)
+        # 0 = ok, 1 = failed cleanly (the path needs no collective: measured anyway), 2 = a rank is stuck inside RCCL
+        rccl_bad = int(sharding.max_over_ranks(dist, [2.0 if hung else (0.0 if rccl_note == "ok" else 1.0)])[0])
         if rccl_note != "ok":
             print("rank {}: RCCL broadcast {}".format(rank, rccl_note), file=sys.stderr)
+        if rccl_bad and rccl_note == "ok":
+            rccl_note = "ok here, failed on another rank"
     total = args.warmup + args.steps
-    stats = None if args.no_stats else dev.DeviceBuffer.zeros(32 * B * total)
+    stats = None if args.no_stats else dev.DeviceBuffer.zeros(32 * B * max(total, 64))
 
-    import ctypes
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
     nat.check(lib.ofl_event_create(ctypes.byref(ev0)))
     nat.check(lib.ofl_event_create(ctypes.byref(ev1)))
 
-    def step(i):
-        fa, fb, sign, out = sets[i % len(sets)]
+    def step(i, which=None):
+        fa, fb, sign, out = (which or sets)[i % len(sets)]
         dev.compose3_launch(fa, fb, sign, out, stats, 32 * B * i if stats is not None else 0, batch=B)
 
-    for i in range(args.warmup):
-        step(i)
-    device_sync()
-    barrier()
-    t0 = time.perf_counter()
-    nat.check(lib.ofl_event_record(ev0, None))
-    for i in range(args.warmup, total):
-        step(i)
-    nat.check(lib.ofl_event_record(ev1, None))
-    device_sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ms = ctypes.c_float()
-    nat.check(lib.ofl_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)))
-    kernel_ms = ms.value / args.steps
+    def timed(steps, warm, which=None, first=0):
+        """`warm` untimed + `steps` timed launches; returns (wall seconds, HIP-event ms per launch) of the timed ones."""
+        for i in range(warm):
+            step(first + i, which)
+        device_sync()
+        barrier()
+        t0 = time.perf_counter()
+        nat.check(lib.ofl_event_record(ev0, None))
+        for i in range(warm, warm + steps):
+            step(first + i, which)
+        nat.check(lib.ofl_event_record(ev1, None))
+        device_sync()
+        barrier()
+        el = time.perf_counter() - t0
+        ms = ctypes.c_float()
+        nat.check(lib.ofl_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)))
+        return el, ms.value / steps
 
+    # untimed, time-based pre-warm: a GPU that has idled through the set-up needs a few hundred ms of work before its
+    # clocks settle; the driver's --warmup 5 alone is 2 ms of launches
+    prewarm_ms, t0 = 0.0, time.perf_counter()
+    while args.prewarm_ms > 0 and prewarm_ms < args.prewarm_ms:
+        for i in range(16):
+            step(i % 64)
+        device_sync()
+        prewarm_ms = (time.perf_counter() - t0) * 1e3
+    if stats is not None:
+        nat.check(lib.ofl_memset(stats.ptr, 0, stats.nbytes, None))
+
+    elapsed, kernel_ms = timed(args.steps, args.warmup)
     if dist is not None:
-        from oflibnumpy_amd import sharding
         elapsed, kernel_ms = sharding.max_over_ranks(dist, [elapsed, kernel_ms])
 
     # the predicates computed inside the timed launches: none of these synthetic flows is zero, so the
@@ -240,9 +295,25 @@ def main():
         words = stats.to_host((total * B, 8), np.uint32)
         assert words[:, [0, 1, 4, 5, 6, 7]].all(), "unexpected zero-flow predicate"
 
+    # secondary sampling patterns, same launch shape (N = 1 only): "rot" = the two roles swapped (samples on a grid
+    # rotated by 30 degrees), "shift" = a 3.3-px translation as the sampling field
+    algo_bytes = BYTES_PER_PX * h * w * B
+    secondary = {}
+    if world == 1 and not args.no_secondary and PATTERN == "scale":
+        rot_sets = [(fb, fa, sign, out) for fa, fb, sign, out in sets]
+        tr = of.Flow.from_transforms([['translation', 3.3, -2.7]], [h, w], ref)
+        shift_sets = []
+        for fa, fb, sign, out in sets:
+            sb = Batch(mask=(fb if ref == 't' else fa).mask)
+            for j in range(B):
+                sb.put(j, tr, with_mask=False)
+            shift_sets.append((fa, sb, sign, out) if ref == 't' else (sb, fb, sign, out))
+        for name, which in (("rot", rot_sets), ("shift", shift_sets)):
+            _, kms = timed(max(20, min(args.steps, 50)), 5, which)
+            secondary[name] = {"kernel_ms": round(kms, 5), "frac": round(algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
     if rank == 0:
         fields = args.steps * world * B
-        algo_bytes = BYTES_PER_PX * h * w * B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "flow-fields/sec for combine_with mode=3 @{}x{} float32".format(h, w),
@@ -256,24 +327,34 @@ def main():
                                    "pixels; {} independent pairs per step (one launch) per GPU, {} rotating HBM-resident "
                                    "sets".format(ref, h, w, B, len(sets)),
                        "fields_per_step_per_gpu": B, "fused_zero_flow_predicates": stats is not None, "sampling_pattern": PATTERN,
-                       "parallelism": "independent pairs per GPU x{}".format(world), "rccl_broadcast": rccl_note},
+                       "parallelism": "independent pairs per GPU x{}".format(world), "rccl_broadcast": rccl_note,
+                       "rccl_ranks": rccl_ranks, "prewarm_ms": round(prewarm_ms, 1),
+                       "parity_note": "bit-identical to oracle/ofl_oracle.c; cv2.remap parity unpinned below 1/32 px (OpenCV absent)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "compose3_xpose_kernel", "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        tpath = os.path.join(ROOT, "profiles", "r01_compose3_traffic.json")
-        if os.path.exists(tpath) and (h, w) == (H, W) and PATTERN == "scale":
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-            # correction + WRITE_SIZE), scaled from the profiled batch to this run's batch
-            line["roofline"]["traffic"] = round(json.load(open(tpath))["hbm_bytes_per_field"] * B)
+        if secondary:
+            line["roofline"]["other_patterns"] = secondary
+        for rel in TRAFFIC_FILES:
+            tpath = os.path.join(ROOT, rel)
+            if os.path.exists(tpath) and (h, w) == (H, W) and PATTERN == "scale":
+                # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+                # correction + WRITE_SIZE), scaled from the profiled batch to this run's batch -- not measured in this run
+                line["roofline"]["traffic"] = round(json.load(open(tpath))["hbm_bytes_per_field"] * B)
+                line["roofline"]["traffic_source"] = rel
+                break
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(h, w, ref)
         print(json.dumps(line), flush=True)
     if dist is not None:
-        if rccl_hung:                         # a rank still stuck inside the communicator set-up cannot shut down cleanly
+        if rccl_bad >= 2:
+            # some rank is still inside RCCL: neither the communicator nor the process group can be torn down in step.
+            # Every rank leaves with the same non-zero code (the line above says why); nothing is re-exec'ed.
             sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(3)
         nat.check(lib.ofl_comm_destroy())      # no-op when no communicator was created
         dist.barrier()
         dist.destroy_process_group()

@@ -283,6 +283,7 @@ int ofl_resize_flow_dev(const float *vecs, const uint8_t *mask, int H, int W, in
 int ofl_comm_unique_id(void *id128);
 int ofl_comm_init(const void *id128, int rank, int world);
 int ofl_comm_broadcast(void *dptr, size_t bytes, int root, void *stream);
+int ofl_comm_size(int *world);              /* ranks of the live communicator (ncclCommCount), 0 without one */
 int ofl_comm_destroy(void);
 
 #ifdef __cplusplus

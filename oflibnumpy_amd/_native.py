@@ -84,6 +84,7 @@ SIGNATURES = {
     "ofl_comm_unique_id": (_ci, [_vp]),
     "ofl_comm_init": (_ci, [_vp, _ci, _ci]),
     "ofl_comm_broadcast": (_ci, [_vp, _cs, _ci, _vp]),
+    "ofl_comm_size": (_ci, [ctypes.POINTER(_ci)]),
     "ofl_comm_destroy": (_ci, []),
 }
 

@@ -33,7 +33,8 @@ class DeviceFlowBatch:
         lib = nat.load()
         for i, f in enumerate(flows):
             m = np.ascontiguousarray(f.mask).view(np.uint8)
-            nat.check(lib.ofl_upload(b.vecs.ptr + i * px * 8, f.vecs.ctypes.data, px * 8, None))
+            v = np.ascontiguousarray(f.vecs, np.float32)       # Flow.vecs keeps the layout of its input (astype order 'K')
+            nat.check(lib.ofl_upload(b.vecs.ptr + i * px * 8, v.ctypes.data, px * 8, None))
             nat.check(lib.ofl_upload(b.mask.ptr + i * px, m.ctypes.data, px, None))
             nat.check(lib.ofl_stream_sync(None))
         return b

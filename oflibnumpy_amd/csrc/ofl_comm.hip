@@ -15,6 +15,7 @@ typedef int (*fn_init_rank)(nccl_comm_t *, int, nccl_uid_t, int);
 typedef int (*fn_bcast)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_destroy)(nccl_comm_t);
 typedef const char *(*fn_errstr)(int);
+typedef int (*fn_count)(nccl_comm_t, int *);
 
 struct Rccl {
     void       *handle = nullptr;
@@ -23,6 +24,7 @@ struct Rccl {
     fn_bcast    bcast = nullptr;
     fn_destroy  destroy = nullptr;
     fn_errstr   errstr = nullptr;
+    fn_count    count = nullptr;
     nccl_comm_t comm = nullptr;
     int         world = 0, rank = -1;
 } g;
@@ -41,6 +43,7 @@ int load_rccl()
     g.bcast     = (fn_bcast)dlsym(g.handle, "ncclBroadcast");
     g.destroy   = (fn_destroy)dlsym(g.handle, "ncclCommDestroy");
     g.errstr    = (fn_errstr)dlsym(g.handle, "ncclGetErrorString");
+    g.count     = (fn_count)dlsym(g.handle, "ncclCommCount");
     if (!g.get_uid || !g.init_rank || !g.bcast || !g.destroy)
         return fail(OFL_E_RCCL, "librccl lacks a required symbol");
     return OFL_OK;
@@ -88,6 +91,20 @@ int ofl_comm_broadcast(void *dptr, size_t bytes, int root, void *stream)
     if (bytes == 0) return OFL_OK;
     int rc = g.bcast(dptr, dptr, bytes, /*ncclUint8*/ 1, root, g.comm, stream_of(stream));
     if (rc != 0) return rccl_fail(rc, "ncclBroadcast");
+    return OFL_OK;
+}
+
+int ofl_comm_size(int *world)
+{
+    if (!world) return fail(OFL_E_INVALID, "ofl_comm_size: NULL");
+    *world = 0;
+    if (!g.comm) return OFL_OK;                       // no communicator: 0 ranks
+    int n = g.world;
+    if (g.count) {                                    // ask RCCL itself, not our bookkeeping
+        int rc = g.count(g.comm, &n);
+        if (rc != 0) return rccl_fail(rc, "ncclCommCount");
+    }
+    *world = n;
     return OFL_OK;
 }
 

@@ -32,6 +32,15 @@ int hip_fail(hipError_t e, const char *what)
 int need_device()
 {
     if (!rt().ready) return fail(OFL_E_NODEVICE, "no HIP device selected: call ofl_init(device) first");
+    // HIP's current device is per THREAD and defaults to 0: a caller on another thread than the one that ran
+    // ofl_init (a Python worker thread, a launcher's helper) would otherwise create streams / communicators on GPU 0
+    // while the buffers live on rt().device.  One cheap runtime call per thread.
+    static thread_local int bound = -1;
+    if (bound != rt().device) {
+        hipError_t e = hipSetDevice(rt().device);
+        if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+        bound = rt().device;
+    }
     return OFL_OK;
 }
 

@@ -45,3 +45,55 @@ def max_over_ranks(dist, values):
     t = torch.tensor([float(v) for v in values], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t]
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(script, argv, world, timeout=None, env=None):
+    """Self-launch: run `script argv` once per rank as FRESH child processes (subprocess, never os.exec*) with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them, relay rank 0's
+    stdout to ours and return the worst child exit code.  The caller must not have touched the GPU: the parent stays a
+    plain launcher.  Ranks > 0 write their stdout to our stderr (the contract is ONE JSON line on stdout)."""
+    import os
+    import subprocess
+    import sys
+    import time
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this pool
+    procs = []
+    for rank in range(world):
+        e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    out0 = b""
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs[1:]:
+            p.wait(timeout=None if deadline is None else max(1.0, deadline - time.monotonic()))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        sys.stdout.write(out0.decode("utf-8", "replace") if out0 else "")
+        sys.stdout.flush()
+        return 124
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    worst = 0
+    for p in procs:
+        rc = p.returncode
+        if rc != 0 and worst == 0:
+            worst = rc if rc > 0 else 128 - rc          # a signal: shell convention
+    return worst

@@ -80,3 +80,48 @@ def test_two_ranks_over_gloo(tmp_path):
     assert [d["uid_sum"] for d in outs] == [want_sum, want_sum]
     assert outs[0]["items"] + outs[1]["items"] == list(range(10))
     assert outs[0]["t"] == outs[1]["t"] == [2.0, 5.0]
+
+
+SPAWNED = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    if "WORLD_SIZE" not in os.environ:
+        from oflibnumpy_amd import sharding
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], int(sys.argv[1]), timeout=120))
+    import torch.distributed as dist
+    from oflibnumpy_amd import sharding
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["LOCAL_RANK"]) == rank
+    fd = os.dup(1); os.dup2(2, 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    os.dup2(fd, 1)
+    t = sharding.max_over_ranks(dist, [float(rank)])
+    print(json.dumps({{"rank": rank, "world": world, "max_rank": t[0], "argv": sys.argv[1:]}}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(int(sys.argv[2]) if rank == 1 else 0)
+""")
+
+
+def test_self_spawn_relays_rank0_and_worst_exit_code(tmp_path):
+    """`python bench.py --gpus N` without a launcher: the parent spawns N fresh rank processes with the torchrun
+    environment, prints rank 0's stdout only, and exits with the worst child code."""
+    script = tmp_path / "spawned.py"
+    script.write_text(SPAWNED.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for want_rc in (0, 5):
+        p = subprocess.run([sys.executable, str(script), "2", str(want_rc)], env=env, capture_output=True, text=True, timeout=180)
+        assert p.returncode == want_rc, p.stderr[-2000:]
+        lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        d = __import__("json").loads(lines[0])
+        assert d == {"rank": 0, "world": 2, "max_rank": 1.0, "argv": ["2", str(want_rc)]}
+
+
+def test_bench_launcher_mode_is_reached_before_the_engine_loads():
+    """bench.py / tools/bench_bands.py with --gpus N > 1 and no WORLD_SIZE must hand over to spawn_ranks before
+    loading the native library / selecting a device (the parent never touches the GPU)."""
+    for rel in ("bench.py", os.path.join("tools", "bench_bands.py")):
+        src = open(os.path.join(ROOT, rel)).read()
+        i_spawn, i_engine = src.index("spawn_ranks("), src.index("ensure_device()")
+        assert 0 < i_spawn < i_engine, rel          # the package import itself is pure Python: no dlopen, no HIP call

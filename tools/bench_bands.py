@@ -5,6 +5,7 @@ replicated -- rank 0's copy is broadcast over RCCL when the ranks own different 
 after the launch.  Strong scaling: the field is fixed, the bands shrink with N.
 
     python tools/bench_bands.py                      # 1 GPU (the whole field)
+    python tools/bench_bands.py --gpus N             # spawns its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         tools/bench_bands.py --gpus N [--steps K] [--check]
 """
@@ -28,7 +29,12 @@ def main():
     ap.add_argument("--tiles", type=int, nargs=2, default=[432, 384], help="repetitions of the 10 x 20 fixture (rows, cols)")
     ap.add_argument("--check", action="store_true", help="rank 0 also computes the whole field and compares its band")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # launcher mode: spawn the ranks before touching the GPU
+        from oflibnumpy_amd import sharding
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
     os.environ.setdefault("OFL_DEVICE", os.environ.get("LOCAL_RANK", "0"))
     import oflibnumpy_amd as of
     from oflibnumpy_amd import device as dev, sharding

@@ -66,8 +66,12 @@ enum {
     OFL_RULE_GT_HALF = 2    /* int16 concat (round-half-even): interpolated > 0.5 */
 };
 
-/* flag OR-ed into the `valid_rule` argument of the scatter entries */
-enum { OFL_SCATTER_ROUND = 0x100 };
+/* flags OR-ed into the `valid_rule` argument of the scatter entries */
+enum {
+    OFL_SCATTER_ROUND  = 0x100,  /* out = rint(result): np.round of integer-typed targets, utils.py:256-257 */
+    OFL_SCATTER_NEGATE = 0x200   /* out = -result: the values are -vals (Flow.invert s->s = self.apply(-self), flow_class.py:746,
+                                    without materialising -self; negation commutes exactly with the interpolation) */
+};
 
 /* bits written by the zero-flow statistics (ofl_flow_stats_dev, and the fused compose kernel) */
 enum {
@@ -223,6 +227,32 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
                          float *out_rows, uint8_t *valid_rows, int valid_rule,
                          void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
 int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes);
+
+/* Certificate of the warped grid as a triangulation (one pass over the flow, one 144-byte read-back; synchronises).
+ * SciPy's griddata (utils.py:253) triangulates the points with Qhull; the cell-wise mesh of the warped grid IS that
+ * Delaunay triangulation when no triangle is folded, every interior edge passes the local Delaunay test, no point is
+ * dropped and the mesh border is straight between the warped image corners (then the convex hull is the border's).
+ * `certified` = 1 states exactly that; such a field takes ofl_scatter_certified_dev -- one kernel, no owner map, no
+ * atomics, no synchronisation.  The scatter entries above certify internally on every call; callers that warp with
+ * the same field repeatedly certify once and keep the record (it depends on flow, sign, point_precision, pmask only).
+ */
+typedef struct ofl_mesh_cert {
+    uint32_t certified;        /* 1: cell-wise mesh == Delaunay triangulation of the warped points (up to co-circular cells) */
+    uint32_t folded_cells;     /* cells whose two triangles are not both positively oriented */
+    uint32_t bad_edges;        /* interior mesh edges failing the local Delaunay (in-circle) test beyond rounding */
+    uint32_t dropped;          /* 1: pmask drops points */
+    double   border_dev;       /* px: largest distance of a border point from the straight side between its corners */
+    double   corner[4][2];     /* warped image corners (x, y): (0,0), (W-1,0), (W-1,H-1), (0,H-1) */
+} ofl_mesh_cert;
+int ofl_scatter_certify_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask, int H, int W,
+                            void *workspace, size_t workspace_bytes, ofl_mesh_cert *cert_host, void *stream);
+/* Rows [row0, row0 + rows) of the grid result for a CERTIFIED field (cert->certified must be 1, no point mask):
+ * out_rows [rows][W][C], valid_rows [rows][W] as in ofl_scatter_linear_dev; asynchronous.  fail_count_dev (device
+ * uint32, may be NULL) counts nodes inside the hull for which no triangle was found -- 0 for a true certificate. */
+int ofl_scatter_certified_dev(const float *flow, int sign, int point_precision, const float *vals, int C,
+                              const uint8_t *vmask, int H, int W, int row0, int rows, float *out_rows,
+                              uint8_t *valid_rows, int valid_rule, const ofl_mesh_cert *cert,
+                              uint32_t *fail_count_dev, void *stream);
 int ofl_scatter_linear(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                        const float *vals, int C, const uint8_t *vmask, int H, int W,
                        const float *query, float *out, uint8_t *valid, int valid_rule);

@@ -16,8 +16,14 @@ U8, I16, U16, F32, F64 = 0, 1, 2, 3, 4
 QUANT_OPENCV, QUANT_EXACT = 0, 1
 ARITH_NATIVE, ARITH_FLOAT_RNE = 0, 1
 RULE_EQ1, RULE_GE_HALF, RULE_GT_HALF = 0, 1, 2
-SCATTER_ROUND = 0x100
+SCATTER_ROUND, SCATTER_NEGATE = 0x100, 0x200
 STAT_NONZERO_MASKED, STAT_NONZERO_TH_MASKED, STAT_NONZERO, STAT_NONZERO_TH, STAT_NONFINITE, STAT_MASK_HAS_ZERO = 1, 2, 4, 8, 16, 32
+
+
+class MeshCert(ctypes.Structure):
+    """ofl_mesh_cert of include/ofl.h"""
+    _fields_ = [("certified", ctypes.c_uint32), ("folded_cells", ctypes.c_uint32), ("bad_edges", ctypes.c_uint32),
+                ("dropped", ctypes.c_uint32), ("border_dev", ctypes.c_double), ("corner", (ctypes.c_double * 2) * 4)]
 
 
 class NativeError(RuntimeError):
@@ -71,6 +77,8 @@ SIGNATURES = {
     "ofl_scatter_linear_f64_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_rows_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_linear_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
+    "ofl_scatter_certify_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _ci, _vp, _cs, _vp, _vp]),
+    "ofl_scatter_certified_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp]),
     "ofl_scatter_workspace_bytes": (_ci, [_ci, _ci, _ci, ctypes.POINTER(_cs)]),
     "ofl_scatter_linear": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci]),
     "ofl_sample_points_dev": (_ci, [_vp, _ci, _ci, _vp, _cs, _vp, _vp]),

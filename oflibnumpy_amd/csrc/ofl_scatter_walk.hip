@@ -1,0 +1,426 @@
+// ofl_scatter_walk.hip -- K3 fast path: the warped grid as a CERTIFIED Delaunay triangulation.
+//
+// scipy.interpolate.griddata(points, values, grid, 'linear') (src/oflibnumpy/utils.py:253) triangulates the
+// warped grid points with Qhull.  When the cell-wise mesh of the warped grid -- every source cell split along its
+// Delaunay diagonal -- has (1) only positively oriented triangles, (2) only locally Delaunay interior edges and
+// (3) a border that is straight between the four warped image corners, then by the Delaunay lemma that mesh IS the
+// Delaunay triangulation of the points (unique up to co-circular cells, where Qhull itself is arbitrary), and the
+// convex hull of the points is the hull of the border points.  `scatter_certify_kernel` evaluates exactly these
+// conditions in one pass over the flow (counts + border deviations, read back once per field and cached by the
+// caller); for a certified field `scatter_walk_kernel` resolves every output node in ONE pass without an owner map,
+// atomics, a hull on the host or any synchronisation: the node finds its source cell by Newton steps on the
+// piecewise-affine map (the flow at the node gives the first estimate, each visited triangle's affine map the
+// next) and interpolates with SciPy's inclusion rule and float64 barycentric coordinates.  Every affine field of the
+// reference's tests and of BASELINE configs 1-4 is certified; anything else goes to the exact path (ofl_delaunay.hip).
+#include "ofl_scatter_dev.h"
+#include <math.h>
+#include <type_traits>
+
+using namespace ofl;
+using namespace ofl_sc;
+
+namespace {
+
+constexpr double kEdgeTol   = 1e-12;   // relative in-circle excess that counts as "not locally Delaunay" (beyond rounding)
+constexpr double kBorderMax = 1e-4;    // px: largest deviation of a border point from its straight side for a certificate
+constexpr int    kWalkIters = 16;
+
+struct CertDev {                       // device record written by the certify kernel (128 bytes)
+    uint32_t folded, bad_edges, dropped, degenerate;
+    unsigned long long dev_min[4], dev_max[4];      // ordered keys of the signed border deviations per side (inward > 0)
+    D2 corner[4];                                    // P(0,0), P(W-1,0), P(W-1,H-1), P(0,H-1)
+};
+static_assert(sizeof(CertDev) == 16 + 64 + 64, "CertDev layout");
+
+struct WalkCert { D2 c[4]; double delta; };
+
+__device__ __forceinline__ unsigned long long okey(double d)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+double okey_inv(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int off)
+{
+    const int lo = __shfl_xor(__double2loint(v), off), hi = __shfl_xor(__double2hiint(v), off);
+    return __hiloint2double(hi, lo);
+}
+
+// in-circle determinant of d against the positively oriented triangle (a, b, c), divided by the fourth power of the
+// local length scale: > 0 when d is inside the circumcircle
+__device__ __forceinline__ double incircle_rel(const D2 &a, const D2 &b, const D2 &c, const D2 &d)
+{
+    const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    const double a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+    const double ic = ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx);
+    const double s = a2 + b2 + c2;
+    return s > 0.0 ? ic / (s * s) : 0.0;
+}
+
+__device__ __forceinline__ void tri_pts(int diag, int t, const D2 &pa, const D2 &pb, const D2 &pc, const D2 &pd,
+                                        D2 &q0, D2 &q1, D2 &q2)
+{
+    int i0, i1, i2;
+    tri_corners(diag, t, i0, i1, i2);
+    q0 = pick4(i0, pa, pb, pc, pd); q1 = pick4(i1, pa, pb, pc, pd); q2 = pick4(i2, pa, pb, pc, pd);
+}
+
+// ------------------------------------------------------------------------------------------------ certificate
+__global__ __launch_bounds__(256)
+void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                            CertDev *__restrict__ out)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const bool inpt = x < W && y < H;
+    int fold = 0, bad = 0, drop = 0;
+    if (inpt && pmask && !pmask[(size_t)y * W + x]) drop = 1;
+    if (x < W - 1 && y < H - 1) {
+        const D2 pa = point_of(flow, sign, W, x, y), pb = point_of(flow, sign, W, x + 1, y);
+        const D2 pc = point_of(flow, sign, W, x + 1, y + 1), pd = point_of(flow, sign, W, x, y + 1);
+        const int diag = pick_diagonal(pa, pb, pc, pd);
+        D2 u0, u1, u2, v0, v1, v2;
+        tri_pts(diag, 0, pa, pb, pc, pd, u0, u1, u2);
+        tri_pts(diag, 1, pa, pb, pc, pd, v0, v1, v2);
+        // convex, positively oriented cells only (a reflex cell is a legal mesh cell, but the walk kernel's diagonal
+        // rule assumes convexity; such fields take the exact path)
+        if (!(cross2(pa, pb, pc) > 0.0 && cross2(pa, pc, pd) > 0.0 && cross2(pb, pc, pd) > 0.0 && cross2(pb, pd, pa) > 0.0)) {
+            fold = 1;
+        } else {
+            // the cell's own diagonal is Delaunay by construction; its right and bottom edges are shared with the
+            // neighbouring cells: the vertex opposite the edge in the neighbour's triangle must not lie inside the
+            // circumcircle of this cell's triangle on the edge (local Delaunay test).  Left / top edges belong to the
+            // neighbours on that side; edges on the image border have no second triangle.
+            if (x + 2 < W) {
+                const D2 pb2 = point_of(flow, sign, W, x + 2, y), pc2 = point_of(flow, sign, W, x + 2, y + 1);
+                const int dr = pick_diagonal(pb, pb2, pc2, pc);
+                const D2 opp = dr == 0 ? pc2 : pb2;                       // (a', c', d') or (b', d', a') holds the edge d'-a'
+                // this cell's triangle on the edge b-c: diag 0 -> (a, b, c) = triangle 0; diag 1 -> (b, c, d) = triangle 0
+                if (incircle_rel(u0, u1, u2, opp) > kEdgeTol) bad += 1;
+            }
+            if (y + 2 < H) {
+                const D2 pd2 = point_of(flow, sign, W, x, y + 2), pc3 = point_of(flow, sign, W, x + 1, y + 2);
+                const int db = pick_diagonal(pd, pc, pc3, pd2);
+                const D2 opp = db == 0 ? pc3 : pd2;                       // (a", b", c") or (b", d", a") holds the edge a"-b"
+                // this cell's triangle on the edge c-d: diag 0 -> (a, c, d) = triangle 1; diag 1 -> (b, c, d) = triangle 0
+                const bool t1 = diag == 0;
+                if (incircle_rel(t1 ? v0 : u0, t1 ? v1 : u1, t1 ? v2 : u2, opp) > kEdgeTol) bad += 1;
+            }
+        }
+    }
+    // border: signed distance of every border point from the straight line between the two warped corners of its side
+    const bool border_block = blockIdx.x == 0 || blockIdx.y == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.y == gridDim.y - 1;
+    int degen = 0;
+    if (border_block) {
+        const D2 c0 = point_of(flow, sign, W, 0, 0), c1 = point_of(flow, sign, W, W - 1, 0);
+        const D2 c2 = point_of(flow, sign, W, W - 1, H - 1), c3 = point_of(flow, sign, W, 0, H - 1);
+        D2 p = { 0.0, 0.0 };
+        if (inpt) p = point_of(flow, sign, W, x, y);
+#pragma unroll
+        for (int side = 0; side < 4; ++side) {
+            const bool on = inpt && (side == 0 ? y == 0 : side == 1 ? x == W - 1 : side == 2 ? y == H - 1 : x == 0);
+            const D2 A = pick4(side, c0, c1, c2, c3), B = pick4((side + 1) & 3, c0, c1, c2, c3);
+            const double len = sqrt((B.x - A.x) * (B.x - A.x) + (B.y - A.y) * (B.y - A.y));
+            double dmin = 1e300, dmax = -1e300;
+            if (on) {
+                if (!(len > 0.0)) degen = 1;
+                else dmin = dmax = cross2(A, B, p) / len;
+            }
+            if (__any(on)) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    dmin = fmin(dmin, shfl_xor_d(dmin, off));
+                    dmax = fmax(dmax, shfl_xor_d(dmax, off));
+                }
+                if ((threadIdx.x & 63) == 0 && dmin <= dmax) {
+                    atomicMin(&out->dev_min[side], okey(dmin));
+                    atomicMax(&out->dev_max[side], okey(dmax));
+                }
+            }
+        }
+        if (inpt) {
+            if (x == 0 && y == 0) out->corner[0] = p;
+            if (x == W - 1 && y == 0) out->corner[1] = p;
+            if (x == W - 1 && y == H - 1) out->corner[2] = p;
+            if (x == 0 && y == H - 1) out->corner[3] = p;
+        }
+    }
+    const int nf = __syncthreads_count(fold), nd = __syncthreads_or(drop), ng = __syncthreads_or(degen);
+    // bad edges: up to two per thread
+    const int nb = __syncthreads_count(bad >= 1) + __syncthreads_count(bad >= 2);
+    if (threadIdx.x == 0) {
+        if (nf) atomicAdd(&out->folded, (uint32_t)nf);
+        if (nb) atomicAdd(&out->bad_edges, (uint32_t)nb);
+        if (nd) out->dropped = 1u;
+        if (ng) out->degenerate = 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ walk
+struct Hit { size_t vi[3]; double c0, c1, c2; float2 fv[3]; };
+
+struct __attribute__((aligned(8))) Pair2 { float lo_u, lo_v, hi_u, hi_v; };    // two adjacent vectors: ONE 16-byte load
+
+__device__ __forceinline__ D2 warp_pt(int x, int y, float u, float v, int sign)
+{
+    D2 p;
+    p.x = sign >= 0 ? (double)x + (double)u : (double)x - (double)u;
+    p.y = sign >= 0 ? (double)y + (double)v : (double)y - (double)v;
+    if (sign == 2 || sign == -2) { p.x = (double)(float)p.x; p.y = (double)(float)p.y; }
+    return p;
+}
+
+// Tests the two triangles of source cell (cx, cy) for the position (qx, qy) with SciPy's inclusion rule (division-free
+// edge functions; the certificate guarantees convex, positively oriented cells, so the Delaunay diagonal is one
+// in-circle sign).  On a miss the affine map of the less-missed triangle turns the position into a new estimate
+// (ex, ey) of its source index (a Newton step on the piecewise-affine map).
+__device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int sign, int W, int cx, int cy,
+                                         double qx, double qy, Hit &h, double &ex, double &ey)
+{
+    const size_t i00 = (size_t)cy * W + cx;
+    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(flow + 2 * i00);
+    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(flow + 2 * (i00 + W));
+    const D2 pa = warp_pt(cx, cy, r0.lo_u, r0.lo_v, sign), pb = warp_pt(cx + 1, cy, r0.hi_u, r0.hi_v, sign);
+    const D2 pc = warp_pt(cx + 1, cy + 1, r1.hi_u, r1.hi_v, sign), pd = warp_pt(cx, cy + 1, r1.lo_u, r1.lo_v, sign);
+    const int diag = incircle(pa, pb, pc, pd) > 0 ? 1 : 0;             // as pick_diagonal for a convex, positive cell
+    double best = -1e300;
+    int bt = 0;
+    double bw1 = 0.0, bw2 = 0.0, bdet = 1.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int i0, i1, i2;
+        tri_corners(diag, t, i0, i1, i2);
+        const D2 q0 = pick4(i0, pa, pb, pc, pd), q1 = pick4(i1, pa, pb, pc, pd), q2 = pick4(i2, pa, pb, pc, pd);
+        const double e1x = q1.x - q0.x, e1y = q1.y - q0.y, e2x = q2.x - q0.x, e2y = q2.y - q0.y;
+        const double det = e1x * e2y - e1y * e2x;                       // > 0 (certificate)
+        const double dx = qx - q0.x, dy = qy - q0.y;
+        const double w1 = dx * e2y - dy * e2x, w2 = e1x * dy - e1y * dx, w0 = det - w1 - w2;
+        const double tol = kEps * det;
+        const double worst = fmin(w0, fmin(w1, w2));
+        if (worst >= -tol) {
+            const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
+            const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
+            const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
+            h.vi[0] = (size_t)y0 * W + x0; h.vi[1] = (size_t)y1 * W + x1; h.vi[2] = (size_t)y2 * W + x2;
+            h.c1 = w1 / det; h.c2 = w2 / det; h.c0 = 1.0 - h.c1 - h.c2;        // the coordinates as `bary` forms them
+            const float2 fa = make_float2(r0.lo_u, r0.lo_v), fb = make_float2(r0.hi_u, r0.hi_v);
+            const float2 fc = make_float2(r1.hi_u, r1.hi_v), fd = make_float2(r1.lo_u, r1.lo_v);
+            h.fv[0] = pick4(i0, fa, fb, fc, fd); h.fv[1] = pick4(i1, fa, fb, fc, fd); h.fv[2] = pick4(i2, fa, fb, fc, fd);
+            return true;
+        }
+        if (worst / det > best) { best = worst / det; bt = t; bw1 = w1; bw2 = w2; bdet = det; }
+    }
+    {
+        int i0, i1, i2;
+        tri_corners(diag, bt, i0, i1, i2);
+        const double c1 = bw1 / bdet, c2 = bw2 / bdet, c0 = 1.0 - c1 - c2;
+        const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
+        const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
+        const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
+        ex = c0 * x0 + c1 * x1 + c2 * x2;
+        ey = c0 * y0 + c1 * y1 + c2 * y2;
+    }
+    return false;
+}
+
+__device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int sign, int H, int W, int x, int y, Hit &h)
+{
+    const double qx = (double)x, qy = (double)y;
+    // first estimate of the source index: one Newton step from the node itself, i = q - J^-1 (P(q) - q), with the
+    // Jacobian J = I + s * grad f from the differences to the node's right / lower neighbours (exact for affine fields)
+    const int xn = x + 1 < W ? x + 1 : x - 1, yn = y + 1 < H ? y + 1 : y - 1;
+    const float2 f0 = *reinterpret_cast<const float2 *>(flow + ((size_t)y * W + x) * 2);
+    const float2 fxn = *reinterpret_cast<const float2 *>(flow + ((size_t)y * W + xn) * 2);
+    const float2 fyn = *reinterpret_cast<const float2 *>(flow + ((size_t)yn * W + x) * 2);
+    const double sg = sign >= 0 ? 1.0 : -1.0, hx = (double)(xn - x), hy = (double)(yn - y);
+    const double ja = 1.0 + sg * ((double)fxn.x - (double)f0.x) / hx, jb = sg * ((double)fyn.x - (double)f0.x) / hy;
+    const double jc = sg * ((double)fxn.y - (double)f0.y) / hx, jd = 1.0 + sg * ((double)fyn.y - (double)f0.y) / hy;
+    const double jdet = ja * jd - jb * jc, rx = sg * (double)f0.x, ry = sg * (double)f0.y;
+    double ex = qx - rx, ey = qy - ry;
+    if (fabs(jdet) > 1e-3) { ex = qx - (jd * rx - jb * ry) / jdet; ey = qy - (ja * ry - jc * rx) / jdet; }
+    int pcx = -1, pcy = -1, ppcx = -2, ppcy = -2;
+    for (int it = 0; it < kWalkIters; ++it) {
+        const int cx = (int)fmin(fmax(floor(ex), 0.0), (double)(W - 2)), cy = (int)fmin(fmax(floor(ey), 0.0), (double)(H - 2));
+        if ((cx == pcx && cy == pcy) || (cx == ppcx && cy == ppcy)) break;      // no progress / a 2-cycle across an edge
+        ppcx = pcx; ppcy = pcy; pcx = cx; pcy = cy;
+        if (try_cell(flow, sign, W, cx, cy, qx, qy, h, ex, ey)) return true;
+    }
+    // the estimate stopped moving without a hit (a node outside the mesh ends here, clamped to a border cell; a node on
+    // a cell edge may alternate between its two sides): the cells around the last two stops decide
+    double dx, dy;
+    for (int k = 0; k < 2; ++k) {
+        const int bx = k ? ppcx : pcx, by = k ? ppcy : pcy;
+        if (bx < 0) continue;
+        for (int oy = -1; oy <= 1; ++oy)
+            for (int ox = -1; ox <= 1; ++ox) {
+                const int cx = bx + ox, cy = by + oy;
+                if (cx < 0 || cy < 0 || cx > W - 2 || cy > H - 2) continue;
+                if (try_cell(flow, sign, W, cx, cy, qx, qy, h, dx, dy)) return true;
+            }
+    }
+    return false;
+}
+
+// Exact hull membership of a node that no mesh triangle covers and that lies within the certificate's band around the
+// straight line of border side `side`: with o the outward and s the tangential coordinate of the side's points
+// relative to the node, the node is inside the convex hull iff a point on its left and a point on its right span a
+// chord that passes on or outside it: max_L o/|s| + max_R o/s >= 0.  SciPy covers such a node with the sliver triangle
+// on that chord, i.e. (up to the sliver's height) the interpolation between the chord's end points.
+__device__ bool side_scan(const float *__restrict__ flow, int sign, int H, int W, int side, const WalkCert &wc,
+                          double qx, double qy, Hit &h)
+{
+    const D2 A = wc.c[side], B = wc.c[(side + 1) & 3];
+    const double len = sqrt((B.x - A.x) * (B.x - A.x) + (B.y - A.y) * (B.y - A.y));
+    const double tx = (B.x - A.x) / len, ty = (B.y - A.y) / len;
+    const int n = (side & 1) ? H : W;
+    double aL = -1e300, aR = -1e300, sL = 0.0, sR = 0.0;
+    size_t iL = 0, iR = 0;
+    for (int i = 0; i < n; ++i) {
+        const int px = side == 0 ? i : side == 1 ? W - 1 : side == 2 ? W - 1 - i : 0;
+        const int py = side == 0 ? 0 : side == 1 ? i : side == 2 ? H - 1 : H - 1 - i;
+        const D2 p = point_of(flow, sign, W, px, py);
+        const double dx = p.x - qx, dy = p.y - qy;
+        const double s = dx * tx + dy * ty, o = -(-ty * dx + tx * dy);
+        if (s == 0.0) {
+            if (o >= 0.0) { iL = iR = (size_t)py * W + px; sL = -1.0; sR = 1.0; aL = aR = 0.0; break; }
+            continue;
+        }
+        const double a = o / fabs(s);
+        if (s < 0.0) { if (a > aL) { aL = a; sL = s; iL = (size_t)py * W + px; } }
+        else         { if (a > aR) { aR = a; sR = s; iR = (size_t)py * W + px; } }
+    }
+    if (aL == -1e300 || aR == -1e300 || !(aL + aR >= -1e-14)) return false;
+    const double span = sR - sL;
+    h.vi[0] = iL; h.vi[1] = iR; h.vi[2] = iL;
+    h.c0 = sR / span; h.c1 = -sL / span; h.c2 = 0.0;
+    return true;
+}
+
+template <typename VT, bool FLOWVALS>      // FLOWVALS: vals == flow, C == 2: the values are the corner vectors already loaded
+__global__ __launch_bounds__(256)
+void scatter_walk_kernel(const float *__restrict__ flow, int sign, const VT *__restrict__ vals, int C,
+                         const uint8_t *__restrict__ vmask, int H, int W, int row0, int rows,
+                         VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, WalkCert wc,
+                         uint32_t *__restrict__ fail)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
+    if (x >= W || yl >= rows) return;
+    const size_t o = (size_t)yl * W + x;
+    Hit h;
+    bool found = walk_locate(flow, sign, H, W, x, y, h);
+    if (!found) {
+        // not covered by the mesh: outside the convex hull -- unless the node sits within the noise band of a border
+        // side, where the hull of the (almost collinear) border points decides
+        const double qx = (double)x, qy = (double)y;
+        bool outside = false, inside_all = true;
+        int near_mask = 0;
+#pragma unroll
+        for (int side = 0; side < 4; ++side) {
+            const D2 A = wc.c[side], B = wc.c[(side + 1) & 3];
+            const double len = sqrt((B.x - A.x) * (B.x - A.x) + (B.y - A.y) * (B.y - A.y));
+            const double d = cross2(A, B, D2{ qx, qy }) / len;            // inward > 0
+            if (d < -2.0 * wc.delta - 1e-12) outside = true;
+            else if (d <= 2.0 * wc.delta + 1e-12) near_mask |= 1 << side;
+        }
+        if (!outside && near_mask) {
+            bool first = true;
+            for (int side = 0; side < 4 && inside_all; ++side) {
+                if (!((near_mask >> side) & 1)) continue;
+                Hit hs;
+                if (!side_scan(flow, sign, H, W, side, wc, qx, qy, hs)) inside_all = false;
+                else if (first) { h = hs; first = false; }
+            }
+            found = inside_all;
+        } else if (!outside && fail) {
+            atomicAdd(fail, 1u);            // well inside the hull and still no triangle: the certificate was wrong
+        }
+    }
+    if (found && FLOWVALS && h.c2 != 0.0) {     // (side-scan hits carry no corner vectors: c2 == 0 marks them)
+        const double u = h.c0 * (double)h.fv[0].x + h.c1 * (double)h.fv[1].x + h.c2 * (double)h.fv[2].x;
+        const double v = h.c0 * (double)h.fv[0].y + h.c1 * (double)h.fv[1].y + h.c2 * (double)h.fv[2].y;
+        const bool neg = (valid_rule & OFL_SCATTER_NEGATE) != 0, rnd = (valid_rule & OFL_SCATTER_ROUND) != 0;
+        const double ru = rnd ? rint(u) : u, rv = rnd ? rint(v) : v;
+        *reinterpret_cast<float2 *>(out + o * 2) = make_float2((float)(neg ? -ru : ru), (float)(neg ? -rv : rv));
+        resolve_emit(vals, 0, vmask, h.vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);       // validity only
+    } else if (found) {
+        resolve_emit(vals, C, vmask, h.vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);
+    } else {
+        for (int c = 0; c < C; ++c) out[o * C + c] = (VT)0;              // NaN -> 0, utils.py:254
+        if (valid) valid[o] = 0;
+    }
+}
+
+}  // namespace
+
+namespace ofl_sc {
+
+// host side of the certificate: launch, ONE small read-back, evaluation
+int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, void *scratch128,
+                 ofl_mesh_cert *cert, hipStream_t s)
+{
+    memset(cert, 0, sizeof(*cert));
+    if (H < 2 || W < 2) return OFL_OK;                                   // no cells: never certified
+    CertDev init;
+    memset(&init, 0, sizeof(init));
+    for (int k = 0; k < 4; ++k) { init.dev_min[k] = ~0ull; init.dev_max[k] = 0ull; }
+    CertDev *dev = (CertDev *)scratch128;
+    OFL_HIP(hipMemcpyAsync(dev, &init, sizeof(init), hipMemcpyHostToDevice, s));
+    const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
+    hipLaunchKernelGGL(scatter_certify_kernel, grid, block, 0, s, flow, sign_pp, pmask, H, W, dev);
+    OFL_HIP(hipGetLastError());
+    CertDev r;
+    OFL_HIP(hipMemcpyAsync(&r, dev, sizeof(r), hipMemcpyDeviceToHost, s));
+    OFL_HIP(hipStreamSynchronize(s));
+    cert->folded_cells = r.folded;
+    cert->bad_edges = r.bad_edges;
+    cert->dropped = r.dropped;
+    double dev_abs = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        if (r.dev_min[k] == ~0ull) { dev_abs = INFINITY; break; }
+        dev_abs = fmax(dev_abs, fmax(fabs(okey_inv(r.dev_min[k])), fabs(okey_inv(r.dev_max[k]))));
+    }
+    cert->border_dev = dev_abs;
+    bool convex = !r.degenerate;
+    for (int k = 0; k < 4; ++k) {
+        cert->corner[k][0] = r.corner[k].x; cert->corner[k][1] = r.corner[k].y;
+        const D2 a = r.corner[k], b = r.corner[(k + 1) & 3], c = r.corner[(k + 2) & 3];
+        if (!((b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x) > 0.0)) convex = false;
+    }
+    cert->certified = (r.folded == 0 && r.bad_edges == 0 && r.dropped == 0 && convex && dev_abs <= kBorderMax) ? 1u : 0u;
+    return OFL_OK;
+}
+
+template <typename VT>
+int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uint8_t *vmask, int H, int W,
+                int row0, int rows, VT *out, uint8_t *valid, int valid_rule, const ofl_mesh_cert *cert,
+                uint32_t *fail_dev, hipStream_t s)
+{
+    WalkCert wc;
+    for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
+    wc.delta = cert->border_dev;
+    const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
+    if (std::is_same<VT, float>::value && (const void *)vals == (const void *)flow && C == 2)
+        hipLaunchKernelGGL((scatter_walk_kernel<VT, true>), grid, block, 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
+                           out, valid, valid_rule, wc, fail_dev);
+    else
+        hipLaunchKernelGGL((scatter_walk_kernel<VT, false>), grid, block, 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
+                           out, valid, valid_rule, wc, fail_dev);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+template int walk_launch<float>(const float *, int, const float *, int, const uint8_t *, int, int, int, int, float *,
+                                uint8_t *, int, const ofl_mesh_cert *, uint32_t *, hipStream_t);
+template int walk_launch<double>(const float *, int, const double *, int, const uint8_t *, int, int, int, int, double *,
+                                 uint8_t *, int, const ofl_mesh_cert *, uint32_t *, hipStream_t);
+
+}  // namespace ofl_sc

@@ -209,6 +209,7 @@ class DeviceFlow:
         self.shape = (int(shape[0]), int(shape[1]))
         self.ref = ref
         self._stats = stats
+        self._certs = {}            # (sign, point_precision) -> MeshCert of the warped grid without a point mask
 
     # -- construction / transfer
     @classmethod
@@ -233,7 +234,23 @@ class DeviceFlow:
         return self.vecs.to_host((h, w, 2), np.float32), self.mask.to_host((h, w), np.uint8).view(np.bool_)    # bytes are 0 / 1
 
     def relabel(self, ref):
-        return DeviceFlow(self.vecs, self.mask, self.shape, ref, self._stats)
+        out = DeviceFlow(self.vecs, self.mask, self.shape, ref, self._stats)
+        out._certs = self._certs        # same vectors: same warped grid
+        return out
+
+    def mesh_cert(self, sign, point_precision=0):
+        """Certificate of the grid warped by sign * vecs with every point kept (ofl_scatter_certify_dev): evaluated
+        once per field and sign, then the certified scatter entry runs without any synchronisation."""
+        key = (sign, point_precision)
+        c = self._certs.get(key)
+        if c is None:
+            h, w = self.shape
+            c = nat.MeshCert()
+            ws = _workspace(h, w, 0)
+            nat.check(_lib().ofl_scatter_certify_dev(self.vecs.ptr, sign, point_precision, None, h, w, ws.ptr, ws.nbytes,
+                                                     ctypes.byref(c), None))
+            self._certs[key] = c
+        return c
 
     @property
     def n_px(self):
@@ -284,6 +301,7 @@ class DeviceFlow:
     def __neg__(self):
         out = self._axpy(None, -1.0)
         out._stats = self._stats            # the zero-flow predicates do not change under negation
+        out._certs = {(-sg, pp): c for (sg, pp), c in self._certs.items()}      # x - (-f) is x + f: same warped grid
         return out
 
     def _compose(self, sampled, sign, quant=nat.QUANT_OPENCV):
@@ -350,8 +368,9 @@ class DeviceFlow:
             return image, vmask
         out = DeviceImage(DeviceBuffer(self.n_px * C * 4), image.shape, np.float32)
         valid = DeviceBuffer(self.n_px)
-        scatter_linear(self.vecs, +1, self._point_mask(consider_mask), image.buf, C, vmask, h, w, None,
-                       out.buf, valid, 0)
+        pm = self._point_mask(consider_mask)
+        scatter_linear(self.vecs, +1, pm, image.buf, C, vmask, h, w, None, out.buf, valid, 0,
+                       cert=self.mesh_cert(+1) if pm is None else None)
         return out, valid
 
     def resize(self, scale):
@@ -382,16 +401,21 @@ class DeviceFlow:
             self._stats = flow_stats(self.vecs, self.mask, self.n_px) | _STATS_KNOW_MASK
         return self.mask if (self._stats & nat.STAT_MASK_HAS_ZERO) else None
 
-    def _scatter_flow(self, target, consider_mask=True, sign=1):
-        """'s'-reference apply of a Flow target: utils.py:237-258 + flow_class.py:634-643, 668."""
+    def _scatter_flow(self, target, consider_mask=True, sign=1, negate=False):
+        """'s'-reference apply of a Flow target: utils.py:237-258 + flow_class.py:634-643, 668.  negate: the target is
+        -`target` (its vectors are negated inside the kernel, OFL_SCATTER_NEGATE)."""
         if self.is_zero(thresholded=True, masked=False):
-            return target._and_mask(self)
+            return (-target if negate else target)._and_mask(self)
         h, w = self.shape
         out = DeviceFlow.empty(self.shape, target.ref)
-        vmask = DeviceBuffer(self.n_px)
-        _mask_and(target.mask, self.mask, vmask, self.n_px)      # mask channel, flow_class.py:643
-        scatter_linear(self.vecs, sign, self._point_mask(consider_mask), target.vecs, 2, vmask,
-                       h, w, None, out.vecs, out.mask, 0)
+        if target.mask is self.mask:
+            vmask = self.mask                                     # m & m
+        else:
+            vmask = DeviceBuffer(self.n_px)
+            _mask_and(target.mask, self.mask, vmask, self.n_px)  # mask channel, flow_class.py:643
+        pm = self._point_mask(consider_mask)
+        scatter_linear(self.vecs, sign, pm, target.vecs, 2, vmask, h, w, None, out.vecs, out.mask,
+                       nat.SCATTER_NEGATE if negate else 0, cert=self.mesh_cert(sign) if pm is None else None)
         return out
 
     def switch_ref(self):
@@ -408,7 +432,8 @@ class DeviceFlow:
         """Flow.invert, flow_class.py:735-753."""
         ref = self.ref if ref is None else ref
         if self.ref == 's':
-            return self.apply(-self) if ref == 's' else (-self).relabel('t')
+            # s -> s: self.apply(-self) (flow_class.py:746) -- the negation happens inside the scatter kernel
+            return self._scatter_flow(self, negate=True) if ref == 's' else (-self).relabel('t')
         if ref == 's':
             return (-self).relabel('s')
         return self.invert('s').switch_ref()
@@ -501,8 +526,9 @@ class DeviceFlow:
             return self.mask
         h, w = self.shape
         valid = DeviceBuffer(self.n_px)
-        scatter_linear(self.vecs, sign, self._point_mask(consider_mask), None, 0, self.mask,
-                       h, w, None, None, valid, 0)
+        pm = self._point_mask(consider_mask)
+        scatter_linear(self.vecs, sign, pm, None, 0, self.mask, h, w, None, None, valid, 0,
+                       cert=self.mesh_cert(sign) if pm is None else None)
         return valid
 
 
@@ -572,12 +598,18 @@ def _workspace(h, w, C):
 
 
 def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, valid_rule, point_precision=0,
-                   stream=None):
+                   stream=None, cert=None):
     """K3: scattered -> regular-grid linear interpolation.  Replaces utils.py:237-258 (and, with `query`,
-    flow_class.py:1398-1410).  Raises ValueError("No points given") like qhull when nothing is kept."""
+    flow_class.py:1398-1410).  Raises ValueError("No points given") like qhull when nothing is kept.
+    cert: a MeshCert of this very (flow, sign, point_precision) without point mask; when it certifies the mesh the
+    asynchronous one-kernel entry is taken (no workspace, no read-back)."""
+    ptr = lambda b: b.ptr if b is not None else None
+    if cert is not None and cert.certified and pmask is None and query is None:
+        nat.check(_lib().ofl_scatter_certified_dev(flow.ptr, sign, point_precision, ptr(vals), C, ptr(vmask), h, w, 0, h,
+                                                   ptr(out), ptr(valid), valid_rule, ctypes.byref(cert), None, stream))
+        return (h * w, 0, 0)
     ws = _workspace(h, w, C)
     info = (ctypes.c_uint64 * 3)()
-    ptr = lambda b: b.ptr if b is not None else None
     nat.check(_lib().ofl_scatter_linear_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),
                                             h, w, ptr(query), ptr(out), ptr(valid), valid_rule, ws.ptr, ws.nbytes,
                                             info, stream))

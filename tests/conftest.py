@@ -32,6 +32,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden2():
+    """Round-2 reference outputs (tests/golden/make_golden.py::main_delaunay): folds, holes, curved borders, shear."""
+    return np.load(os.path.join(GOLDEN, "ref_delaunay_cases.npz"))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import np_oracle
     np_oracle.build()

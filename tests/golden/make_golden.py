@@ -181,5 +181,81 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def main_delaunay(of):
+    """Round 2: cases where the cell-wise mesh of the warped grid is NOT the Delaunay triangulation SciPy builds --
+    folds (the tiled Sintel field of BASELINE config 5 as loaded), holes of the point mask with random image values,
+    curved mesh borders, sheared cells, larger smooth deformations, speckled point masks.  Written to a second file so
+    that ref_scipy_paths.npz stays byte-identical."""
+    Flow = of.Flow
+    out = {}
+    rng = np.random.default_rng(29)
+
+    def case(tag, f, img, consider_mask=True, with_invert=True):
+        out[tag + "/in_vecs"] = f.vecs
+        out[tag + "/in_mask"] = f.mask
+        out[tag + "/img"] = img
+        w, v = f.apply(img, return_valid_area=True, consider_mask=consider_mask)
+        out[tag + "/apply"] = w
+        out[tag + "/apply_valid"] = v
+        out[tag + "/valid_target"] = f.valid_target(consider_mask=consider_mask)
+        if with_invert:
+            r = f.invert()
+            out[tag + "/invert_vecs"] = r.vecs
+            out[tag + "/invert_mask"] = r.mask
+
+    # 1. BASELINE config 5 as loaded: tests/sintel.flo (10 x 20, u = r * c, v = 0) tiled 4 x 4, ref 's' (from_sintel)
+    flo = Flow.from_sintel("/root/reference/tests/sintel.flo")
+    assert flo.ref == 's'
+    tiled = Flow(np.tile(flo.vecs, (4, 4, 1)), 's')
+    case("sintel4x4", tiled, rng.random((40, 80, 3), dtype=np.float32))
+
+    shape = (60, 80)
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype('f')
+    img = rng.random(shape + (3,), dtype=np.float32)
+    base = Flow.from_transforms([['rotation', 40, 30, 14], ['scaling', 20, 20, 0.93]], shape, 's')
+
+    # 2. a 20 x 30 hole in the point mask, random image values
+    hole = np.ones(shape, bool)
+    hole[20:40, 25:55] = False
+    case("hole_img", Flow(base.vecs, 's', hole), img)
+
+    # 3. curved mesh border (radial distortion: the convex hull reaches beyond the warped border in pockets)
+    r2 = ((xx - 40) ** 2 + (yy - 30) ** 2) / 2500.0
+    barrel = np.stack([(xx - 40) * 0.06 * r2, (yy - 30) * 0.06 * r2], -1).astype('f')
+    case("curved", Flow(base.vecs + barrel, 's'), img)
+    pincushion = -barrel
+    case("curved_in", Flow(base.vecs + pincushion, 's'), img)
+
+    # 4. sheared cells: x += 1.3 y -- grid edges stop being Delaunay everywhere
+    shear = np.zeros(shape + (2,), 'f')
+    shear[..., 0] = 1.3 * yy - 30
+    case("shear", Flow(shear, 's'), img)
+
+    # 5. a larger smooth deformation (3 px sinusoid, near fold-over) on top of a similarity
+    wob = np.stack([3.0 * np.sin(2 * np.pi * xx / 47.0) * np.cos(2 * np.pi * yy / 31.0),
+                    2.0 * np.cos(2 * np.pi * xx / 37.0) * np.sin(2 * np.pi * yy / 41.0)], -1).astype('f')
+    case("wobble3", Flow(base.vecs + wob, 's'), img)
+
+    # 6. speckled point mask (10 % dropped) with random image values, smooth non-affine field
+    small = np.stack([0.5 * np.sin(xx / 9) * np.cos(yy / 7), 0.4 * np.cos(xx / 8) * np.sin(yy / 6)], -1).astype('f')
+    speck = rng.random(shape) > 0.1
+    case("speckle_img", Flow(base.vecs + small, 's', speck), img)
+
+    # 7. anisotropic scaling + shear (affine, but no cell is co-circular: the triangulation is unique)
+    aff = np.stack([0.15 * (xx - 30) + 0.2 * (yy - 20), -0.1 * (xx - 30) + 0.25 * (yy - 20)], -1).astype('f')
+    case("affine_generic", Flow(aff, 's'), img)
+    case("affine_generic_hole", Flow(aff, 's', hole), img)
+
+    # 8. motion boundary with a generic (non-integer, non-axis-aligned) background motion
+    blk = (base.vecs + small).copy()
+    blk[18:40, 22:58] += np.array([6.4, -3.7], 'f')
+    case("block_generic", Flow(blk, 's'), img)
+
+    path = os.path.join(HERE, "ref_delaunay_cases.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 if __name__ == "__main__":
     main()
+    main_delaunay(_import_reference())

@@ -1,0 +1,183 @@
+"""GPU parity tests of the two round-2 scatter paths behind ofl_scatter_linear_dev:
+
+  * the CERTIFIED fast path (ofl_scatter_certify_dev + ofl_scatter_certified_dev): when the cell-wise mesh of the
+    warped grid provably is the Delaunay triangulation SciPy builds, one kernel resolves the grid;
+  * the EXACT path for everything else: a real Delaunay triangulation of the kept points on the GPU.
+
+Expected values come from the oracle (which calls the same scipy.interpolate.griddata as the reference,
+src/oflibnumpy/utils.py:253) and from outputs of the real reference in tests/golden/.  Bars: validity masks
+bit-exact, values within 1e-4 relative wherever the Delaunay triangulation is unique (co-circular cells -- exact
+squares of translations / axis-aligned scalings -- are the only exemption: Qhull itself is arbitrary there).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 2e-5
+
+
+def certify(of, vecs, sign=1, pmask=None, pp=0):
+    from oflibnumpy_amd import device as dev
+    nat, lib = of.native, of.native.load()
+    h, w = vecs.shape[:2]
+    f = dev.DeviceBuffer.from_host(np.ascontiguousarray(vecs, np.float32))
+    pm = dev.DeviceBuffer.from_host(pmask.astype(np.uint8)) if pmask is not None else None
+    ws = dev._workspace(h, w, 0)
+    c = nat.MeshCert()
+    nat.check(lib.ofl_scatter_certify_dev(f.ptr, sign, pp, pm.ptr if pm is not None else None, h, w, ws.ptr, ws.nbytes,
+                                          ctypes.byref(c), None))
+    return c
+
+
+def wobble(shape, ax=0.5, ay=0.4):
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float32)
+    return np.stack([ax * np.sin(xx / 9) * np.cos(yy / 7), ay * np.cos(xx / 8) * np.sin(yy / 6)], -1).astype(np.float32)
+
+
+def test_certificates(gpu):
+    """What the certify pass reports for the field families of the reference's tests and of BASELINE.json."""
+    of = gpu
+    shape = (48, 64)
+    for tr in ([['rotation', 20, 30, 25]], [['scaling', 10, 8, 0.85]], [['translation', 3, -2]],
+               [['translation', 3.3, -2.7]], [['rotation', 16, 12, 15], ['scaling', 5, 5, 1.1]]):
+        for sign in (1, -1):
+            c = certify(of, of.from_transforms(tr, shape, 's'), sign)
+            assert c.certified == 1 and c.folded_cells == 0 and c.bad_edges == 0 and c.dropped == 0, (tr, sign)
+            assert c.border_dev < 1e-4
+    v = of.from_transforms([['rotation', 20, 30, 10]], shape, 's')
+    c = certify(of, v + wobble(shape, 1.5, 1.2))
+    assert c.certified == 0 and c.border_dev > 0.1 and c.folded_cells == 0           # curved border: hull != mesh border
+    blk = np.zeros(shape + (2,), np.float32)
+    blk[12:28, 16:40] = [4.3, 2.6]
+    c = certify(of, blk)
+    assert c.certified == 0 and c.folded_cells > 0 and c.bad_edges > 0               # motion boundary: folds and stretched cells
+    shear = np.zeros(shape + (2,), np.float32)
+    shear[..., 0] = 1.7 * np.mgrid[:shape[0], :shape[1]][0]                          # x += 1.7 y: grid edges stop being Delaunay
+    c = certify(of, shear)
+    assert c.certified == 0 and c.folded_cells == 0 and c.bad_edges > 1000
+    m = np.ones(shape, bool)
+    m[5, 7] = False
+    assert certify(of, v, pmask=m).certified == 0 and certify(of, v, pmask=m).dropped == 1
+    # BASELINE configs 1-4 at reduced size: all affine
+    for tr in ([['rotation', 200, 150, -30]], [['scaling', 100, 80, 0.9]], [['rotation', 192, 108, -20], ['scaling', 100, 80, 0.9]]):
+        assert certify(of, of.from_transforms(tr, (216, 384), 's')).certified == 1
+
+
+def affine_field(shape, a, b, c, d, tx=0.0, ty=0.0):
+    """flow of the affine map (x, y) -> (x, y) + [[a, b], [c, d]] (x - w/2, y - h/2) + (tx, ty)"""
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float64)
+    xx -= shape[1] / 2.0
+    yy -= shape[0] / 2.0
+    return np.stack([a * xx + b * yy + tx, c * xx + d * yy + ty], -1).astype(np.float32)
+
+
+def test_certified_walk_matches_scipy(gpu, oracle):
+    """Image-valued 's' warps of certified fields against SciPy: random (non-affine) values, a speckled value mask,
+    1-3 channels, both signs.  Generic affine maps (anisotropic scaling + mild shear) have no co-circular cell, so
+    EVERY node must agree; similarity transforms leave exactly co-circular cells (their float32 rounding is the
+    same at all four corners of ~13 % of the cells), where Qhull's choice is arbitrary and only the rest is compared."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev
+    from test_gpu_scatter import ambiguous_nodes
+    rng = np.random.default_rng(5)
+    fields = [((40, 56), affine_field((40, 56), 0.15, 0.2, -0.1, 0.25, 1.3, -0.4), True),
+              ((37, 91), affine_field((37, 91), -0.2, 0.1, 0.15, -0.1, -3.0, 2.0), True),
+              ((64, 48), affine_field((64, 48), 0.4, -0.15, 0.1, 0.3), True),
+              ((40, 56), of.from_transforms([['rotation', 20, 25, 17]], (40, 56), 's'), False),
+              ((50, 50), of.from_transforms([['scaling', 20, 30, 0.8], ['rotation', 25, 25, 45]], (50, 50), 's'), False)]
+    for it, (shape, vecs, unique) in enumerate(fields):
+        tr = it
+        h, w = shape
+        sign = 1 if it % 2 == 0 else -1
+        C = 1 + it % 3
+        vals = rng.standard_normal((h, w, C)).astype(np.float32)
+        vm = rng.random((h, w)) > 0.2
+        c = certify(of, vecs, sign)
+        assert c.certified == 1
+        f, dv, dm = (dev.DeviceBuffer.from_host(a) for a in (vecs, vals, vm.astype(np.uint8)))
+        out, valid, cnt = dev.DeviceBuffer(h * w * C * 4), dev.DeviceBuffer(h * w), dev.DeviceBuffer.zeros(16)
+        of.native.check(of.native.load().ofl_scatter_certified_dev(f.ptr, sign, 0, dv.ptr, C, dm.ptr, h, w, 0, h, out.ptr, valid.ptr,
+                                                                   0, ctypes.byref(c), cnt.ptr, None))
+        got, gv = out.to_host((h, w, C), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+        assert int(cnt.to_host((1,), np.uint32)[0]) == 0
+        want = O.scatter_griddata(sign * vecs, np.concatenate([vals, vm[..., None].astype(np.float32)], -1), None)
+        amb = ambiguous_nodes(vecs, sign)
+        assert amb.sum() == 0 if unique else amb.mean() < 0.7
+        np.testing.assert_array_equal(gv[~amb], (want[..., -1] == 1)[~amb], err_msg=str(tr))
+        bad = ~np.isclose(got, want[..., :C], rtol=RTOL, atol=ATOL).all(-1)
+        assert not (bad & ~amb).any(), (tr, int((bad & ~amb).sum()))
+        # the generic entry takes the same path and gives the same bits; so do row bands
+        out2, valid2 = dev.DeviceBuffer(h * w * C * 4), dev.DeviceBuffer(h * w)
+        dev.scatter_linear(f, sign, None, dv, C, dm, h, w, None, out2, valid2, 0)
+        np.testing.assert_array_equal(out2.to_host((h, w, C), np.float32), got)
+        np.testing.assert_array_equal(valid2.to_host((h, w), np.uint8).astype(bool), gv)
+        parts = []
+        for r0, r1 in ((0, 13), (13, 14), (14, h)):
+            ob, vb = dev.DeviceBuffer((r1 - r0) * w * C * 4), dev.DeviceBuffer((r1 - r0) * w)
+            dev.scatter_rows(f, sign, None, dv, C, dm, h, w, r0, r1 - r0, ob, vb)
+            parts.append(ob.to_host((r1 - r0, w, C), np.float32))
+        np.testing.assert_array_equal(np.concatenate(parts), got)
+
+
+def test_certified_4k_no_walk_failures(gpu):
+    """BASELINE config 3 at full size through the certified entry: the failure counter stays 0, the inverse matches
+    the analytic one, and the fused negation equals the two-step form bit for bit."""
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    shape = [2160, 3840]
+    for tr, inv_tr in (([['scaling', 1000, 800, 0.9]], [['scaling', 1000, 800, 1 / 0.9]]),
+                       ([['rotation', 1920, 1080, -20]], [['rotation', 1920, 1080, 20]])):
+        f = of.Flow.from_transforms(tr, shape, 's')
+        d = f.to_device()
+        c = d.mesh_cert(+1)
+        assert c.certified == 1, (tr, c.folded_cells, c.bad_edges, c.border_dev)
+        h, w = shape
+        out, valid, cnt = dev.DeviceBuffer(h * w * 8), dev.DeviceBuffer(h * w), dev.DeviceBuffer.zeros(16)
+        of.native.check(of.native.load().ofl_scatter_certified_dev(d.vecs.ptr, 1, 0, d.vecs.ptr, 2, d.mask.ptr, h, w, 0, h, out.ptr,
+                                                                   valid.ptr, of.native.SCATTER_NEGATE, ctypes.byref(c), cnt.ptr, None))
+        assert int(cnt.to_host((1,), np.uint32)[0]) == 0
+        got, gm = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+        want = of.Flow.from_transforms(inv_tr, shape, 's')
+        assert gm.mean() > 0.5
+        np.testing.assert_allclose(got[gm], want.vecs[gm], rtol=1e-4, atol=2e-3)
+        inv = d.invert()
+        v2, m2 = inv.to_host()
+        np.testing.assert_array_equal(v2, got)
+        np.testing.assert_array_equal(m2, gm)
+        two_step = d.apply(-d).to_host()
+        np.testing.assert_array_equal(two_step[0], got)
+        np.testing.assert_array_equal(two_step[1], gm)
+
+
+def test_nodes_in_the_noise_band_of_the_border(gpu, oracle):
+    """A translation that puts the warped top border ON a row of nodes, plus 1e-6 px of noise: whether such a node
+    is inside the convex hull is decided by the (almost collinear) border points, exactly as SciPy's hull does."""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(8)
+    shape = (24, 32)
+    for k in range(6):
+        vecs = np.zeros(shape + (2,), np.float32)
+        vecs[..., 0] = 0.25
+        vecs[..., 1] = 1.0
+        vecs[0, :, 1] += (rng.random(shape[1]) - 0.5).astype(np.float32) * 2e-6      # top border at y = 1 +- 1e-6
+        vecs[:, 0, 0] += (rng.random(shape[0]) - 0.5).astype(np.float32) * 2e-6
+        c = certify(of, vecs)
+        assert c.certified == 1 and 0 < c.border_dev < 1e-5
+        f, o = of.Flow(vecs, 's'), O.OFlow(vecs, 's')
+        np.testing.assert_array_equal(f.valid_target(), o.valid_target(), err_msg=str(k))
+        img = rng.random(shape + (2,), dtype=np.float32)
+        gw, gv = f.apply(img, return_valid_area=True)
+        ow, ov = o.apply(img, return_valid_area=True)
+        np.testing.assert_array_equal(gv, ov)
+        # nodes on the noise band (row 1): SciPy interpolates inside a sliver triangle of height 1e-6 between border
+        # points, the kernel along the sliver's chord -- both convex combinations of values of the border row, equal for
+        # affine data; everything else agrees to rounding
+        np.testing.assert_allclose(gw[2:], ow[2:], rtol=RTOL, atol=ATOL)
+        on = gv[1]
+        assert (gw[1][on] >= img[0].min(0) - 1e-6).all() and (gw[1][on] <= img[0].max(0) + 1e-6).all()
+        gi, oi = f.invert(), o.invert()
+        np.testing.assert_array_equal(gi.mask, oi.mask)
+        np.testing.assert_allclose(gi.vecs[gi.mask], oi.vecs[oi.mask], rtol=RTOL, atol=ATOL)

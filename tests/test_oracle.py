@@ -63,6 +63,26 @@ def test_oracle_matches_reference_outputs(oracle, golden):
             np.testing.assert_array_equal(r, golden[tag + '/out'], err_msg=tag)
 
 
+def delaunay_tags(g):
+    return sorted({k.split('/')[0] for k in g.files})
+
+
+def test_oracle_matches_reference_outputs_round2(oracle, golden2):
+    """The round-2 cases (folded tiled Sintel field of BASELINE config 5 as loaded, holes with image values, curved
+    borders, sheared cells, speckled point masks, generic affine fields): bit for bit."""
+    tags = delaunay_tags(golden2)
+    assert len(tags) == 10 and 'sintel4x4' in tags
+    for tag in tags:
+        f = oracle.OFlow(golden2[tag + '/in_vecs'], 's', golden2[tag + '/in_mask'])
+        w, v = f.apply(golden2[tag + '/img'], return_valid_area=True)
+        np.testing.assert_array_equal(w, golden2[tag + '/apply'], err_msg=tag)
+        np.testing.assert_array_equal(v, golden2[tag + '/apply_valid'], err_msg=tag)
+        np.testing.assert_array_equal(f.valid_target(), golden2[tag + '/valid_target'], err_msg=tag)
+        r = f.invert()
+        np.testing.assert_array_equal(r.vecs, golden2[tag + '/invert_vecs'], err_msg=tag)
+        np.testing.assert_array_equal(r.mask, golden2[tag + '/invert_mask'], err_msg=tag)
+
+
 def B(rows):
     return np.array(rows).astype(bool)
 

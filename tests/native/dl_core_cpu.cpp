@@ -1,0 +1,120 @@
+// CPU build of the exact scatter path's geometry core (oflibnumpy_amd/csrc/ofl_delaunay_core.h) -- TEST infrastructure:
+// tests/test_delaunay_core.py compiles this file with g++ and checks the stars it produces against SciPy's Delaunay
+// triangulation on the reference fixtures.  The product never loads it (the GPU kernels include the same header).
+#include "../../oflibnumpy_amd/csrc/ofl_delaunay_core.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+using namespace ofl_dl;
+
+namespace {
+
+// sequential clip for polygons of any size (the far pass; the GPU version of this step is workgroup-cooperative)
+template <class RelFn>
+int poly_clip_any(Poly &P, const P2 &C, int ctag, RelFn rel, std::vector<char> &cut)
+{
+    const double h = 0.5 * (C.x * C.x + C.y * C.y);
+    const int n = P.n;
+    cut.assign(n, 0);
+    int ncut = 0;
+    for (int k = 0; k < n; ++k) { cut[k] = vertex_cut(P, k, n, C, ctag, h, rel); ncut += cut[k]; }
+    if (ncut == 0 || ncut == n) return 0;
+    int a = -1;
+    for (int k = 0; k < n; ++k) if (cut[k] && !cut[k == 0 ? n - 1 : k - 1]) { a = k; break; }
+    int L = 0;
+    while (cut[(a + L) % n]) ++L;
+    const int b = (a + L - 1) % n, ia = a == 0 ? n - 1 : a - 1, ib = (b + 1) % n;
+    if (n - L + 2 > P.cap) return -1;
+    const int tb = P.T(b);
+    const P2 v1 = cut_point(P.T(ia), C, h, rel, P.X(ia), P.Y(ia), P.X(a), P.Y(a));
+    const P2 v2 = cut_point(tb, C, h, rel, P.X(b), P.Y(b), P.X(ib), P.Y(ib));
+    std::vector<double> nx, ny; std::vector<int> nt;
+    for (int j = 0; j < n - L; ++j) { const int k = (b + 1 + j) % n; nx.push_back(P.X(k)); ny.push_back(P.Y(k)); nt.push_back(P.T(k)); }
+    nx.push_back(v1.x); ny.push_back(v1.y); nt.push_back(ctag);
+    nx.push_back(v2.x); ny.push_back(v2.y); nt.push_back(tb);
+    for (size_t k = 0; k < nx.size(); ++k) { P.X((int)k) = nx[k]; P.Y((int)k) = ny[k]; P.T((int)k) = nt[k]; }
+    P.n = (int)nx.size();
+    return 1;
+}
+
+}  // namespace
+
+// pts [n][2]; tri_out receives (p, a, b) for every pair of consecutive real neighbours of every star ("emit all");
+// info: [0] far sites, [1] polygon overflows in the near pass, [2] grid gx, [3] grid gy
+extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, int *tri_out, long long tri_cap,
+                            long long *n_tri, int *info)
+{
+    if (n <= 0) return -1;
+    double x0 = pts[0], x1 = pts[0], y0 = pts[1], y1 = pts[1];
+    for (int i = 1; i < n; ++i) {
+        x0 = std::min(x0, pts[2 * i]); x1 = std::max(x1, pts[2 * i]);
+        y0 = std::min(y0, pts[2 * i + 1]); y1 = std::max(y1, pts[2 * i + 1]);
+    }
+    Grid g;
+    const double bw = x1 - x0, bh = y1 - y0;
+    double s = sqrt(std::max(bw * bh, 1e-300) / n);
+    s = std::max(s, (bw + bh) / (double)n);
+    if (!(s > 0)) s = 1.0;
+    g.ox = x0; g.oy = y0; g.s = s; g.inv_s = 1.0 / s;
+    g.gx = (int)floor(bw / s) + 1; g.gy = (int)floor(bh / s) + 1;
+    const size_t nb = (size_t)g.gx * g.gy;
+    std::vector<unsigned> bstart(nb + 1, 0), sorted(n), cursor(nb, 0);
+    auto bucket = [&](int i) { return (size_t)g.by(pts[2 * i + 1]) * g.gx + g.bx(pts[2 * i]); };
+    for (int i = 0; i < n; ++i) ++bstart[bucket(i) + 1];
+    for (size_t b = 0; b < nb; ++b) bstart[b + 1] += bstart[b];
+    for (int i = 0; i < n; ++i) { const size_t b = bucket(i); sorted[bstart[b] + cursor[b]++] = (unsigned)i; }   // ascending index per bucket
+    auto pos = [&](int i) { return P2{ pts[2 * i], pts[2 * i + 1] }; };
+    std::vector<double> vx(4096), vy(4096);
+    std::vector<int> tag(4096);
+    std::vector<int> far;
+    std::vector<char> flags;
+    long long nt = 0;
+    int overflow = 0;
+    auto emit = [&](int p, const Poly &P) {
+        for (int k = 0; k < P.n; ++k) {
+            const int a = P.T(k), b = P.T((k + 1) % P.n);
+            if (a < 0 || b < 0 || a == b) continue;
+            if (nt < tri_cap) { tri_out[3 * nt] = p; tri_out[3 * nt + 1] = a; tri_out[3 * nt + 2] = b; }
+            ++nt;
+        }
+    };
+    for (int p = 0; p < n; ++p) {
+        Poly P{ vx.data(), vy.data(), tag.data(), 1, near_cap, 0 };
+        const int rc = star_near(P, p, pos(p), g, bstart.data(), sorted.data(), pos, rings);
+        if (rc == 1) { emit(p, P); continue; }
+        if (rc < 0) ++overflow;
+        far.push_back(p);
+    }
+    for (int p : far) {
+        Poly P{ vx.data(), vy.data(), tag.data(), 1, 4096, 0 };
+        poly_init(P);
+        const P2 pp = pos(p);
+        auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
+        // the sites of the near rings first (nearest buckets first shrink the cell quickly), then every far site
+        const int bx = g.bx(pp.x), by = g.by(pp.y);
+        for (int r = 0; r <= rings; ++r)
+            for (int row = by - r; row <= by + r; ++row) {
+                if (row < 0 || row >= g.gy) continue;
+                for (int col = bx - r; col <= bx + r; ++col) {
+                    if (col < 0 || col >= g.gx) continue;
+                    if (std::max(abs(row - by), abs(col - bx)) != r) continue;
+                    for (unsigned j = bstart[(size_t)row * g.gx + col]; j < bstart[(size_t)row * g.gx + col + 1]; ++j) {
+                        const int c = (int)sorted[j];
+                        const P2 C = rel(c);
+                        if (c == p || (C.x == 0.0 && C.y == 0.0)) continue;
+                        if (poly_clip_any(P, C, c, rel, flags) < 0) return -2;
+                    }
+                }
+            }
+        for (int c : far) {
+            const P2 C = rel(c);
+            if (c == p || (C.x == 0.0 && C.y == 0.0)) continue;
+            if (poly_clip_any(P, C, c, rel, flags) < 0) return -2;
+        }
+        emit(p, P);
+    }
+    *n_tri = nt;
+    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy;
+    return 0;
+}

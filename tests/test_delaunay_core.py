@@ -1,0 +1,122 @@
+"""CPU suite, part 4: the geometry core of the exact scatter path (oflibnumpy_amd/csrc/ofl_delaunay_core.h, the very
+header the HIP kernels include) compiled for the host and checked against scipy.spatial.Delaunay -- what
+scipy.interpolate.griddata (src/oflibnumpy/utils.py:253) triangulates with -- on the reference fixtures: every
+simplex SciPy builds that is UNIQUELY Delaunay (no other site within rounding of its circumcircle) must be found
+by the stars, and every triangle the stars emit must have an empty circumcircle."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.spatial import Delaunay, cKDTree
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def core(tmp_path_factory):
+    out = tmp_path_factory.mktemp("dlcore") / "libdlcore.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(out),
+                           os.path.join(ROOT, "tests", "native", "dl_core_cpu.cpp")])
+    lib = ctypes.CDLL(str(out))
+    lib.dl_stars_cpu.restype = ctypes.c_int
+    return lib
+
+
+def stars(lib, pts, rings=6, near_cap=16):
+    pts = np.ascontiguousarray(pts, np.float64)
+    n = len(pts)
+    cap = 12 * n + 1024
+    tri = np.zeros((cap, 3), np.int32)
+    nt = ctypes.c_longlong(0)
+    info = (ctypes.c_int * 4)()
+    rc = lib.dl_stars_cpu(pts.ctypes.data_as(ctypes.c_void_p), n, rings, near_cap, tri.ctypes.data_as(ctypes.c_void_p),
+                          ctypes.c_longlong(cap), ctypes.byref(nt), info)
+    assert rc == 0 and nt.value <= cap
+    return tri[:nt.value], list(info)
+
+
+def circum(pts, tri):
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    bx, by, cx, cy = b[:, 0] - a[:, 0], b[:, 1] - a[:, 1], c[:, 0] - a[:, 0], c[:, 1] - a[:, 1]
+    d = 2 * (bx * cy - by * cx)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ux = (cy * (bx * bx + by * by) - by * (cx * cx + cy * cy)) / d
+        uy = (bx * (cx * cx + cy * cy) - cx * (bx * bx + by * by)) / d
+    return np.stack([a[:, 0] + ux, a[:, 1] + uy], 1), np.hypot(ux, uy), d
+
+
+def unique_simplices(pts, simplices, tol=1e-9):
+    """simplices with no FOURTH site within tol (relative) of their circumcircle"""
+    cen, r, d = circum(pts, simplices)
+    tree = cKDTree(pts)
+    ok = np.zeros(len(simplices), bool)
+    for i, (c, rad) in enumerate(zip(cen, r)):
+        if not np.isfinite(rad) or rad > 1e6:
+            continue
+        near = tree.query_ball_point(c, rad * (1 + 1e-6) + 1e-9)
+        others = [j for j in near if j not in simplices[i]]
+        ok[i] = all(abs(np.hypot(*(pts[j] - c)) - rad) > tol * max(rad, 1.0) for j in others)
+    return ok
+
+
+def fixture_points(g, tag):
+    vecs, mask = g[tag + '/in_vecs'], g[tag + '/in_mask']
+    h, w = vecs.shape[:2]
+    yy, xx = np.mgrid[:h, :w]
+    p = np.stack([(xx + vecs[..., 0].astype(np.float64)).ravel(), (yy + vecs[..., 1].astype(np.float64)).ravel()], 1)
+    return p[mask.ravel()]
+
+
+@pytest.mark.parametrize("tag", ["curved", "curved_in", "shear", "wobble3", "speckle_img", "affine_generic",
+                                 "affine_generic_hole", "block_generic", "hole_img"])
+def test_stars_equal_scipy_delaunay(core, golden2, tag):
+    pts = fixture_points(golden2, tag)
+    tri, info = stars(core, pts)
+    assert info[1] == 0 or info[0] > 0                      # overflowing stars went to the far pass
+    ours = {tuple(sorted(t)) for t in tri.tolist()}
+    d = Delaunay(pts)
+    uniq = unique_simplices(pts, d.simplices)
+    assert uniq.mean() > (0.5 if tag == "hole_img" else 0.9)          # hole_img: a similarity, ~13 % co-circular cells
+    missing = [tuple(sorted(s)) for s, u in zip(d.simplices.tolist(), uniq) if u and tuple(sorted(s)) not in ours]
+    assert not missing, (tag, len(missing), missing[:5])
+    # nothing but Delaunay triangles: no site strictly inside a circumcircle (beyond rounding)
+    t = np.array(sorted(ours))
+    cen, r, det = circum(pts, t)
+    tree = cKDTree(pts)
+    good = np.isfinite(r) & (r < 1e6)
+    dist, _ = tree.query(cen[good], k=4)
+    assert (dist[:, 3] >= r[good] * (1 - 1e-7) - 1e-9).all(), tag
+    # every star is emitted from each of its sites: a unique simplex appears three times
+    cnt = {}
+    for tt in tri.tolist():
+        cnt[tuple(sorted(tt))] = cnt.get(tuple(sorted(tt)), 0) + 1
+    assert all(cnt[tuple(sorted(s))] == 3 for s, u in zip(d.simplices.tolist(), uniq) if u)
+
+
+def test_stars_on_folds_and_duplicates(core, golden2):
+    """BASELINE config 5 as loaded: the tiled Sintel field puts every site on the integer lattice, many of them twice.
+    The stars still cover SciPy's triangulation wherever it is unique, and their triangles are all Delaunay."""
+    pts = fixture_points(golden2, "sintel4x4")
+    tri, info = stars(core, pts)
+    ours = {tuple(sorted(t)) for t in tri.tolist()}
+    upts, inv = np.unique(pts, axis=0, return_inverse=True)
+    d = Delaunay(upts)
+    uniq = unique_simplices(upts, d.simplices)
+    ours_u = {tuple(sorted(int(inv[i]) for i in t)) for t in ours}
+    missing = [tuple(sorted(s)) for s, u in zip(d.simplices.tolist(), uniq) if u and tuple(sorted(s)) not in ours_u]
+    assert not missing, (len(missing), missing[:5])
+
+
+def test_far_pass_handles_unbounded_and_large_cells(core):
+    """Random sites with a large empty disc: hull sites (unbounded cells) and the rim of the disc (cells larger than
+    the ring search) go through the far pass; the result is SciPy's triangulation."""
+    rng = np.random.default_rng(3)
+    pts = rng.random((3000, 2)) * [120, 90]
+    pts = pts[np.hypot(pts[:, 0] - 60, pts[:, 1] - 45) > 25]
+    tri, info = stars(core, pts, rings=3)
+    assert info[0] > 50
+    ours = {tuple(sorted(t)) for t in tri.tolist()}
+    ref = {tuple(sorted(s)) for s in Delaunay(pts).simplices.tolist()}
+    assert ref <= ours and len(ours - ref) == 0

@@ -176,8 +176,8 @@ def test_nodes_in_the_noise_band_of_the_border(gpu, oracle):
         # points, the kernel along the sliver's chord -- both convex combinations of values of the border row, equal for
         # affine data; everything else agrees to rounding
         np.testing.assert_allclose(gw[2:], ow[2:], rtol=RTOL, atol=ATOL)
-        on = gv[1]
-        assert (gw[1][on] >= img[0].min(0) - 1e-6).all() and (gw[1][on] <= img[0].max(0) + 1e-6).all()
+        lo, hi = img[:2].min((0, 1)) - 1e-6, img[:2].max((0, 1)) + 1e-6
+        assert (gw[1][gv[1]] >= lo).all() and (gw[1][gv[1]] <= hi).all()
         gi, oi = f.invert(), o.invert()
         np.testing.assert_array_equal(gi.mask, oi.mask)
         np.testing.assert_allclose(gi.vecs[gi.mask], oi.vecs[oi.mask], rtol=RTOL, atol=ATOL)

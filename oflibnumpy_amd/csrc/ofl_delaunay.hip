@@ -1,0 +1,729 @@
+// ofl_delaunay.hip -- K3 exact path: a real Delaunay triangulation of the warped points on the GPU.
+//
+// Replaces scipy.interpolate.griddata(points, values, grid, 'linear') (src/oflibnumpy/utils.py:253) for every field
+// whose cell-wise mesh is NOT provably the Delaunay triangulation (ofl_scatter_walk.hip certifies the others):
+// folded meshes (motion boundaries, the tiled Sintel field of BASELINE config 5 as loaded), dropped points (holes and
+// speckle of the point mask), curved mesh borders (pockets between the mesh and its convex hull), sheared cells.
+//
+//   bin      the kept points are counting-sorted into a bucket grid over their bounding box (~1 point per bucket)
+//   stars    one thread per point builds its Voronoi cell / Delaunay star from the buckets around it
+//            (ofl_delaunay_core.h: half-plane clipping, in-circle decisions, security radius); cells that are not
+//            final within kRings bucket rings -- hull points, rims of large holes, fan apexes of border pockets --
+//            are finished by one WORKGROUP per point against the near buckets plus all other unfinished points
+//            (every Delaunay neighbour of an unfinished point beyond the ring search is itself unfinished)
+//   raster   every star's triangles (p, n_k, n_k+1) are scan-converted with SciPy's inclusion rule; atomicMin keeps
+//            the smallest triangle id per node -- each triangle is emitted by all three of its sites, so stars that
+//            disagree on an exactly co-circular cell (where Qhull itself is arbitrary) still tile the hull
+//   resolve  float64 barycentric interpolation from the owner triangle, vertices in canonical order so that all
+//            copies of a triangle give the same bits; nodes without an owner are outside the convex hull (NaN -> 0)
+//
+// Everything is a pure function of the inputs (buckets are sorted by point index, far points are compacted in
+// index order, triangle ids derive from point indices), so row bands concatenate to the full result bit for bit.
+#include "ofl_scatter_dev.h"
+#include "ofl_delaunay_core.h"
+#include <algorithm>
+#include <vector>
+
+using namespace ofl;
+using namespace ofl_sc;
+using namespace ofl_dl;
+
+namespace {
+
+constexpr int      kRings    = 6;        // bucket rings of the per-thread star pass
+constexpr int      kNearCap  = 16;       // polygon capacity of the per-thread pass == neighbour slots per point
+constexpr int      kSlots    = 16;
+constexpr int      kFarCap   = 2560;     // polygon capacity of the workgroup pass (LDS: 20 B per vertex)
+constexpr unsigned kFarK     = 4096;     // triangle-id stride of a far point (>= kFarCap)
+constexpr unsigned kNoOwner  = 0xFFFFFFFFu;
+constexpr int      kSmallArea = 1024;
+constexpr unsigned char kDegFar = 0xFF;
+constexpr int      kScanChunk = 2048;    // elements per block of the scan kernels (256 threads x 8)
+
+struct DlHead {                           // device header of the exact path (256 bytes)
+    unsigned long long kx0, kx1, ky0, ky1;   // ordered keys of the bounding box while it is reduced
+    Grid     grid;
+    unsigned kept, n_far, pool_used, err;    // err bit 0: far polygon overflow, bit 1: pool overflow, bit 2: big list overflow
+    unsigned long long big_n;
+    unsigned pad[32];
+};
+static_assert(sizeof(DlHead) <= 256, "DlHead");
+
+struct DlWs {
+    DlHead   *head;
+    unsigned *bstart;      // [bcap + 1] counts -> exclusive starts
+    unsigned *scan_tmp;    // block sums of the scan levels
+    unsigned *sorted;      // [N] point indices bucket by bucket
+    unsigned char *deg;    // [N] 0 .. 16, kDegFar
+    unsigned *nbr;         // [N][kSlots]   (doubles as the bucket cursors while sorting)
+    unsigned *far_idx;     // [N]
+    unsigned *far_deg;     // [N]
+    unsigned *far_off;     // [N]
+    int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
+    unsigned *big;         // [big_cap] triangle ids with a large bounding box
+    uint32_t *owner;       // [H][W] (biased by the first row of the band)
+    size_t    bcap, pool_cap, big_cap;
+    int       oy0, oy1;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t scan_tmp_elems(size_t n)
+{
+    size_t t = 0;
+    while (n > 1) { n = (n + kScanChunk - 1) / kScanChunk; t += n; }
+    return t + 16;
+}
+
+// device-side helpers -------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long okey(double d)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double okey_inv(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct PosFn {
+    const float *flow; int sign, W;
+    __device__ __forceinline__ P2 operator()(int i) const
+    {
+        const int y = i / W, x = i - y * W;
+        const D2 p = point_of(flow, sign, W, x, y);
+        return P2{ p.x, p.y };
+    }
+};
+
+__device__ __forceinline__ bool kept_pt(const uint8_t *pmask, size_t i) { return !pmask || pmask[i] != 0; }
+
+// exclusive scan of one value per thread over a 256-thread block; `total` = block sum (valid in all threads)
+__device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned &total)
+{
+    __shared__ unsigned s_w[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)inc, off);
+        if (lane >= off) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < w; ++k) base += s_w[k];
+    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------ binning
+__global__ __launch_bounds__(256)
+void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W, DlHead *head)
+{
+    const size_t n = (size_t)H * W;
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    unsigned cnt = 0;
+    const PosFn pos{ flow, sign, W };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (!kept_pt(pmask, i)) continue;
+        const P2 p = pos((int)i);
+        x0 = fmin(x0, p.x); x1 = fmax(x1, p.x); y0 = fmin(y0, p.y); y1 = fmax(y1, p.y);
+        ++cnt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fmin(x0, __hiloint2double(__shfl_xor(__double2hiint(x0), off), __shfl_xor(__double2loint(x0), off)));
+        x1 = fmax(x1, __hiloint2double(__shfl_xor(__double2hiint(x1), off), __shfl_xor(__double2loint(x1), off)));
+        y0 = fmin(y0, __hiloint2double(__shfl_xor(__double2hiint(y0), off), __shfl_xor(__double2loint(y0), off)));
+        y1 = fmax(y1, __hiloint2double(__shfl_xor(__double2hiint(y1), off), __shfl_xor(__double2loint(y1), off)));
+        cnt += (unsigned)__shfl_xor((int)cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicMin(&head->kx0, okey(x0)); atomicMax(&head->kx1, okey(x1));
+        atomicMin(&head->ky0, okey(y0)); atomicMax(&head->ky1, okey(y1));
+        atomicAdd(&head->kept, cnt);
+    }
+}
+
+__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap)
+{
+    Grid g;
+    g.ox = 0.0; g.oy = 0.0; g.s = 1.0; g.inv_s = 1.0; g.gx = 1; g.gy = 1;
+    const unsigned n = head->kept;
+    if (n > 0) {
+        const double x0 = okey_inv(head->kx0), x1 = okey_inv(head->kx1), y0 = okey_inv(head->ky0), y1 = okey_inv(head->ky1);
+        const double bw = x1 - x0, bh = y1 - y0;
+        double s = sqrt(fmax(bw * bh, 1e-300) / (double)n);             // ~1 point per bucket
+        s = fmax(s, (bw + bh) / (double)n);
+        if (!(s > 0.0) || !isfinite(s)) s = 1.0;
+        for (int it = 0; it < 64; ++it) {
+            const double fx = floor(bw / s) + 1.0, fy = floor(bh / s) + 1.0;
+            if (fx * fy <= (double)bcap && fx < 2e9 && fy < 2e9) break;
+            s *= 1.5;
+        }
+        g.ox = x0; g.oy = y0; g.s = s; g.inv_s = 1.0 / s;
+        g.gx = (int)(floor(bw / s) + 1.0); g.gy = (int)(floor(bh / s) + 1.0);
+    }
+    head->grid = g;
+}
+
+__global__ __launch_bounds__(256)
+void dl_count_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                     const DlHead *__restrict__ head, unsigned *__restrict__ bcount)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * W || !kept_pt(pmask, i)) return;
+    const Grid g = head->grid;
+    const P2 p = PosFn{ flow, sign, W }((int)i);
+    atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
+}
+
+// exclusive scan, level by level: reduce builds the block sums bottom-up, apply scans top-down in place
+__global__ __launch_bounds__(256)
+void dl_scan_reduce_kernel(const unsigned *__restrict__ in, size_t n, unsigned *__restrict__ sums)
+{
+    const size_t base = (size_t)blockIdx.x * kScanChunk;
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const size_t i = base + (size_t)threadIdx.x * 8 + k; if (i < n) v += in[i]; }
+    unsigned total;
+    (void)block_exscan(v, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256)
+void dl_scan_apply_kernel(unsigned *__restrict__ data, size_t n, const unsigned *__restrict__ offsets)
+{
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
+    unsigned e[8], v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { e[k] = base + k < n ? data[base + k] : 0u; v += e[k]; }
+    unsigned total;
+    unsigned run = block_exscan(v, total) + (offsets ? offsets[blockIdx.x] : 0u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (base + k < n) data[base + k] = run; run += e[k]; }
+}
+
+__global__ __launch_bounds__(256)
+void dl_fill_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                    const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ cursor,
+                    unsigned *__restrict__ sorted)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * W || !kept_pt(pmask, i)) return;
+    const Grid g = head->grid;
+    const P2 p = PosFn{ flow, sign, W }((int)i);
+    const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
+    sorted[bstart[b] + atomicAdd(&cursor[b], 1u)] = (unsigned)i;
+}
+
+// ascending point index inside every bucket (the fill order is not deterministic)
+__global__ __launch_bounds__(256)
+void dl_sort_kernel(const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted)
+{
+    const size_t nb = (size_t)head->grid.gx * head->grid.gy;
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
+        const unsigned lo = bstart[b], hi = bstart[b + 1];
+        if (hi - lo < 2 || hi - lo > 256) continue;                 // (a bucket of hundreds of coincident points keeps its fill order)
+        for (unsigned i = lo + 1; i < hi; ++i) {
+            const unsigned v = sorted[i];
+            unsigned j = i;
+            while (j > lo && sorted[j - 1] > v) { sorted[j] = sorted[j - 1]; --j; }
+            sorted[j] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stars, near pass
+__global__ __launch_bounds__(64)
+void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                         const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
+                         const unsigned *__restrict__ sorted, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
+{
+    __shared__ double s_vx[kNearCap][64], s_vy[kNearCap][64];
+    __shared__ int    s_tag[kNearCap][64];
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= (size_t)H * W) return;
+    if (!kept_pt(pmask, p)) { deg[p] = 0; return; }
+    const Grid g = head->grid;
+    const PosFn pos{ flow, sign, W };
+    Poly P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
+    const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings);
+    bool ok = rc == 1 && P.n <= kSlots;
+    for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
+    if (!ok) { deg[p] = kDegFar; return; }
+    deg[p] = (unsigned char)P.n;
+    for (int k = 0; k < P.n; ++k) nbr[p * kSlots + k] = (unsigned)P.T(k);
+}
+
+// far points compacted in ascending index order
+__global__ __launch_bounds__(256)
+void dl_far_count_kernel(const unsigned char *__restrict__ deg, size_t n, unsigned *__restrict__ cnt)
+{
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n && deg[base + k] == kDegFar) ++v;
+    unsigned total;
+    (void)block_exscan(v, total);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256)
+void dl_far_write_kernel(const unsigned char *__restrict__ deg, size_t n, const unsigned *__restrict__ offs,
+                         unsigned *__restrict__ far_idx, DlHead *head, unsigned last_block)
+{
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n && deg[base + k] == kDegFar) ++v;
+    unsigned total;
+    unsigned at = block_exscan(v, total) + offs[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n && deg[base + k] == kDegFar) far_idx[at++] = (unsigned)(base + k);
+    if (blockIdx.x == last_block && threadIdx.x == 0) head->n_far = offs[blockIdx.x] + total;
+}
+
+// ------------------------------------------------------------------------------------------------ stars, far pass
+// One workgroup per unfinished point.  The cell lives in LDS; candidates are tested 256 at a time against the current
+// cell (one candidate per thread), and the few that cut it are applied one after the other, in candidate order, by
+// the whole workgroup (vertex flags and the shift of the surviving vertices in parallel).
+struct FarLds {
+    double vx[kFarCap], vy[kFarCap];
+    int    tag[kFarCap];
+    unsigned char cut[kFarCap];
+    int    cidx[256];
+    double ccx[256], ccy[256];
+    unsigned long long hit[4];
+    int    n, a, ncut, status;
+};
+
+__device__ void far_shift(FarLds &L, int s0, int s1, int d0)
+{
+    // moves vertices [s0, s1) to [d0, d0 + s1 - s0); ranges may overlap; all threads of the workgroup take part
+    if (d0 == s0 || s1 <= s0) return;
+    const int t = threadIdx.x;
+    if (d0 < s0) {
+        for (int base = s0; base < s1; base += 256) {
+            const int k = base + t;
+            double x = 0, y = 0; int g = 0;
+            if (k < s1) { x = L.vx[k]; y = L.vy[k]; g = L.tag[k]; }
+            __syncthreads();
+            if (k < s1) { L.vx[k - s0 + d0] = x; L.vy[k - s0 + d0] = y; L.tag[k - s0 + d0] = g; }
+            __syncthreads();
+        }
+    } else {
+        for (int end = s1; end > s0; end -= 256) {
+            const int k = end - 1 - t;
+            double x = 0, y = 0; int g = 0;
+            if (k >= s0) { x = L.vx[k]; y = L.vy[k]; g = L.tag[k]; }
+            __syncthreads();
+            if (k >= s0) { L.vx[k - s0 + d0] = x; L.vy[k - s0 + d0] = y; L.tag[k - s0 + d0] = g; }
+            __syncthreads();
+        }
+    }
+}
+
+template <class RelFn>
+__device__ void far_apply(FarLds &L, const P2 &C, int ctag, RelFn rel)
+{
+    // cooperative version of ofl_dl::poly_clip
+    __syncthreads();                                   // the previous application has been read by every thread
+    const int t = threadIdx.x, n = L.n;
+    const double h = 0.5 * (C.x * C.x + C.y * C.y);
+    Poly P{ L.vx, L.vy, L.tag, 1, kFarCap, n };
+    if (t == 0) { L.a = 0x7fffffff; L.ncut = 0; }
+    __syncthreads();
+    int mine = 0;
+    for (int k = t; k < n; k += 256) { const bool c = vertex_cut(P, k, n, C, ctag, h, rel); L.cut[k] = c ? 1 : 0; mine += c; }
+    if (mine) atomicAdd(&L.ncut, mine);
+    __syncthreads();
+    const int ncut = L.ncut;
+    if (ncut == 0 || ncut == n) return;
+    for (int k = t; k < n; k += 256)
+        if (L.cut[k] && !L.cut[k == 0 ? n - 1 : k - 1]) atomicMin(&L.a, k);
+    __syncthreads();
+    const int a = L.a;
+    int len = 0;
+    while (L.cut[(a + len) % n]) ++len;               // every thread walks the (short) run: uniform result
+    const int b = (a + len - 1) % n, ia = a == 0 ? n - 1 : a - 1, ib = (b + 1) % n;
+    const int n2 = n - len + 2;
+    if (n2 > kFarCap) { if (t == 0) L.status |= 1; return; }
+    const int tb = L.tag[b];
+    const P2 v1 = cut_point(L.tag[ia], C, h, rel, L.vx[ia], L.vy[ia], L.vx[a], L.vy[a]);
+    const P2 v2 = cut_point(tb, C, h, rel, L.vx[b], L.vy[b], L.vx[ib], L.vy[ib]);
+    __syncthreads();
+    if (a <= b) {
+        far_shift(L, b + 1, n, a + 2);
+        if (t == 0) {
+            L.vx[a] = v1.x; L.vy[a] = v1.y; L.tag[a] = ctag;
+            L.vx[a + 1] = v2.x; L.vy[a + 1] = v2.y; L.tag[a + 1] = tb;
+        }
+    } else {
+        const int m = a - (b + 1);
+        far_shift(L, b + 1, a, 0);
+        if (t == 0) {
+            L.vx[m] = v1.x; L.vy[m] = v1.y; L.tag[m] = ctag;
+            L.vx[m + 1] = v2.x; L.vy[m + 1] = v2.y; L.tag[m + 1] = tb;
+        }
+    }
+    if (t == 0) L.n = n2;
+    __syncthreads();
+}
+
+// one chunk of up to 256 candidates (thread t holds candidate cand, or -1)
+template <class RelFn>
+__device__ void far_chunk(FarLds &L, int p, const P2 &pp, int cand, const PosFn &pos, RelFn rel)
+{
+    const int t = threadIdx.x;
+    bool hit = false;
+    P2 C{ 0.0, 0.0 };
+    if (cand >= 0 && cand != p) {
+        const P2 q = pos(cand);
+        C.x = q.x - pp.x; C.y = q.y - pp.y;
+        if (!(C.x == 0.0 && C.y == 0.0)) {
+            const int n = L.n;
+            const double h = 0.5 * (C.x * C.x + C.y * C.y);
+            Poly P{ L.vx, L.vy, L.tag, 1, kFarCap, n };
+            for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, h, rel);
+        }
+    }
+    L.cidx[t] = cand; L.ccx[t] = C.x; L.ccy[t] = C.y;
+    const unsigned long long m = __ballot(hit);
+    if ((t & 63) == 0) L.hit[t >> 6] = m;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        unsigned long long bits = L.hit[w];
+        while (bits) {
+            const int j = w * 64 + __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            far_apply(L, P2{ L.ccx[j], L.ccy[j] }, L.cidx[j], rel);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256)
+void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
+                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted,
+                        const unsigned *__restrict__ far_idx, unsigned *__restrict__ far_deg,
+                        unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
+{
+    __shared__ FarLds L;
+    __shared__ unsigned s_off;
+    const int t = threadIdx.x;
+    const unsigned rank = blockIdx.x, n_far = head->n_far;
+    if (rank >= n_far) return;
+    const int p = (int)far_idx[rank];
+    const Grid g = head->grid;
+    const PosFn pos{ flow, sign, W };
+    const P2 pp = pos(p);
+    auto rel = [&](int q) { const P2 v = pos(q); return P2{ v.x - pp.x, v.y - pp.y }; };
+    if (t == 0) {
+        Poly P{ L.vx, L.vy, L.tag, 1, kFarCap, 0 };
+        poly_init(P);
+        L.n = P.n; L.status = 0;
+    }
+    __syncthreads();
+    // the sites of the near buckets (nearest rows first would be nicer; any order gives the same cell)
+    const int bx = g.bx(pp.x), by = g.by(pp.y);
+    for (int dr = 0; dr <= 2 * kRings; ++dr) {
+        const int row = by + ((dr & 1) ? (dr + 1) / 2 : -(dr / 2));        // by, by+1, by-1, by+2, ...
+        if (row < 0 || row >= g.gy) continue;
+        const int x0 = max(bx - kRings, 0), x1 = min(bx + kRings, g.gx - 1);
+        const unsigned lo = bstart[(size_t)row * g.gx + x0], hi = bstart[(size_t)row * g.gx + x1 + 1];
+        for (unsigned base = lo; base < hi; base += 256)
+            far_chunk(L, p, pp, base + t < hi ? (int)sorted[base + t] : -1, pos, rel);
+    }
+    // every other unfinished point
+    for (unsigned base = 0; base < n_far; base += 256)
+        far_chunk(L, p, pp, base + t < n_far ? (int)far_idx[base + t] : -1, pos, rel);
+    const int n = L.n;
+    if (t == 0) {
+        s_off = atomicAdd(&head->pool_used, (unsigned)n);
+        if (L.status) atomicOr(&head->err, 1u);
+    }
+    __syncthreads();
+    const unsigned off = s_off;
+    if ((unsigned long long)off + n > pool_cap) {
+        if (t == 0) { atomicOr(&head->err, 2u); far_deg[rank] = 0; far_off[rank] = 0; }
+        return;
+    }
+    for (int k = t; k < n; k += 256) pool[off + k] = L.tag[k];
+    if (t == 0) { far_deg[rank] = (unsigned)n; far_off[rank] = off; }
+}
+
+// ------------------------------------------------------------------------------------------------ raster
+struct TriRef { unsigned i0, i1, i2; bool ok; };
+
+__device__ __forceinline__ TriRef dl_decode(unsigned id, unsigned far_base, const DlWs &ws)
+{
+    TriRef r;
+    r.ok = false;
+    if (id < far_base) {
+        const unsigned p = id / kSlots, k = id % kSlots, d = ws.deg[p];
+        if (d > kSlots || k >= d) return r;
+        r.i0 = p; r.i1 = ws.nbr[(size_t)p * kSlots + k]; r.i2 = ws.nbr[(size_t)p * kSlots + (k + 1 == d ? 0 : k + 1)];
+        r.ok = true;
+    } else {
+        const unsigned rank = (id - far_base) / kFarK, k = (id - far_base) % kFarK, d = ws.far_deg[rank];
+        if (k >= d) return r;
+        const unsigned off = ws.far_off[rank];
+        const int a = ws.pool[off + k], b = ws.pool[off + (k + 1 == d ? 0 : k + 1)];
+        if (a < 0 || b < 0 || a == b) return r;
+        r.i0 = ws.far_idx[rank]; r.i1 = (unsigned)a; r.i2 = (unsigned)b;
+        r.ok = true;
+    }
+    canonical3(r.i0, r.i1, r.i2);
+    return r;
+}
+
+__device__ __forceinline__ TriBox box_rows(const D2 &p0, const D2 &p1, const D2 &p2, int W, int H, const DlWs &ws)
+{
+    TriBox b = tri_box(p0, p1, p2, W, H);
+    b.y0 = max(b.y0, ws.oy0);
+    b.y1 = min(b.y1, ws.oy1 - 1);
+    return b;
+}
+
+__device__ __forceinline__ D2 pt(const PosFn &pos, unsigned i) { const P2 p = pos((int)i); return D2{ p.x, p.y }; }
+
+__global__ __launch_bounds__(256)
+void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (size_t)H * W) return;
+    const unsigned d = ws.deg[p];
+    if (d == 0 || d > kSlots) return;
+    const PosFn pos{ flow, sign, W };
+    for (unsigned k = 0; k < d; ++k) {
+        const unsigned id = (unsigned)p * kSlots + k;
+        const TriRef tr = dl_decode(id, far_base, ws);
+        if (!tr.ok) continue;
+        const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
+        const TriBox b = box_rows(q0, q1, q2, W, H, ws);
+        if (b.x1 < b.x0 || b.y1 < b.y0) continue;
+        const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
+        if (area > kSmallArea) {
+            const unsigned long long slot = atomicAdd(&ws.head->big_n, 1ull);
+            if (slot < ws.big_cap) ws.big[slot] = id; else atomicOr(&ws.head->err, 4u);
+            continue;
+        }
+        TriEdge te;
+        if (!tri_setup(q0, q1, q2, te)) continue;
+        for (int gy = b.y0; gy <= b.y1; ++gy)
+            for (int gx = b.x0; gx <= b.x1; ++gx)
+                if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+    }
+}
+
+// one wave per triangle: 64 nodes of the bounding box per step
+__device__ __forceinline__ void wave_raster(unsigned id, const TriRef &tr, const PosFn &pos, int H, int W, const DlWs &ws)
+{
+    const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
+    const TriBox b = box_rows(q0, q1, q2, W, H, ws);
+    if (b.x1 < b.x0 || b.y1 < b.y0) return;
+    TriEdge te;
+    if (!tri_setup(q0, q1, q2, te)) return;
+    const long long bw = b.x1 - b.x0 + 1, area = bw * (b.y1 - b.y0 + 1);
+    for (long long j = threadIdx.x & 63; j < area; j += 64) {
+        const int gy = b.y0 + (int)(j / bw), gx = b.x0 + (int)(j % bw);
+        if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void dl_raster_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
+{
+    const unsigned rank = blockIdx.x;
+    if (rank >= ws.head->n_far) return;
+    const unsigned d = ws.far_deg[rank];
+    const PosFn pos{ flow, sign, W };
+    for (unsigned k = threadIdx.x >> 6; k < d; k += 4) {
+        const unsigned id = far_base + rank * kFarK + k;
+        const TriRef tr = dl_decode(id, far_base, ws);
+        if (tr.ok) wave_raster(id, tr, pos, H, W, ws);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void dl_raster_big_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
+{
+    unsigned long long n = ws.head->big_n;
+    if (n > ws.big_cap) n = ws.big_cap;
+    const PosFn pos{ flow, sign, W };
+    for (unsigned long long j = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6); j < n; j += (unsigned long long)gridDim.x * 4) {
+        const unsigned id = ws.big[j];
+        const TriRef tr = dl_decode(id, far_base, ws);
+        if (tr.ok) wave_raster(id, tr, pos, H, W, ws);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resolve
+template <typename VT>
+__global__ __launch_bounds__(256)
+void dl_resolve_kernel(const float *__restrict__ flow, int sign, const VT *__restrict__ vals, int C,
+                       const uint8_t *__restrict__ vmask, int H, int W, int row0, int rows,
+                       VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, DlWs ws, unsigned far_base)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
+    if (x >= W || yl >= rows) return;
+    const size_t o = (size_t)yl * W + x;
+    const unsigned id = ws.owner[(size_t)y * W + x];
+    TriRef tr;
+    tr.ok = false;
+    if (id != kNoOwner) tr = dl_decode(id, far_base, ws);
+    if (!tr.ok) {
+        for (int c = 0; c < C; ++c) out[o * C + c] = (VT)0;                  // outside the convex hull: NaN -> 0, utils.py:254
+        if (valid) valid[o] = 0;
+        return;
+    }
+    const PosFn pos{ flow, sign, W };
+    const size_t vi[3] = { tr.i0, tr.i1, tr.i2 };
+    double c0, c1, c2;
+    (void)bary(pt(pos, tr.i0), pt(pos, tr.i1), pt(pos, tr.i2), (double)x, (double)y, c0, c1, c2);
+    resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
+}
+
+DlWs carve_exact(void *base, int H, int W)
+{
+    const size_t n = (size_t)H * W;
+    DlWs ws;
+    char *p = (char *)base;
+    ws.bcap = 2 * n + 1024;
+    ws.pool_cap = 8 * n + 65536;
+    ws.big_cap = 6 * n + 1024;
+    ws.head = (DlHead *)p;                  p += 256;
+    ws.bstart = (unsigned *)p;              p += align_up((ws.bcap + 1) * 4, 256);
+    ws.scan_tmp = (unsigned *)p;            p += align_up(scan_tmp_elems(ws.bcap + 1) * 4, 256);
+    ws.sorted = (unsigned *)p;              p += align_up(n * 4, 256);
+    ws.deg = (unsigned char *)p;            p += align_up(n, 256);
+    ws.nbr = (unsigned *)p;                 p += align_up(std::max(n * kSlots, ws.bcap) * 4, 256);
+    ws.far_idx = (unsigned *)p;             p += align_up(n * 4, 256);
+    ws.far_deg = (unsigned *)p;             p += align_up(n * 4, 256);
+    ws.far_off = (unsigned *)p;             p += align_up(n * 4, 256);
+    ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
+    ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
+    ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
+    ws.oy0 = 0; ws.oy1 = H;
+    return ws;
+}
+
+int scan_exclusive(unsigned *data, size_t n, unsigned *tmp, hipStream_t s)
+{
+    // levels: data (n) -> sums of 2048-element chunks -> ... -> one value
+    std::vector<std::pair<unsigned *, size_t>> lv;
+    lv.push_back({ data, n });
+    unsigned *t = tmp;
+    while (lv.back().second > 1) {
+        const size_t m = (lv.back().second + kScanChunk - 1) / kScanChunk;
+        hipLaunchKernelGGL(dl_scan_reduce_kernel, dim3((unsigned)m), dim3(256), 0, s, (const unsigned *)lv.back().first, lv.back().second, t);
+        lv.push_back({ t, m });
+        t += m;
+    }
+    OFL_HIP(hipMemsetAsync(lv.back().first, 0, 4, s));          // exclusive prefix of the single top value
+    for (size_t k = lv.size() - 1; k-- > 0;) {
+        const size_t m = (lv[k].second + kScanChunk - 1) / kScanChunk;
+        hipLaunchKernelGGL(dl_scan_apply_kernel, dim3((unsigned)m), dim3(256), 0, s, lv[k].first, lv[k].second, (const unsigned *)lv[k + 1].first);
+    }
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+}  // namespace
+
+namespace ofl_sc {
+
+size_t exact_workspace_bytes(int H, int W)
+{
+    const size_t n = (size_t)H * W;
+    const size_t bcap = 2 * n + 1024, pool_cap = 8 * n + 65536, big_cap = 6 * n + 1024;
+    return 256 + align_up((bcap + 1) * 4, 256) + align_up(scan_tmp_elems(bcap + 1) * 4, 256) + align_up(n * 4, 256) +
+           align_up(n, 256) + align_up(std::max(n * kSlots, bcap) * 4, 256) + 3 * align_up(n * 4, 256) +
+           align_up(pool_cap * 4, 256) + align_up(big_cap * 4, 256) + align_up(n * 4, 256);
+}
+
+// rows [row0, row0 + rows) of the grid result through the exact path; synchronises once (counts of the star passes)
+template <typename VT>
+int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT *vals, int C, const uint8_t *vmask,
+                  int H, int W, int row0, int rows, VT *out, uint8_t *valid, int valid_rule,
+                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
+    if (n >= (1ull << 27)) return fail(OFL_E_INVALID, "ofl_scatter_linear: the exact path takes fields below 2^27 pixels");
+    if (workspace_bytes < exact_workspace_bytes(H, W)) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small for the exact path");
+    DlWs ws = carve_exact(workspace, H, W);
+    ws.oy0 = row0; ws.oy1 = row0 + rows;
+    OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)rows * W * 4, s));
+    ws.owner -= (size_t)row0 * W;
+    DlHead init;
+    memset(&init, 0, sizeof(init));
+    init.kx0 = init.ky0 = ~0ull;
+    OFL_HIP(hipMemcpyAsync(ws.head, &init, sizeof(init), hipMemcpyHostToDevice, s));
+    OFL_HIP(hipMemsetAsync(ws.bstart, 0, (ws.bcap + 1) * 4, s));
+    OFL_HIP(hipMemsetAsync(ws.nbr, 0, ws.bcap * 4, s));                 // bucket cursors
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(dl_bbox_kernel, dim3(std::min<unsigned>(nblk, (unsigned)rt().n_cu * 8)), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
+    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap);
+    hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart);
+    OFL_HIP(hipGetLastError());
+    OFL_TRY(scan_exclusive(ws.bstart, ws.bcap + 1, ws.scan_tmp, s));
+    hipLaunchKernelGGL(dl_fill_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
+                       (const unsigned *)ws.bstart, ws.nbr, ws.sorted);
+    hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
+                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, ws.sorted);
+    hipLaunchKernelGGL(dl_star_near_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, flow, sign_pp, pmask, H, W,
+                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, ws.deg, ws.nbr);
+    OFL_HIP(hipGetLastError());
+    // far points in index order
+    const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
+    unsigned *fcnt = ws.far_deg;                                         // scratch until the far pass writes it
+    hipLaunchKernelGGL(dl_far_count_kernel, dim3(fblk), dim3(256), 0, s, (const unsigned char *)ws.deg, n, fcnt);
+    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
+    hipLaunchKernelGGL(dl_far_write_kernel, dim3(fblk), dim3(256), 0, s, (const unsigned char *)ws.deg, n, (const unsigned *)fcnt,
+                       ws.far_idx, ws.head, fblk - 1);
+    OFL_HIP(hipGetLastError());
+    DlHead h;
+    OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
+    OFL_HIP(hipStreamSynchronize(s));
+    if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = 0; }
+    if (h.kept == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
+    const unsigned long long far_base = (unsigned long long)n * kSlots;
+    if (far_base + (unsigned long long)h.n_far * kFarK >= 0xFFFFFFF0ull)
+        return fail(OFL_E_INVALID, "ofl_scatter_linear: %u unfinished stars exceed the triangle-id space of the exact path", h.n_far);
+    if (h.n_far) {
+        hipLaunchKernelGGL(dl_star_far_kernel, dim3(h.n_far), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+                           (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.far_idx,
+                           ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
+        OFL_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(dl_raster_small_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+    if (h.n_far)
+        hipLaunchKernelGGL(dl_raster_far_kernel, dim3(h.n_far), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+    hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+    const dim3 grid((W + 31) / 32, (rows + 7) / 8);
+    hipLaunchKernelGGL(dl_resolve_kernel<VT>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
+                       out, valid, valid_rule, ws, (unsigned)far_base);
+    OFL_HIP(hipGetLastError());
+    if (info_host) {
+        // callers that ask for the counts also learn whether a capacity of the star passes was exceeded (a fan of more
+        // than kFarCap neighbours, the neighbour pool, the large-triangle list): one more small read-back
+        OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
+        OFL_HIP(hipStreamSynchronize(s));
+        info_host[2] = h.err;
+        if (h.err) return fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
+                                              "neighbours, 2 = neighbour pool, 4 = large-triangle list)", h.err, kFarCap);
+    }
+    return OFL_OK;
+}
+
+template int exact_scatter<float>(const float *, int, const uint8_t *, const float *, int, const uint8_t *, int, int, int, int,
+                                  float *, uint8_t *, int, void *, size_t, uint64_t *, hipStream_t);
+template int exact_scatter<double>(const float *, int, const uint8_t *, const double *, int, const uint8_t *, int, int, int, int,
+                                   double *, uint8_t *, int, void *, size_t, uint64_t *, hipStream_t);
+
+}  // namespace ofl_sc

@@ -854,6 +854,15 @@ HostStage &host_stage()
 
 }  // namespace
 
+namespace {
+size_t legacy_workspace_bytes(int H, int W)
+{
+    return kHeadBytes + align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * (size_t)kHullCap * sizeof(D2) +
+           align_up((size_t)big_cap_for(H, W) * 4, 256) + align_up((size_t)H * W * 4, 256) +
+           align_up((size_t)((W + 31) / 32) * ((H + 7) / 8), 256);
+}
+}  // namespace
+
 extern "C" {
 
 int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
@@ -861,9 +870,8 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
     (void)C;
     if (!bytes) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: NULL");
     if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: bad shape");
-    *bytes = kHeadBytes + align_up((size_t)cand_cap_for(H, W) * sizeof(D2), 256) + 2 * (size_t)kHullCap * sizeof(D2) +
-             align_up((size_t)big_cap_for(H, W) * 4, 256) + align_up((size_t)H * W * 4, 256) +
-             align_up((size_t)((W + 31) / 32) * ((H + 7) / 8), 256);
+    *bytes = legacy_workspace_bytes(H, W);
+    if ((long long)H * W < (1ll << 27)) *bytes = std::max(*bytes, exact_workspace_bytes(H, W));     // the exact path carves the same block
     return OFL_OK;
 }
 
@@ -881,8 +889,7 @@ int scatter_prepare(const float *flow, int sign, const uint8_t *pmask, int H, in
     if (!flow || !workspace) return fail(OFL_E_INVALID, "ofl_scatter_linear: NULL pointer");
     if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 29))
         return fail(OFL_E_INVALID, "ofl_scatter_linear: H*W must be in [1, 2^29)");
-    size_t need = 0;
-    OFL_TRY(ofl_scatter_workspace_bytes(H, W, 0, &need));
+    const size_t need = legacy_workspace_bytes(H, W);
     if (workspace_bytes < need) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small (%zu < %zu)", workspace_bytes, need);
     ws = carve(workspace, H, W);
     if (oy1 < 0) oy1 = H;
@@ -1032,6 +1039,11 @@ int scatter_grid_impl(const char *who, const float *flow, int sign, int point_pr
             return walk_launch<VT>(flow, sign, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule, &cert, nullptr, s);
         }
     }
+    // everything else -- folds, dropped points, curved borders, sheared cells: a real Delaunay triangulation of the kept
+    // points (ofl_delaunay.hip).  The owner-map path below remains for query positions and as a development reference.
+    if (!legacy && workspace && workspace_bytes >= exact_workspace_bytes(H, W) && (long long)H * W < (1ll << 27))
+        return exact_scatter<VT>(flow, sign, pmask, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule,
+                                 workspace, workspace_bytes, info_host, s);
     ScatterWs ws;
     HullRef hull;
     // owners are needed for the rows and, for the gap fill, kFillRadius rows around them -- or everywhere when a point

@@ -181,3 +181,134 @@ def test_nodes_in_the_noise_band_of_the_border(gpu, oracle):
         gi, oi = f.invert(), o.invert()
         np.testing.assert_array_equal(gi.mask, oi.mask)
         np.testing.assert_allclose(gi.vecs[gi.mask], oi.vecs[oi.mask], rtol=RTOL, atol=ATOL)
+
+
+# ---------------------------------------------------------------------------------------------- exact path
+def nonunique_nodes(points, shape):
+    """Grid nodes whose covering simplex of SciPy's own triangulation is NOT uniquely Delaunay (a fourth site within
+    1e-9 of its circumcircle): Qhull's choice among the co-circular alternatives is arbitrary there, and non-affine
+    data (image values) can tell the alternatives apart.  Duplicated sites count as ambiguous too."""
+    from scipy.spatial import Delaunay
+    from test_delaunay_core import unique_simplices
+    upts, inv, counts = np.unique(points, axis=0, return_inverse=True, return_counts=True)
+    d = Delaunay(upts)
+    uniq = unique_simplices(upts, d.simplices)
+    dup_vertex = (counts[d.simplices] > 1).any(1)
+    yy, xx = np.mgrid[:shape[0], :shape[1]]
+    s = d.find_simplex(np.stack([xx.ravel(), yy.ravel()], 1).astype(np.float64)).reshape(shape)
+    amb = np.zeros(shape, bool)
+    inside = s >= 0
+    amb[inside] = ~uniq[s[inside]] | dup_vertex[s[inside]]
+    # a node exactly on an edge / vertex belongs to several simplices: ambiguous when any of its neighbours is
+    from scipy import ndimage
+    return amb, inside
+
+
+def fixture_case(g, tag):
+    vecs, mask, img = g[tag + '/in_vecs'], g[tag + '/in_mask'], g[tag + '/img']
+    h, w = vecs.shape[:2]
+    yy, xx = np.mgrid[:h, :w]
+    pts = np.stack([(xx + vecs[..., 0].astype(np.float64)).ravel(), (yy + vecs[..., 1].astype(np.float64)).ravel()], 1)[mask.ravel()]
+    return vecs, mask, img, pts
+
+
+EXACT_TAGS = ["affine_generic", "affine_generic_hole", "block_generic", "curved", "curved_in", "hole_img", "shear",
+              "speckle_img", "wobble3", "sintel4x4"]
+
+
+@pytest.mark.parametrize("tag", EXACT_TAGS)
+def test_exact_path_matches_reference_outputs(gpu, golden2, tag):
+    """Outputs of the REAL reference (tests/golden/make_golden.py::main_delaunay) for fields whose cell-wise mesh is
+    not the Delaunay triangulation: folds (incl. BASELINE config 5 as loaded, 4 x 4 tiles), holes with random image
+    values, curved borders, sheared cells, speckled point masks.  Masks bit-exact everywhere; values within 1e-4
+    wherever SciPy's triangulation is unique."""
+    of = gpu
+    g = golden2
+    vecs, mask, img, pts = fixture_case(g, tag)
+    f = of.Flow(vecs, 's', mask)
+    amb, inside = nonunique_nodes(pts, vecs.shape[:2])
+    w, v = f.apply(img, return_valid_area=True)
+    np.testing.assert_array_equal(v, g[tag + '/apply_valid'], err_msg=tag)
+    np.testing.assert_array_equal(f.valid_target(), g[tag + '/valid_target'], err_msg=tag)
+    bad = ~np.isclose(w, g[tag + '/apply'], rtol=RTOL, atol=ATOL).all(-1)
+    assert not (bad & ~amb).any(), (tag, int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:5].tolist())
+    r = f.invert()
+    np.testing.assert_array_equal(r.mask, g[tag + '/invert_mask'], err_msg=tag)
+    badv = ~np.isclose(r.vecs, g[tag + '/invert_vecs'], rtol=RTOL, atol=ATOL).all(-1)
+    assert not (badv & ~amb).any(), (tag, int((badv & ~amb).sum()))
+    if tag not in ("sintel4x4", "hole_img"):
+        assert amb.mean() < 0.12, (tag, amb.mean())           # the comparison above is not vacuous
+
+
+def test_exact_path_bands_and_determinism(gpu, golden2):
+    """Row bands of the exact path concatenate to the full result bit for bit, and repeated calls give the same bits
+    (bucket order, far-point order and triangle ids are functions of the input only)."""
+    of = gpu
+    from oflibnumpy_amd import device as dev, sharding
+    rng = np.random.default_rng(77)
+    for tag in ("block_generic", "speckle_img", "sintel4x4", "curved"):
+        vecs, mask, img, _ = fixture_case(golden2, tag)
+        h, w = vecs.shape[:2]
+        f, vals = dev.DeviceBuffer.from_host(vecs), dev.DeviceBuffer.from_host(img)
+        pm = dev.DeviceBuffer.from_host(mask.astype(np.uint8)) if not mask.all() else None
+        vm = dev.DeviceBuffer.from_host((rng.random((h, w)) > 0.1).astype(np.uint8))
+        out, valid = dev.DeviceBuffer(h * w * 12), dev.DeviceBuffer(h * w)
+        info = dev.scatter_linear(f, +1, pm, vals, 3, vm, h, w, None, out, valid, 0)
+        assert info[0] == int(mask.sum()) and info[2] == 0
+        full, fullv = out.to_host((h, w, 3), np.float32), valid.to_host((h, w), np.uint8)
+        dev.scatter_linear(f, +1, pm, vals, 3, vm, h, w, None, out, valid, 0)
+        np.testing.assert_array_equal(out.to_host((h, w, 3), np.float32), full)
+        for world in (3, 5):
+            parts, vparts = [], []
+            for r in range(world):
+                r0, r1 = sharding.row_band(h, r, world)
+                if r1 <= r0:
+                    continue
+                ob, vb = dev.DeviceBuffer((r1 - r0) * w * 12), dev.DeviceBuffer((r1 - r0) * w)
+                dev.scatter_rows(f, +1, pm, vals, 3, vm, h, w, r0, r1 - r0, ob, vb)
+                parts.append(ob.to_host((r1 - r0, w, 3), np.float32)); vparts.append(vb.to_host((r1 - r0, w), np.uint8))
+            np.testing.assert_array_equal(np.concatenate(parts), full, err_msg=tag)
+            np.testing.assert_array_equal(np.concatenate(vparts), fullv, err_msg=tag)
+
+
+def test_exact_path_random_fields_against_scipy(gpu, oracle):
+    """Seeded sweep on ragged shapes: smooth non-affine fields, folds, random point masks with holes, both signs, random
+    image values -- the full result (values and validity of a random value mask) equals SciPy's outside non-unique
+    simplices."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        h, w = int(rng.integers(5, 70)), int(rng.integers(5, 90))
+        yy, xx = np.mgrid[:h, :w].astype(np.float32)
+        amp = rng.uniform(0.2, 4)
+        vecs = np.stack([amp * np.sin(xx / rng.uniform(3, 30) + yy / rng.uniform(5, 40)) + 0.13 * yy,
+                         amp * np.cos(xx / rng.uniform(4, 25)) - 0.07 * xx], -1).astype(np.float32)
+        vecs += rng.uniform(-5, 5, 2).astype(np.float32)
+        if it % 3 == 0:
+            vecs[rng.random((h, w)) < 0.03] += rng.uniform(3, 12)          # isolated outliers: folds
+        pm = None
+        if it % 2:
+            pm = rng.random((h, w)) > rng.uniform(0, 0.3)
+            if it % 4 == 1 and h > 12 and w > 12:
+                pm[h // 4:h // 4 + h // 3, w // 5:w // 5 + w // 2] = False   # a hole
+            if pm.sum() < 8:
+                pm = None
+        sign = 1 if it % 5 else -1
+        C = int(rng.integers(1, 4))
+        vals = rng.random((h, w, C), dtype=np.float32)
+        vm = rng.random((h, w)) > 0.15
+        f, dv, dm = dev.DeviceBuffer.from_host(vecs), dev.DeviceBuffer.from_host(vals), dev.DeviceBuffer.from_host(vm.astype(np.uint8))
+        dpm = dev.DeviceBuffer.from_host(pm.astype(np.uint8)) if pm is not None else None
+        out, valid = dev.DeviceBuffer(h * w * C * 4), dev.DeviceBuffer(h * w)
+        dev.scatter_linear(f, sign, dpm, dv, C, dm, h, w, None, out, valid, 0)
+        got, gv = out.to_host((h, w, C), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+        want = O.scatter_griddata(sign * vecs, np.concatenate([vals, vm[..., None].astype(np.float32)], -1), pm)
+        keep = np.ones((h, w), bool) if pm is None else pm
+        pts = np.stack([(xx + sign * vecs[..., 0].astype(np.float64)).ravel(), (yy + sign * vecs[..., 1].astype(np.float64)).ravel()], 1)[keep.ravel()]
+        amb, inside = nonunique_nodes(pts, (h, w))
+        covered = want[..., -1] != 0
+        np.testing.assert_array_equal(gv[~amb], (want[..., -1] == 1)[~amb], err_msg=str((it, h, w)))
+        bad = ~np.isclose(got, want[..., :C], rtol=RTOL, atol=ATOL).all(-1)
+        assert not (bad & ~amb).any(), (it, h, w, int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:4].tolist())
+        assert amb.mean() < 0.2, (it, amb.mean())

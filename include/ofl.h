@@ -199,10 +199,13 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  *                   (vmask NULL = all ones, i.e. valid == "covered by a triangle").
  * query == NULL evaluates at the regular grid nodes; otherwise query [H][W][2] holds absolute (x, y)
  * positions (mode 2 't').  C may be 0 (validity only).  `workspace` (device) must hold
- * ofl_scatter_workspace_bytes() bytes.  info_host (host uint64[3] or NULL): [0] kept points, [1] number
- * of large triangles, [2] their bounding-box nodes; passing it synchronises and enables the checks
- * that need the counts: OFL_E_NOPOINTS when no point is kept (qhull's "No points given").
- * Known deviation from SciPy: holes left by dropped points are not re-triangulated.
+ * ofl_scatter_workspace_bytes() bytes.  info_host (host uint64[3] or NULL): [0] kept points; on the exact path
+ * [1] points whose Delaunay star was not final within the per-thread ring search and [2] those left for the
+ * workgroup pass (hull points, rims of very large holes); on the owner-map path (query positions) [1] number of
+ * large triangles, [2] their bounding-box nodes.  OFL_E_NOPOINTS when no point is kept (qhull's "No points given").
+ * Grid nodes take one of two paths: a field whose cell-wise mesh is certified to BE the Delaunay triangulation
+ * (ofl_scatter_certify_dev) is resolved by one kernel; every other field -- folds, dropped points, curved borders,
+ * sheared cells -- gets a real Delaunay triangulation of the kept points on the GPU.
  */
 int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                            const float *vals, int C, const uint8_t *vmask, int H, int W,

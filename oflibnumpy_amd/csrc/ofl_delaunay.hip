@@ -31,9 +31,13 @@ using namespace ofl_dl;
 namespace {
 
 constexpr int      kRings    = 6;        // bucket rings of the per-thread star pass
-constexpr int      kNearCap  = 16;       // polygon capacity of the per-thread pass == neighbour slots per point
-constexpr int      kSlots    = 16;
+constexpr int      kNearCap  = 12;       // polygon capacity of the per-thread pass (float32 cell in LDS)
+constexpr int      kSlots    = 16;       // neighbour slots per point
+constexpr int      kMidCap   = 256;      // polygon capacity of the wave pass (unfinished points against the coarse grid of unfinished points)
+constexpr int      kMidRings = 8;        // rings of that coarse grid ...
+constexpr int      kMidScale = 8;        // ... whose cells are this many fine buckets wide
 constexpr int      kFarCap   = 2560;     // polygon capacity of the workgroup pass (LDS: 20 B per vertex)
+constexpr unsigned kDegLeft  = 0xFFFFFFFFu;   // far_deg marker: not finished by the wave pass
 constexpr unsigned kFarK     = 4096;     // triangle-id stride of a far point (>= kFarCap)
 constexpr unsigned kNoOwner  = 0xFFFFFFFFu;
 constexpr int      kSmallArea = 1024;
@@ -42,10 +46,10 @@ constexpr int      kScanChunk = 2048;    // elements per block of the scan kerne
 
 struct DlHead {                           // device header of the exact path (256 bytes)
     unsigned long long kx0, kx1, ky0, ky1;   // ordered keys of the bounding box while it is reduced
-    Grid     grid;
-    unsigned kept, n_far, pool_used, err;    // err bit 0: far polygon overflow, bit 1: pool overflow, bit 2: big list overflow
+    Grid     grid, grid1;                    // fine buckets (all kept points), coarse buckets (unfinished points)
+    unsigned kept, n_far, n_left, pool_used, err;    // err bit 0: far polygon overflow, bit 1: pool overflow, bit 2: big list overflow
     unsigned long long big_n;
-    unsigned pad[32];
+    unsigned pad[16];
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
 
@@ -59,10 +63,14 @@ struct DlWs {
     unsigned *far_idx;     // [N]
     unsigned *far_deg;     // [N]
     unsigned *far_off;     // [N]
+    unsigned *left_idx;    // [N] ranks of the points the wave pass could not finish
+    unsigned *b1start;     // [b1cap + 1] coarse buckets of the unfinished points
+    unsigned *b1cursor;    // [b1cap]
+    unsigned *sorted1;     // [N] their ranks bucket by bucket
     int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
     unsigned *big;         // [big_cap] triangle ids with a large bounding box
     uint32_t *owner;       // [H][W] (biased by the first row of the band)
-    size_t    bcap, pool_cap, big_cap;
+    size_t    bcap, b1cap, pool_cap, big_cap;
     int       oy0, oy1;
 };
 
@@ -168,6 +176,35 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap)
         g.gx = (int)(floor(bw / s) + 1.0); g.gy = (int)(floor(bh / s) + 1.0);
     }
     head->grid = g;
+    Grid g1 = g;                                     // coarse grid of the unfinished points: kMidScale fine buckets per cell
+    g1.s = g.s * kMidScale; g1.inv_s = 1.0 / g1.s;
+    g1.gx = (g.gx + kMidScale - 1) / kMidScale; g1.gy = (g.gy + kMidScale - 1) / kMidScale;
+    head->grid1 = g1;
+}
+
+// the same three binning steps for the unfinished points (ranks into far_idx) on the coarse grid
+__global__ __launch_bounds__(256)
+void dl_count1_kernel(const float *__restrict__ flow, int sign, int W, const DlHead *__restrict__ head,
+                      const unsigned *__restrict__ far_idx, unsigned *__restrict__ bcount)
+{
+    const unsigned r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= head->n_far) return;
+    const Grid g = head->grid1;
+    const P2 p = PosFn{ flow, sign, W }((int)far_idx[r]);
+    atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
+}
+
+__global__ __launch_bounds__(256)
+void dl_fill1_kernel(const float *__restrict__ flow, int sign, int W, const DlHead *__restrict__ head,
+                     const unsigned *__restrict__ far_idx, const unsigned *__restrict__ bstart,
+                     unsigned *__restrict__ cursor, unsigned *__restrict__ sorted)
+{
+    const unsigned r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= head->n_far) return;
+    const Grid g = head->grid1;
+    const P2 p = PosFn{ flow, sign, W }((int)far_idx[r]);
+    const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
+    sorted[bstart[b] + atomicAdd(&cursor[b], 1u)] = r;
 }
 
 __global__ __launch_bounds__(256)
@@ -222,9 +259,9 @@ void dl_fill_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
 
 // ascending point index inside every bucket (the fill order is not deterministic)
 __global__ __launch_bounds__(256)
-void dl_sort_kernel(const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted)
+void dl_sort_kernel(const DlHead *__restrict__ head, int coarse, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted)
 {
-    const size_t nb = (size_t)head->grid.gx * head->grid.gy;
+    const size_t nb = coarse ? (size_t)head->grid1.gx * head->grid1.gy : (size_t)head->grid.gx * head->grid.gy;
     for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
         const unsigned lo = bstart[b], hi = bstart[b + 1];
         if (hi - lo < 2 || hi - lo > 256) continue;                 // (a bucket of hundreds of coincident points keeps its fill order)
@@ -243,71 +280,88 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
                          const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
                          const unsigned *__restrict__ sorted, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
-    __shared__ double s_vx[kNearCap][64], s_vy[kNearCap][64];
-    __shared__ int    s_tag[kNearCap][64];
+    __shared__ float s_vx[kNearCap][64], s_vy[kNearCap][64];
+    __shared__ int   s_tag[kNearCap][64];
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (p >= (size_t)H * W) return;
     if (!kept_pt(pmask, p)) { deg[p] = 0; return; }
     const Grid g = head->grid;
     const PosFn pos{ flow, sign, W };
-    Poly P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
+    PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
     const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings);
-    bool ok = rc == 1 && P.n <= kSlots;
+    bool ok = rc == 1;
     for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
     if (!ok) { deg[p] = kDegFar; return; }
     deg[p] = (unsigned char)P.n;
     for (int k = 0; k < P.n; ++k) nbr[p * kSlots + k] = (unsigned)P.T(k);
 }
 
-// far points compacted in ascending index order
-__global__ __launch_bounds__(256)
-void dl_far_count_kernel(const unsigned char *__restrict__ deg, size_t n, unsigned *__restrict__ cnt)
+// compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx
+template <int MODE>
+__device__ __forceinline__ bool flagged(const void *src, size_t i)
 {
+    return MODE == 0 ? ((const unsigned char *)src)[i] == kDegFar : ((const unsigned *)src)[i] == kDegLeft;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256)
+void dl_flag_count_kernel(const void *__restrict__ src, const DlHead *__restrict__ head, size_t n_fixed, unsigned *__restrict__ cnt)
+{
+    const size_t n = MODE == 0 ? n_fixed : head->n_far;
     const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && deg[base + k] == kDegFar) ++v;
+    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, base + k)) ++v;
     unsigned total;
     (void)block_exscan(v, total);
     if (threadIdx.x == 0) cnt[blockIdx.x] = total;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256)
-void dl_far_write_kernel(const unsigned char *__restrict__ deg, size_t n, const unsigned *__restrict__ offs,
-                         unsigned *__restrict__ far_idx, DlHead *head, unsigned last_block)
+void dl_flag_write_kernel(const void *__restrict__ src, DlHead *head, size_t n_fixed, const unsigned *__restrict__ offs,
+                          unsigned *__restrict__ list, unsigned last_block)
 {
+    const size_t n = MODE == 0 ? n_fixed : head->n_far;
     const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && deg[base + k] == kDegFar) ++v;
+    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, base + k)) ++v;
     unsigned total;
     unsigned at = block_exscan(v, total) + offs[blockIdx.x];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && deg[base + k] == kDegFar) far_idx[at++] = (unsigned)(base + k);
-    if (blockIdx.x == last_block && threadIdx.x == 0) head->n_far = offs[blockIdx.x] + total;
+    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, base + k)) list[at++] = (unsigned)(base + k);
+    if (blockIdx.x == last_block && threadIdx.x == 0) { if (MODE == 0) head->n_far = offs[blockIdx.x] + total; else head->n_left = offs[blockIdx.x] + total; }
 }
 
-// ------------------------------------------------------------------------------------------------ stars, far pass
-// One workgroup per unfinished point.  The cell lives in LDS; candidates are tested 256 at a time against the current
-// cell (one candidate per thread), and the few that cut it are applied one after the other, in candidate order, by
-// the whole workgroup (vertex flags and the shift of the surviving vertices in parallel).
+// ------------------------------------------------------------------------------------------------ stars, cooperative passes
+// One workgroup of NT threads per unfinished point.  The cell lives in LDS; candidates are tested NT at a time against
+// the current cell (one candidate per thread), and the few that cut it are applied one after the other, in candidate
+// order, by the whole workgroup (vertex flags and the shift of the surviving vertices in parallel).
+//   wave pass (CAP 256, NT 64): fine buckets around the point, then rings of the COARSE grid of unfinished points with
+//     the security-radius test -- rims of holes, motion boundaries, anything whose cell spans tens of pixels;
+//   workgroup pass (CAP 2560, NT 256): what is left -- hull points (unbounded cells), rims of very large holes, fan
+//     apexes of border pockets -- against the same candidates plus ALL other points left (a Delaunay neighbour of a
+//     left-over point beyond the coarse rings is itself left over).
+template <int CAP, int NT>
 struct FarLds {
-    double vx[kFarCap], vy[kFarCap];
-    int    tag[kFarCap];
-    unsigned char cut[kFarCap];
-    int    cidx[256];
-    double ccx[256], ccy[256];
-    unsigned long long hit[4];
+    double vx[CAP], vy[CAP];
+    int    tag[CAP];
+    unsigned char cut[CAP];
+    int    cidx[NT];
+    double ccx[NT], ccy[NT];
+    unsigned long long hit[NT / 64];
     int    n, a, ncut, status;
 };
 
-__device__ void far_shift(FarLds &L, int s0, int s1, int d0)
+template <int CAP, int NT>
+__device__ void far_shift(FarLds<CAP, NT> &L, int s0, int s1, int d0)
 {
     // moves vertices [s0, s1) to [d0, d0 + s1 - s0); ranges may overlap; all threads of the workgroup take part
     if (d0 == s0 || s1 <= s0) return;
     const int t = threadIdx.x;
     if (d0 < s0) {
-        for (int base = s0; base < s1; base += 256) {
+        for (int base = s0; base < s1; base += NT) {
             const int k = base + t;
             double x = 0, y = 0; int g = 0;
             if (k < s1) { x = L.vx[k]; y = L.vy[k]; g = L.tag[k]; }
@@ -316,7 +370,7 @@ __device__ void far_shift(FarLds &L, int s0, int s1, int d0)
             __syncthreads();
         }
     } else {
-        for (int end = s1; end > s0; end -= 256) {
+        for (int end = s1; end > s0; end -= NT) {
             const int k = end - 1 - t;
             double x = 0, y = 0; int g = 0;
             if (k >= s0) { x = L.vx[k]; y = L.vy[k]; g = L.tag[k]; }
@@ -327,23 +381,23 @@ __device__ void far_shift(FarLds &L, int s0, int s1, int d0)
     }
 }
 
-template <class RelFn>
-__device__ void far_apply(FarLds &L, const P2 &C, int ctag, RelFn rel)
+template <int CAP, int NT, class RelFn>
+__device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, RelFn rel)
 {
     // cooperative version of ofl_dl::poly_clip
     __syncthreads();                                   // the previous application has been read by every thread
     const int t = threadIdx.x, n = L.n;
     const double h = 0.5 * (C.x * C.x + C.y * C.y);
-    Poly P{ L.vx, L.vy, L.tag, 1, kFarCap, n };
+    Poly P{ L.vx, L.vy, L.tag, 1, CAP, n };
     if (t == 0) { L.a = 0x7fffffff; L.ncut = 0; }
     __syncthreads();
     int mine = 0;
-    for (int k = t; k < n; k += 256) { const bool c = vertex_cut(P, k, n, C, ctag, h, rel); L.cut[k] = c ? 1 : 0; mine += c; }
+    for (int k = t; k < n; k += NT) { const bool c = vertex_cut(P, k, n, C, ctag, ptag, h, rel); L.cut[k] = c ? 1 : 0; mine += c; }
     if (mine) atomicAdd(&L.ncut, mine);
     __syncthreads();
     const int ncut = L.ncut;
     if (ncut == 0 || ncut == n) return;
-    for (int k = t; k < n; k += 256)
+    for (int k = t; k < n; k += NT)
         if (L.cut[k] && !L.cut[k == 0 ? n - 1 : k - 1]) atomicMin(&L.a, k);
     __syncthreads();
     const int a = L.a;
@@ -351,7 +405,7 @@ __device__ void far_apply(FarLds &L, const P2 &C, int ctag, RelFn rel)
     while (L.cut[(a + len) % n]) ++len;               // every thread walks the (short) run: uniform result
     const int b = (a + len - 1) % n, ia = a == 0 ? n - 1 : a - 1, ib = (b + 1) % n;
     const int n2 = n - len + 2;
-    if (n2 > kFarCap) { if (t == 0) L.status |= 1; return; }
+    if (n2 > CAP) { if (t == 0) L.status |= 1; return; }
     const int tb = L.tag[b];
     const P2 v1 = cut_point(L.tag[ia], C, h, rel, L.vx[ia], L.vy[ia], L.vx[a], L.vy[a]);
     const P2 v2 = cut_point(tb, C, h, rel, L.vx[b], L.vy[b], L.vx[ib], L.vy[ib]);
@@ -374,51 +428,159 @@ __device__ void far_apply(FarLds &L, const P2 &C, int ctag, RelFn rel)
     __syncthreads();
 }
 
-// one chunk of up to 256 candidates (thread t holds candidate cand, or -1)
-template <class RelFn>
-__device__ void far_chunk(FarLds &L, int p, const P2 &pp, int cand, const PosFn &pos, RelFn rel)
+// one chunk of up to NT candidates (thread t holds candidate cand, or -1)
+template <int CAP, int NT, class RelFn>
+__device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const PosFn &pos, RelFn rel)
 {
     const int t = threadIdx.x;
     bool hit = false;
     P2 C{ 0.0, 0.0 };
+    __syncthreads();                                   // the cell of the previous chunk is final
     if (cand >= 0 && cand != p) {
         const P2 q = pos(cand);
         C.x = q.x - pp.x; C.y = q.y - pp.y;
         if (!(C.x == 0.0 && C.y == 0.0)) {
             const int n = L.n;
             const double h = 0.5 * (C.x * C.x + C.y * C.y);
-            Poly P{ L.vx, L.vy, L.tag, 1, kFarCap, n };
-            for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, h, rel);
+            Poly P{ L.vx, L.vy, L.tag, 1, CAP, n };
+            for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, p, h, rel);
         }
     }
     L.cidx[t] = cand; L.ccx[t] = C.x; L.ccy[t] = C.y;
     const unsigned long long m = __ballot(hit);
     if ((t & 63) == 0) L.hit[t >> 6] = m;
     __syncthreads();
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         unsigned long long bits = L.hit[w];
         while (bits) {
             const int j = w * 64 + __ffsll((long long)bits) - 1;
             bits &= bits - 1;
-            far_apply(L, P2{ L.ccx[j], L.ccy[j] }, L.cidx[j], rel);
+            far_apply(L, P2{ L.ccx[j], L.ccy[j] }, L.cidx[j], p, rel);
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256)
-void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
+// candidates of the fine buckets within kRings of the point's bucket, nearest rows first
+template <int CAP, int NT, class RelFn>
+__device__ void far_near_rows(FarLds<CAP, NT> &L, int p, const P2 &pp, const Grid &g, const unsigned *__restrict__ bstart,
+                              const unsigned *__restrict__ sorted, const PosFn &pos, RelFn rel)
+{
+    const int t = threadIdx.x, bx = g.bx(pp.x), by = g.by(pp.y);
+    for (int dr = 0; dr <= 2 * kRings; ++dr) {
+        const int row = by + ((dr & 1) ? (dr + 1) / 2 : -(dr / 2));        // by, by+1, by-1, by+2, ...
+        if (row < 0 || row >= g.gy) continue;
+        const int x0 = max(bx - kRings, 0), x1 = min(bx + kRings, g.gx - 1);
+        const unsigned lo = bstart[(size_t)row * g.gx + x0], hi = bstart[(size_t)row * g.gx + x1 + 1];
+        for (unsigned base = lo; base < hi; base += NT)
+            far_chunk(L, p, pp, base + t < hi ? (int)sorted[base + t] : -1, pos, rel);
+    }
+}
+
+// ring r of the coarse grid: unfinished points (ranks -> point indices)
+template <int CAP, int NT, class RelFn>
+__device__ void far_coarse_ring(FarLds<CAP, NT> &L, int p, const P2 &pp, int r, const Grid &g1,
+                                const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
+                                const unsigned *__restrict__ far_idx, const PosFn &pos, RelFn rel)
+{
+    const int t = threadIdx.x, bx = g1.bx(pp.x), by = g1.by(pp.y);
+    auto run = [&](int row, int x0, int x1) {
+        if (row < 0 || row >= g1.gy) return;
+        x0 = max(x0, 0); x1 = min(x1, g1.gx - 1);
+        if (x1 < x0) return;
+        const unsigned lo = b1start[(size_t)row * g1.gx + x0], hi = b1start[(size_t)row * g1.gx + x1 + 1];
+        for (unsigned base = lo; base < hi; base += NT)
+            far_chunk(L, p, pp, base + t < hi ? (int)far_idx[sorted1[base + t]] : -1, pos, rel);
+    };
+    if (r == 0) { run(by, bx, bx); return; }
+    run(by - r, bx - r, bx + r);
+    run(by + r, bx - r, bx + r);
+    for (int row = by - r + 1; row <= by + r - 1; ++row) {
+        if (bx - r >= 0) run(row, bx - r, bx - r);
+        if (bx + r <= g1.gx - 1) run(row, bx + r, bx + r);
+    }
+}
+
+template <int CAP, int NT>
+__device__ void far_store(FarLds<CAP, NT> &L, unsigned rank, DlHead *head, unsigned *__restrict__ far_deg,
+                          unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap, unsigned *s_off)
+{
+    const int t = threadIdx.x, n = L.n;
+    if (t == 0) {
+        *s_off = atomicAdd(&head->pool_used, (unsigned)n);
+        if (L.status) atomicOr(&head->err, 1u);
+    }
+    __syncthreads();
+    const unsigned off = *s_off;
+    if ((unsigned long long)off + n > pool_cap) {
+        if (t == 0) { atomicOr(&head->err, 2u); far_deg[rank] = 0; far_off[rank] = 0; }
+        return;
+    }
+    for (int k = t; k < n; k += NT) pool[off + k] = L.tag[k];
+    if (t == 0) { far_deg[rank] = (unsigned)n; far_off[rank] = off; }
+}
+
+__global__ __launch_bounds__(64)
+void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted,
+                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
                         const unsigned *__restrict__ far_idx, unsigned *__restrict__ far_deg,
                         unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
 {
-    __shared__ FarLds L;
+    __shared__ FarLds<kMidCap, 64> L;
     __shared__ unsigned s_off;
     const int t = threadIdx.x;
-    const unsigned rank = blockIdx.x, n_far = head->n_far;
-    if (rank >= n_far) return;
+    const unsigned rank = blockIdx.x;
+    if (rank >= head->n_far) return;
     const int p = (int)far_idx[rank];
-    const Grid g = head->grid;
+    const Grid g = head->grid, g1 = head->grid1;
+    const PosFn pos{ flow, sign, W };
+    const P2 pp = pos(p);
+    auto rel = [&](int q) { const P2 v = pos(q); return P2{ v.x - pp.x, v.y - pp.y }; };
+    if (t == 0) {
+        Poly P{ L.vx, L.vy, L.tag, 1, kMidCap, 0 };
+        poly_init(P);
+        L.n = P.n; L.status = 0;
+    }
+    __syncthreads();
+    far_near_rows(L, p, pp, g, bstart, sorted, pos, rel);
+    bool done = false;
+    for (int r = 0; r <= kMidRings && !done; ++r) {
+        far_coarse_ring(L, p, pp, r, g1, b1start, sorted1, far_idx, pos, rel);
+        // the cell is final once every unfinished point within twice its farthest vertex has been applied: points in
+        // unvisited coarse cells are at least r * s1 away (finished points farther than the fine rings cannot be
+        // neighbours: they would not have finished)
+        double r2 = 0.0;
+        const int n = L.n;
+        for (int k = t; k < n; k += 64) r2 = fmax(r2, L.vx[k] * L.vx[k] + L.vy[k] * L.vy[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            r2 = fmax(r2, __hiloint2double(__shfl_xor(__double2hiint(r2), off), __shfl_xor(__double2loint(r2), off)));
+        const double cover = (double)r * g1.s;
+        done = cover * cover >= 4.0 * r2;
+        if (L.status) break;
+    }
+    __syncthreads();
+    if (!done || L.status) { if (t == 0) far_deg[rank] = kDegLeft; return; }
+    far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
+}
+
+__global__ __launch_bounds__(256)
+void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
+                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted,
+                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
+                        const unsigned *__restrict__ far_idx, const unsigned *__restrict__ left_idx,
+                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
+                        unsigned long long pool_cap)
+{
+    __shared__ FarLds<kFarCap, 256> L;
+    __shared__ unsigned s_off;
+    const int t = threadIdx.x;
+    const unsigned n_left = head->n_left;
+    if (blockIdx.x >= n_left) return;
+    const unsigned rank = left_idx[blockIdx.x];
+    const int p = (int)far_idx[rank];
+    const Grid g = head->grid, g1 = head->grid1;
     const PosFn pos{ flow, sign, W };
     const P2 pp = pos(p);
     auto rel = [&](int q) { const P2 v = pos(q); return P2{ v.x - pp.x, v.y - pp.y }; };
@@ -428,32 +590,12 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
         L.n = P.n; L.status = 0;
     }
     __syncthreads();
-    // the sites of the near buckets (nearest rows first would be nicer; any order gives the same cell)
-    const int bx = g.bx(pp.x), by = g.by(pp.y);
-    for (int dr = 0; dr <= 2 * kRings; ++dr) {
-        const int row = by + ((dr & 1) ? (dr + 1) / 2 : -(dr / 2));        // by, by+1, by-1, by+2, ...
-        if (row < 0 || row >= g.gy) continue;
-        const int x0 = max(bx - kRings, 0), x1 = min(bx + kRings, g.gx - 1);
-        const unsigned lo = bstart[(size_t)row * g.gx + x0], hi = bstart[(size_t)row * g.gx + x1 + 1];
-        for (unsigned base = lo; base < hi; base += 256)
-            far_chunk(L, p, pp, base + t < hi ? (int)sorted[base + t] : -1, pos, rel);
-    }
-    // every other unfinished point
-    for (unsigned base = 0; base < n_far; base += 256)
-        far_chunk(L, p, pp, base + t < n_far ? (int)far_idx[base + t] : -1, pos, rel);
-    const int n = L.n;
-    if (t == 0) {
-        s_off = atomicAdd(&head->pool_used, (unsigned)n);
-        if (L.status) atomicOr(&head->err, 1u);
-    }
+    far_near_rows(L, p, pp, g, bstart, sorted, pos, rel);
+    for (int r = 0; r <= kMidRings; ++r) far_coarse_ring(L, p, pp, r, g1, b1start, sorted1, far_idx, pos, rel);
+    for (unsigned base = 0; base < n_left; base += 256)
+        far_chunk(L, p, pp, base + t < n_left ? (int)far_idx[left_idx[base + t]] : -1, pos, rel);
     __syncthreads();
-    const unsigned off = s_off;
-    if ((unsigned long long)off + n > pool_cap) {
-        if (t == 0) { atomicOr(&head->err, 2u); far_deg[rank] = 0; far_off[rank] = 0; }
-        return;
-    }
-    for (int k = t; k < n; k += 256) pool[off + k] = L.tag[k];
-    if (t == 0) { far_deg[rank] = (unsigned)n; far_off[rank] = off; }
+    far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
 }
 
 // ------------------------------------------------------------------------------------------------ raster
@@ -470,7 +612,7 @@ __device__ __forceinline__ TriRef dl_decode(unsigned id, unsigned far_base, cons
         r.ok = true;
     } else {
         const unsigned rank = (id - far_base) / kFarK, k = (id - far_base) % kFarK, d = ws.far_deg[rank];
-        if (k >= d) return r;
+        if (d == kDegLeft || k >= d) return r;
         const unsigned off = ws.far_off[rank];
         const int a = ws.pool[off + k], b = ws.pool[off + (k + 1 == d ? 0 : k + 1)];
         if (a < 0 || b < 0 || a == b) return r;
@@ -491,6 +633,27 @@ __device__ __forceinline__ TriBox box_rows(const D2 &p0, const D2 &p1, const D2 
 
 __device__ __forceinline__ D2 pt(const PosFn &pos, unsigned i) { const P2 p = pos((int)i); return D2{ p.x, p.y }; }
 
+// one triangle by one thread; large bounding boxes go to the list swept by whole waves
+__device__ __forceinline__ void thread_raster(unsigned id, const PosFn &pos, int H, int W, const DlWs &ws, unsigned far_base)
+{
+    const TriRef tr = dl_decode(id, far_base, ws);
+    if (!tr.ok) return;
+    const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
+    const TriBox b = box_rows(q0, q1, q2, W, H, ws);
+    if (b.x1 < b.x0 || b.y1 < b.y0) return;
+    const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
+    if (area > kSmallArea) {
+        const unsigned long long slot = atomicAdd(&ws.head->big_n, 1ull);
+        if (slot < ws.big_cap) ws.big[slot] = id; else atomicOr(&ws.head->err, 4u);
+        return;
+    }
+    TriEdge te;
+    if (!tri_setup(q0, q1, q2, te)) return;
+    for (int gy = b.y0; gy <= b.y1; ++gy)
+        for (int gx = b.x0; gx <= b.x1; ++gx)
+            if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+}
+
 __global__ __launch_bounds__(256)
 void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
 {
@@ -499,56 +662,21 @@ void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int
     const unsigned d = ws.deg[p];
     if (d == 0 || d > kSlots) return;
     const PosFn pos{ flow, sign, W };
-    for (unsigned k = 0; k < d; ++k) {
-        const unsigned id = (unsigned)p * kSlots + k;
-        const TriRef tr = dl_decode(id, far_base, ws);
-        if (!tr.ok) continue;
-        const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
-        const TriBox b = box_rows(q0, q1, q2, W, H, ws);
-        if (b.x1 < b.x0 || b.y1 < b.y0) continue;
-        const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
-        if (area > kSmallArea) {
-            const unsigned long long slot = atomicAdd(&ws.head->big_n, 1ull);
-            if (slot < ws.big_cap) ws.big[slot] = id; else atomicOr(&ws.head->err, 4u);
-            continue;
-        }
-        TriEdge te;
-        if (!tri_setup(q0, q1, q2, te)) continue;
-        for (int gy = b.y0; gy <= b.y1; ++gy)
-            for (int gx = b.x0; gx <= b.x1; ++gx)
-                if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
-    }
-}
-
-// one wave per triangle: 64 nodes of the bounding box per step
-__device__ __forceinline__ void wave_raster(unsigned id, const TriRef &tr, const PosFn &pos, int H, int W, const DlWs &ws)
-{
-    const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
-    const TriBox b = box_rows(q0, q1, q2, W, H, ws);
-    if (b.x1 < b.x0 || b.y1 < b.y0) return;
-    TriEdge te;
-    if (!tri_setup(q0, q1, q2, te)) return;
-    const long long bw = b.x1 - b.x0 + 1, area = bw * (b.y1 - b.y0 + 1);
-    for (long long j = threadIdx.x & 63; j < area; j += 64) {
-        const int gy = b.y0 + (int)(j / bw), gx = b.x0 + (int)(j % bw);
-        if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
-    }
+    for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, pos, H, W, ws, far_base);
 }
 
 __global__ __launch_bounds__(256)
 void dl_raster_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
 {
-    const unsigned rank = blockIdx.x;
+    const unsigned rank = blockIdx.x * 256 + threadIdx.x;
     if (rank >= ws.head->n_far) return;
     const unsigned d = ws.far_deg[rank];
+    if (d == kDegLeft) return;
     const PosFn pos{ flow, sign, W };
-    for (unsigned k = threadIdx.x >> 6; k < d; k += 4) {
-        const unsigned id = far_base + rank * kFarK + k;
-        const TriRef tr = dl_decode(id, far_base, ws);
-        if (tr.ok) wave_raster(id, tr, pos, H, W, ws);
-    }
+    for (unsigned k = 0; k < d; ++k) thread_raster(far_base + rank * kFarK + k, pos, H, W, ws, far_base);
 }
 
+// one wave per large triangle: 64 nodes of the bounding box per step
 __global__ __launch_bounds__(256)
 void dl_raster_big_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
 {
@@ -558,7 +686,17 @@ void dl_raster_big_kernel(const float *__restrict__ flow, int sign, int H, int W
     for (unsigned long long j = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6); j < n; j += (unsigned long long)gridDim.x * 4) {
         const unsigned id = ws.big[j];
         const TriRef tr = dl_decode(id, far_base, ws);
-        if (tr.ok) wave_raster(id, tr, pos, H, W, ws);
+        if (!tr.ok) continue;
+        const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
+        const TriBox b = box_rows(q0, q1, q2, W, H, ws);
+        if (b.x1 < b.x0 || b.y1 < b.y0) continue;
+        TriEdge te;
+        if (!tri_setup(q0, q1, q2, te)) continue;
+        const long long bw = b.x1 - b.x0 + 1, area = bw * (b.y1 - b.y0 + 1);
+        for (long long i = threadIdx.x & 63; i < area; i += 64) {
+            const int gy = b.y0 + (int)(i / bw), gx = b.x0 + (int)(i % bw);
+            if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+        }
     }
 }
 
@@ -589,14 +727,26 @@ void dl_resolve_kernel(const float *__restrict__ flow, int sign, const VT *__res
     resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
 }
 
-DlWs carve_exact(void *base, int H, int W)
+struct Sizes { size_t n, bcap, b1cap, pool_cap, big_cap; };
+
+Sizes sizes_for(int H, int W)
 {
-    const size_t n = (size_t)H * W;
+    Sizes z;
+    z.n = (size_t)H * W;
+    z.bcap = 2 * z.n + 1024;
+    z.b1cap = z.bcap / (kMidScale * kMidScale) + 2 * (size_t)(H + W) + 4096;       // ceil per axis adds a row and a column
+    z.pool_cap = 8 * z.n + 65536;
+    z.big_cap = 6 * z.n + 1024;
+    return z;
+}
+
+DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
+{
+    const Sizes z = sizes_for(H, W);
+    const size_t n = z.n;
     DlWs ws;
     char *p = (char *)base;
-    ws.bcap = 2 * n + 1024;
-    ws.pool_cap = 8 * n + 65536;
-    ws.big_cap = 6 * n + 1024;
+    ws.bcap = z.bcap; ws.b1cap = z.b1cap; ws.pool_cap = z.pool_cap; ws.big_cap = z.big_cap;
     ws.head = (DlHead *)p;                  p += 256;
     ws.bstart = (unsigned *)p;              p += align_up((ws.bcap + 1) * 4, 256);
     ws.scan_tmp = (unsigned *)p;            p += align_up(scan_tmp_elems(ws.bcap + 1) * 4, 256);
@@ -606,10 +756,15 @@ DlWs carve_exact(void *base, int H, int W)
     ws.far_idx = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_deg = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_off = (unsigned *)p;             p += align_up(n * 4, 256);
+    ws.left_idx = (unsigned *)p;            p += align_up(n * 4, 256);
+    ws.b1start = (unsigned *)p;             p += align_up((ws.b1cap + 1) * 4, 256);
+    ws.b1cursor = (unsigned *)p;            p += align_up(ws.b1cap * 4, 256);
+    ws.sorted1 = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
     ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
     ws.oy0 = 0; ws.oy1 = H;
+    if (total) *total = (size_t)(p - (char *)base);
     return ws;
 }
 
@@ -640,14 +795,12 @@ namespace ofl_sc {
 
 size_t exact_workspace_bytes(int H, int W)
 {
-    const size_t n = (size_t)H * W;
-    const size_t bcap = 2 * n + 1024, pool_cap = 8 * n + 65536, big_cap = 6 * n + 1024;
-    return 256 + align_up((bcap + 1) * 4, 256) + align_up(scan_tmp_elems(bcap + 1) * 4, 256) + align_up(n * 4, 256) +
-           align_up(n, 256) + align_up(std::max(n * kSlots, bcap) * 4, 256) + 3 * align_up(n * 4, 256) +
-           align_up(pool_cap * 4, 256) + align_up(big_cap * 4, 256) + align_up(n * 4, 256);
+    size_t total = 0;
+    (void)carve_exact(nullptr, H, W, &total);
+    return total;
 }
 
-// rows [row0, row0 + rows) of the grid result through the exact path; synchronises once (counts of the star passes)
+// rows [row0, row0 + rows) of the grid result through the exact path; synchronises twice (counts of the star passes)
 template <typename VT>
 int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT *vals, int C, const uint8_t *vmask,
                   int H, int W, int row0, int rows, VT *out, uint8_t *valid, int valid_rule,
@@ -675,17 +828,17 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
     hipLaunchKernelGGL(dl_fill_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
                        (const unsigned *)ws.bstart, ws.nbr, ws.sorted);
     hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
-                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, ws.sorted);
+                       (const DlHead *)ws.head, 0, (const unsigned *)ws.bstart, ws.sorted);
     hipLaunchKernelGGL(dl_star_near_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, flow, sign_pp, pmask, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, ws.deg, ws.nbr);
     OFL_HIP(hipGetLastError());
-    // far points in index order
+    // unfinished points in index order
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
-    unsigned *fcnt = ws.far_deg;                                         // scratch until the far pass writes it
-    hipLaunchKernelGGL(dl_far_count_kernel, dim3(fblk), dim3(256), 0, s, (const unsigned char *)ws.deg, n, fcnt);
+    unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
+    hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_far_write_kernel, dim3(fblk), dim3(256), 0, s, (const unsigned char *)ws.deg, n, (const unsigned *)fcnt,
-                       ws.far_idx, ws.head, fblk - 1);
+    hipLaunchKernelGGL(dl_flag_write_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, ws.head, n, (const unsigned *)fcnt,
+                       ws.far_idx, fblk - 1);
     OFL_HIP(hipGetLastError());
     DlHead h;
     OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -696,14 +849,43 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
     if (far_base + (unsigned long long)h.n_far * kFarK >= 0xFFFFFFF0ull)
         return fail(OFL_E_INVALID, "ofl_scatter_linear: %u unfinished stars exceed the triangle-id space of the exact path", h.n_far);
     if (h.n_far) {
-        hipLaunchKernelGGL(dl_star_far_kernel, dim3(h.n_far), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
-                           (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.far_idx,
-                           ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
+        // coarse grid of the unfinished points, wave pass, then the workgroup pass for what is still left
+        const unsigned rblk = (h.n_far + 255) / 256;
+        OFL_HIP(hipMemsetAsync(ws.b1start, 0, (ws.b1cap + 1) * 4, s));
+        OFL_HIP(hipMemsetAsync(ws.b1cursor, 0, ws.b1cap * 4, s));
+        hipLaunchKernelGGL(dl_count1_kernel, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
+                           (const unsigned *)ws.far_idx, ws.b1start);
+        OFL_TRY(scan_exclusive(ws.b1start, ws.b1cap + 1, ws.scan_tmp, s));
+        hipLaunchKernelGGL(dl_fill1_kernel, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
+                           (const unsigned *)ws.far_idx, (const unsigned *)ws.b1start, ws.b1cursor, ws.sorted1);
+        hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.b1cap + 255) / 256), 65535u)), dim3(256), 0, s,
+                           (const DlHead *)ws.head, 1, (const unsigned *)ws.b1start, ws.sorted1);
+        hipLaunchKernelGGL(dl_star_mid_kernel, dim3(h.n_far), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
+                           (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.b1start,
+                           (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, ws.far_deg, ws.far_off, ws.pool,
+                           (unsigned long long)ws.pool_cap);
         OFL_HIP(hipGetLastError());
+        const unsigned lblk = (h.n_far + kScanChunk - 1) / kScanChunk;
+        unsigned *lcnt = (unsigned *)ws.big;                             // the large-triangle list is empty until the raster passes
+        hipLaunchKernelGGL(dl_flag_count_kernel<1>, dim3(lblk), dim3(256), 0, s, (const void *)ws.far_deg, (const DlHead *)ws.head, (size_t)0, lcnt);
+        OFL_TRY(scan_exclusive(lcnt, lblk, ws.scan_tmp, s));
+        hipLaunchKernelGGL(dl_flag_write_kernel<1>, dim3(lblk), dim3(256), 0, s, (const void *)ws.far_deg, ws.head, (size_t)0,
+                           (const unsigned *)lcnt, ws.left_idx, lblk - 1);
+        OFL_HIP(hipGetLastError());
+        OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
+        OFL_HIP(hipStreamSynchronize(s));
+        if (info_host) info_host[2] = h.n_left;
+        if (h.n_left) {
+            hipLaunchKernelGGL(dl_star_far_kernel, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.b1start,
+                               (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                               ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
+            OFL_HIP(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(dl_raster_small_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     if (h.n_far)
-        hipLaunchKernelGGL(dl_raster_far_kernel, dim3(h.n_far), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+        hipLaunchKernelGGL(dl_raster_far_kernel, dim3((h.n_far + 255) / 256), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     const dim3 grid((W + 31) / 32, (rows + 7) / 8);
     hipLaunchKernelGGL(dl_resolve_kernel<VT>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
@@ -714,7 +896,6 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
         // than kFarCap neighbours, the neighbour pool, the large-triangle list): one more small read-back
         OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
         OFL_HIP(hipStreamSynchronize(s));
-        info_host[2] = h.err;
         if (h.err) return fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
                                               "neighbours, 2 = neighbour pool, 4 = large-triangle list)", h.err, kFarCap);
     }

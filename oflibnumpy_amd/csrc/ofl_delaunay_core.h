@@ -35,16 +35,21 @@ constexpr double kDecide = 1e-9;      // relative margin inside which the vertex
 // Polygon of the cell under construction: vertex k at (vx, vy)[k * stride] relative to the site, tag[k * stride] =
 // the site whose bisector carries the edge from vertex k to vertex k + 1 (-1 .. -4: the box sides y = -B, x = B,
 // y = B, x = -B).  Counter-clockwise in (x, y).
-struct Poly {
-    double *vx, *vy;
-    int    *tag;
-    int     stride, cap, n;
-    DL_HD double &X(int k) const { return vx[k * stride]; }
-    DL_HD double &Y(int k) const { return vy[k * stride]; }
-    DL_HD int    &T(int k) const { return tag[k * stride]; }
+template <typename R>       // R = double, or float for the per-thread pass (half the LDS; decisions that come close go to
+struct PolyT {              // the in-circle predicate on the float64 SITE coordinates either way)
+    R   *vx, *vy;
+    int *tag;
+    int  stride, cap, n;
+    DL_HD R   &X(int k) const { return vx[k * stride]; }
+    DL_HD R   &Y(int k) const { return vy[k * stride]; }
+    DL_HD int &T(int k) const { return tag[k * stride]; }
+    // relative margin inside which the test on the stored vertex coordinates defers to the predicate
+    static constexpr double decide = sizeof(R) == 8 ? kDecide : 4e-6;
 };
+using Poly = PolyT<double>;
 
-DL_HD void poly_init(Poly &P)
+template <class PolyX>
+DL_HD void poly_init(PolyX &P)
 {
     P.X(0) = -kBox; P.Y(0) = -kBox; P.T(0) = -1;
     P.X(1) =  kBox; P.Y(1) = -kBox; P.T(1) = -2;
@@ -53,7 +58,9 @@ DL_HD void poly_init(Poly &P)
     P.n = 4;
 }
 
-// > 0 when c lies inside the circle through the origin, a and b (any orientation of a, b)
+// > 0 when c lies inside the circle through the origin, a and b (any orientation of a, b); exactly 0 for four
+// co-circular points in exact arithmetic that float64 represents exactly (lattice points: translations, the tiled
+// Sintel field) -- vertex_cut breaks such ties by index
 DL_HD double incircle_origin(const P2 &a, const P2 &b, const P2 &c)
 {
     const double a2 = a.x * a.x + a.y * a.y, b2 = b.x * b.x + b.y * b.y, c2 = c.x * c.x + c.y * c.y;
@@ -74,20 +81,40 @@ DL_HD void edge_line(int tag, RelFn rel, double &nx, double &ny, double &h)
 }
 
 // does the bisector of candidate c (relative position C, h = |C|^2 / 2) cut off vertex k of an n-vertex polygon?
-template <class RelFn>
-DL_HD bool vertex_cut(const Poly &P, int k, int n, const P2 &C, int ctag, double h, RelFn rel)
+// Exact ties (determinant == 0: the sites p, a, c, b lie on one circle) are broken the way the certified mesh path
+// breaks them for its square cells: of the two diagonals of the quadrilateral the one through the site with the
+// smallest index exists.  c cutting the vertex makes p - c an edge, so it cuts iff the smallest index is p's or c's;
+// seen from any of the four sites the same diagonal wins, so their stars agree.
+template <class PolyX, class RelFn>
+DL_HD bool vertex_cut(const PolyX &P, int k, int n, const P2 &C, int ctag, int ptag, double h, RelFn rel)
 {
     const int ta = P.T(k == 0 ? n - 1 : k - 1), tb = P.T(k);
     if (ctag == ta || ctag == tb) return false;       // the candidate already carries an edge at this vertex
-    const double tx = P.X(k) * C.x, ty = P.Y(k) * C.y;
+    const double tx = (double)P.X(k) * C.x, ty = (double)P.Y(k) * C.y;
     const double d = tx + ty - h;
-    const double m = kDecide * (fabs(tx) + fabs(ty) + h);
+    const double m = PolyX::decide * (fabs(tx) + fabs(ty) + h);
     if (d > m) return true;
     if (d < -m) return false;
     if (ta >= 0 && tb >= 0 && ta != tb) {
         const P2 A = rel(ta), B = rel(tb);
         if ((A.x == C.x && A.y == C.y) || (B.x == C.x && B.y == C.y)) return false;     // a duplicate of an edge's site
-        return incircle_origin(A, B, C) > 0.0;
+        if (A.x * B.y - A.y * B.x != 0.0) {          // (p, a, b collinear: parallel bisectors, the vertex is a box vertex)
+            const double ic = incircle_origin(A, B, C);
+            if (ic != 0.0) return ic > 0.0;
+            const int lo_pc = ptag < ctag ? ptag : ctag, lo_ab = ta < tb ? ta : tb;
+            return lo_pc < lo_ab;
+        }
+    }
+    // a vertex on the box (unbounded cell): the stored coordinates (float32 in the per-thread pass, and ~1e9 in size)
+    // cannot resolve a candidate whose bisector passes within a few units of it -- re-derive the vertex in float64 from
+    // the two lines that define it
+    double ax, ay, ah, bx, by, bh;
+    edge_line(ta, rel, ax, ay, ah);
+    edge_line(tb, rel, bx, by, bh);
+    const double det = ax * by - bx * ay;
+    if (det != 0.0) {
+        const double vx = (ah * by - bh * ay) / det, vy = (ax * bh - bx * ah) / det;
+        if (isfinite(vx) && isfinite(vy)) return vx * C.x + vy * C.y - h > 0.0;
     }
     return d > 0.0;
 }
@@ -115,14 +142,14 @@ DL_HD P2 cut_point(int tag, const P2 &C, double h, RelFn rel, double ux, double 
 
 // Clips the polygon with the bisector of candidate `ctag` at relative position C.  Returns 0 (unchanged), 1 (clipped)
 // or -1 (the polygon would exceed its capacity; it is left unchanged).  Sequential; n <= 64.
-template <class RelFn>
-DL_HD int poly_clip(Poly &P, const P2 &C, int ctag, RelFn rel)
+template <class PolyX, class RelFn>
+DL_HD int poly_clip(PolyX &P, const P2 &C, int ctag, int ptag, RelFn rel)
 {
     const double h = 0.5 * (C.x * C.x + C.y * C.y);
     const int n = P.n;
     unsigned long long cut = 0;
     for (int k = 0; k < n; ++k)
-        if (vertex_cut(P, k, n, C, ctag, h, rel)) cut |= 1ull << k;
+        if (vertex_cut(P, k, n, C, ctag, ptag, h, rel)) cut |= 1ull << k;
     if (!cut) return 0;
     const unsigned long long full = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     if (cut == full) return 0;                       // the site itself is inside every half-plane: rounding only
@@ -154,11 +181,12 @@ DL_HD int poly_clip(Poly &P, const P2 &C, int ctag, RelFn rel)
 }
 
 // squared distance of the farthest cell vertex from the site
-DL_HD double poly_rmax2(const Poly &P)
+template <class PolyX>
+DL_HD double poly_rmax2(const PolyX &P)
 {
     double r2 = 0.0;
-    for (int k = 0; k < P.n; ++k) r2 = fmax(r2, P.X(k) * P.X(k) + P.Y(k) * P.Y(k));
-    return r2;
+    for (int k = 0; k < P.n; ++k) r2 = fmax(r2, (double)P.X(k) * (double)P.X(k) + (double)P.Y(k) * (double)P.Y(k));
+    return sizeof(P.X(0)) == 8 ? r2 : r2 * 1.00001;
 }
 
 // bucket grid over the bounding box of the sites
@@ -172,8 +200,8 @@ struct Grid {
 // All sites of the buckets on the Chebyshev ring r around bucket (bx, by) are applied to the cell of site p (at pp).
 // Buckets are stored row-major and `sorted` lists the sites bucket by bucket, so a run of buckets in one row is ONE
 // contiguous range of `sorted`.  Returns -1 when the polygon overflows.
-template <class PosFn>
-DL_HD int apply_ring(Poly &P, int p, const P2 &pp, int bx, int by, int r, const Grid &g,
+template <class PolyX, class PosFn>
+DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const Grid &g,
                      const unsigned *bstart, const unsigned *sorted, PosFn pos)
 {
     auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
@@ -189,7 +217,7 @@ DL_HD int apply_ring(Poly &P, int p, const P2 &pp, int bx, int by, int r, const 
             const P2 q = pos(c);
             const P2 C = { q.x - pp.x, q.y - pp.y };
             if (C.x == 0.0 && C.y == 0.0) continue;           // a duplicate of p: same cell
-            if (poly_clip(P, C, c, rel) < 0) return -1;
+            if (poly_clip(P, C, c, p, rel) < 0) return -1;
         }
         return 0;
     };
@@ -205,8 +233,8 @@ DL_HD int apply_ring(Poly &P, int p, const P2 &pp, int bx, int by, int r, const 
 // The star of site p from the sites within `rings` bucket rings.  Returns 1 when the cell is final (every site within
 // twice the farthest cell vertex has been applied: sites in unvisited buckets are at least r * s away), 0 when it is
 // not (unbounded cells, rims of large holes: the far pass finishes those), -1 when the polygon overflowed.
-template <class PosFn>
-DL_HD int star_near(Poly &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
+template <class PolyX, class PosFn>
+DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
                     PosFn pos, int rings)
 {
     poly_init(P);

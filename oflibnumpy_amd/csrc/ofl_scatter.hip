@@ -1029,11 +1029,11 @@ int scatter_grid_impl(const char *who, const float *flow, int sign, int point_pr
     if (H <= 0 || W <= 0 || row0 < 0 || rows <= 0 || row0 + rows > H)
         return fail(OFL_E_INVALID, "%s: rows [%d, %d) outside the %d-row grid", who, row0, row0 + rows, H);
     static const bool legacy = getenv("OFL_SC_LEGACY") != nullptr;       // development knob: always take the owner-map path
-    if (!legacy && !pmask && workspace && workspace_bytes >= 256) {
+    if (!legacy && workspace && workspace_bytes >= 256) {
         // certified fast path: when the cell-wise mesh provably IS the Delaunay triangulation (ofl_scatter_walk.hip),
         // one kernel resolves the rows -- no owner map, no hull
         ofl_mesh_cert cert;
-        OFL_TRY(certify_mesh(flow, sign, nullptr, H, W, workspace, &cert, s));
+        OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));       // a point mask without zeros drops nothing
         if (cert.certified) {
             if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
             return walk_launch<VT>(flow, sign, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule, &cert, nullptr, s);

@@ -3,6 +3,7 @@
 // triangulation on the reference fixtures.  The product never loads it (the GPU kernels include the same header).
 #include "../../oflibnumpy_amd/csrc/ofl_delaunay_core.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -12,13 +13,13 @@ namespace {
 
 // sequential clip for polygons of any size (the far pass; the GPU version of this step is workgroup-cooperative)
 template <class RelFn>
-int poly_clip_any(Poly &P, const P2 &C, int ctag, RelFn rel, std::vector<char> &cut)
+int poly_clip_any(Poly &P, const P2 &C, int ctag, int ptag, RelFn rel, std::vector<char> &cut)
 {
     const double h = 0.5 * (C.x * C.x + C.y * C.y);
     const int n = P.n;
     cut.assign(n, 0);
     int ncut = 0;
-    for (int k = 0; k < n; ++k) { cut[k] = vertex_cut(P, k, n, C, ctag, h, rel); ncut += cut[k]; }
+    for (int k = 0; k < n; ++k) { cut[k] = vertex_cut(P, k, n, C, ctag, ptag, h, rel); ncut += cut[k]; }
     if (ncut == 0 || ncut == n) return 0;
     int a = -1;
     for (int k = 0; k < n; ++k) if (cut[k] && !cut[k == 0 ? n - 1 : k - 1]) { a = k; break; }
@@ -41,7 +42,7 @@ int poly_clip_any(Poly &P, const P2 &C, int ctag, RelFn rel, std::vector<char> &
 }  // namespace
 
 // pts [n][2]; tri_out receives (p, a, b) for every pair of consecutive real neighbours of every star ("emit all");
-// info: [0] far sites, [1] polygon overflows in the near pass, [2] grid gx, [3] grid gy
+// info[8]: [0] far sites, [1] polygon overflows in the near pass, [2] grid gx, [3] grid gy, [4] largest star
 extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, int *tri_out, long long tri_cap,
                             long long *n_tri, int *info)
 {
@@ -70,8 +71,9 @@ extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, i
     std::vector<int> far;
     std::vector<char> flags;
     long long nt = 0;
-    int overflow = 0;
+    int overflow = 0, maxdeg = 0;
     auto emit = [&](int p, const Poly &P) {
+        maxdeg = std::max(maxdeg, P.n);
         for (int k = 0; k < P.n; ++k) {
             const int a = P.T(k), b = P.T((k + 1) % P.n);
             if (a < 0 || b < 0 || a == b) continue;
@@ -79,7 +81,23 @@ extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, i
             ++nt;
         }
     };
+    std::vector<float> fx(64), fy(64);
     for (int p = 0; p < n; ++p) {
+        // near_cap < 0: the float32 cell of the GPU's per-thread pass
+        if (near_cap < 0) {
+            PolyT<float> P{ fx.data(), fy.data(), tag.data(), 1, -near_cap, 0 };
+            const int rc = star_near(P, p, pos(p), g, bstart.data(), sorted.data(), pos, rings);
+            bool ok = rc == 1;
+            for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
+            if (ok) {
+                Poly Q{ vx.data(), vy.data(), tag.data(), 1, 64, P.n };
+                emit(p, Q);
+                continue;
+            }
+            if (rc < 0) ++overflow;
+            far.push_back(p);
+            continue;
+        }
         Poly P{ vx.data(), vy.data(), tag.data(), 1, near_cap, 0 };
         const int rc = star_near(P, p, pos(p), g, bstart.data(), sorted.data(), pos, rings);
         if (rc == 1) { emit(p, P); continue; }
@@ -103,18 +121,65 @@ extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, i
                         const int c = (int)sorted[j];
                         const P2 C = rel(c);
                         if (c == p || (C.x == 0.0 && C.y == 0.0)) continue;
-                        if (poly_clip_any(P, C, c, rel, flags) < 0) return -2;
+                        if (poly_clip_any(P, C, c, p, rel, flags) < 0) return -2;
                     }
                 }
             }
         for (int c : far) {
             const P2 C = rel(c);
             if (c == p || (C.x == 0.0 && C.y == 0.0)) continue;
-            if (poly_clip_any(P, C, c, rel, flags) < 0) return -2;
+            if (poly_clip_any(P, C, c, p, rel, flags) < 0) return -2;
         }
         emit(p, P);
     }
     *n_tri = nt;
-    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy;
+    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy; info[4] = maxdeg;
+    return 0;
+}
+
+// debugging aid: the near-pass star of ONE site with float32 or float64 cell storage, every clip printed
+extern "C" int dl_star_trace(const double *pts, int n, int p, int use_float, int rings)
+{
+    double x0 = pts[0], x1 = pts[0], y0 = pts[1], y1 = pts[1];
+    for (int i = 1; i < n; ++i) {
+        x0 = std::min(x0, pts[2 * i]); x1 = std::max(x1, pts[2 * i]);
+        y0 = std::min(y0, pts[2 * i + 1]); y1 = std::max(y1, pts[2 * i + 1]);
+    }
+    Grid g;
+    const double bw = x1 - x0, bh = y1 - y0;
+    double s = std::max(sqrt(std::max(bw * bh, 1e-300) / n), (bw + bh) / (double)n);
+    g.ox = x0; g.oy = y0; g.s = s; g.inv_s = 1.0 / s;
+    g.gx = (int)floor(bw / s) + 1; g.gy = (int)floor(bh / s) + 1;
+    const size_t nb = (size_t)g.gx * g.gy;
+    std::vector<unsigned> bstart(nb + 1, 0), sorted(n), cursor(nb, 0);
+    auto bucket = [&](int i) { return (size_t)g.by(pts[2 * i + 1]) * g.gx + g.bx(pts[2 * i]); };
+    for (int i = 0; i < n; ++i) ++bstart[bucket(i) + 1];
+    for (size_t b = 0; b < nb; ++b) bstart[b + 1] += bstart[b];
+    for (int i = 0; i < n; ++i) { const size_t b = bucket(i); sorted[bstart[b] + cursor[b]++] = (unsigned)i; }
+    auto pos = [&](int i) { return P2{ pts[2 * i], pts[2 * i + 1] }; };
+    const P2 pp = pos(p);
+    auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
+    std::vector<double> vx(64), vy(64); std::vector<float> fx(64), fy(64); std::vector<int> tag(64);
+    Poly D{ vx.data(), vy.data(), tag.data(), 1, 64, 0 };
+    PolyT<float> F{ fx.data(), fy.data(), tag.data(), 1, 64, 0 };
+    if (use_float) poly_init(F); else poly_init(D);
+    const int bx = g.bx(pp.x), by = g.by(pp.y);
+    for (int r = 0; r <= rings; ++r) {
+        for (int row = by - r; row <= by + r; ++row) for (int col = bx - r; col <= bx + r; ++col) {
+            if (row < 0 || row >= g.gy || col < 0 || col >= g.gx || std::max(abs(row - by), abs(col - bx)) != r) continue;
+            for (unsigned j = bstart[(size_t)row * g.gx + col]; j < bstart[(size_t)row * g.gx + col + 1]; ++j) {
+                const int c = (int)sorted[j];
+                const P2 C = rel(c);
+                if (c == p || (C.x == 0 && C.y == 0)) continue;
+                const int rc = use_float ? poly_clip(F, C, c, p, rel) : poly_clip(D, C, c, p, rel);
+                if (rc) {
+                    const int m = use_float ? F.n : D.n;
+                    printf("r=%d clip by %d (%.4f,%.4f) rc=%d n=%d:", r, c, C.x, C.y, rc, m);
+                    for (int k = 0; k < m; ++k) printf(" [%d](%.5g,%.5g)", tag[k], use_float ? (double)F.X(k) : D.X(k), use_float ? (double)F.Y(k) : D.Y(k));
+                    printf("\n");
+                }
+            }
+        }
+    }
     return 0;
 }

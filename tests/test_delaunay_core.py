@@ -30,7 +30,7 @@ def stars(lib, pts, rings=6, near_cap=16):
     cap = 12 * n + 1024
     tri = np.zeros((cap, 3), np.int32)
     nt = ctypes.c_longlong(0)
-    info = (ctypes.c_int * 4)()
+    info = (ctypes.c_int * 8)()
     rc = lib.dl_stars_cpu(pts.ctypes.data_as(ctypes.c_void_p), n, rings, near_cap, tri.ctypes.data_as(ctypes.c_void_p),
                           ctypes.c_longlong(cap), ctypes.byref(nt), info)
     assert rc == 0 and nt.value <= cap
@@ -71,9 +71,10 @@ def fixture_points(g, tag):
 
 @pytest.mark.parametrize("tag", ["curved", "curved_in", "shear", "wobble3", "speckle_img", "affine_generic",
                                  "affine_generic_hole", "block_generic", "hole_img"])
-def test_stars_equal_scipy_delaunay(core, golden2, tag):
+@pytest.mark.parametrize("near_cap", [16, -12])      # float64 cells of 16 vertices / the GPU's float32 cells of 12
+def test_stars_equal_scipy_delaunay(core, golden2, tag, near_cap):
     pts = fixture_points(golden2, tag)
-    tri, info = stars(core, pts)
+    tri, info = stars(core, pts, near_cap=near_cap)
     assert info[1] == 0 or info[0] > 0                      # overflowing stars went to the far pass
     ours = {tuple(sorted(t)) for t in tri.tolist()}
     d = Delaunay(pts)

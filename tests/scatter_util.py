@@ -1,0 +1,32 @@
+"""Helpers shared by the GPU scatter tests: where is SciPy's own triangulation unique?"""
+import numpy as np
+
+
+def warped_points(vecs, keep=None, sign=1):
+    h, w = vecs.shape[:2]
+    yy, xx = np.mgrid[:h, :w]
+    p = np.stack([(xx + sign * vecs[..., 0].astype(np.float64)).ravel(), (yy + sign * vecs[..., 1].astype(np.float64)).ravel()], 1)
+    return p if keep is None else p[np.asarray(keep, bool).ravel()]
+
+
+def nonunique_nodes(points, shape):
+    """Grid nodes whose covering simplex of SciPy's own triangulation is NOT uniquely Delaunay (a fourth site within
+    1e-9 of its circumcircle, or a duplicated site): Qhull's choice among the co-circular alternatives is arbitrary
+    there, and non-affine data (image values, speckled masks) can tell the alternatives apart.  Everywhere else the
+    Delaunay triangulation -- and with it griddata's result -- is unique.  Returns (ambiguous, inside_hull)."""
+    from scipy.spatial import Delaunay
+    from test_delaunay_core import unique_simplices
+    upts, inv, counts = np.unique(points, axis=0, return_inverse=True, return_counts=True)
+    d = Delaunay(upts)
+    uniq = unique_simplices(upts, d.simplices)
+    dup_vertex = (counts[d.simplices] > 1).any(1)
+    yy, xx = np.mgrid[:shape[0], :shape[1]]
+    s = d.find_simplex(np.stack([xx.ravel(), yy.ravel()], 1).astype(np.float64)).reshape(shape)
+    amb = np.zeros(shape, bool)
+    inside = s >= 0
+    amb[inside] = ~uniq[s[inside]] | dup_vertex[s[inside]]
+    return amb, inside
+
+
+def ambiguous_for(vecs, keep=None, sign=1):
+    return nonunique_nodes(warped_points(vecs, keep, sign), vecs.shape[:2])[0]

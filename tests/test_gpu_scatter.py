@@ -6,15 +6,18 @@ Expected values are (a) outputs of the REAL reference captured in tests/golden/r
 (b) the oracle, which calls the same scipy.interpolate.griddata the reference calls.
 
 Bars: validity masks bit-exact; interpolated float32 values within 1e-4 relative (BASELINE.json) -- in
-practice ~1e-6 -- wherever the warped grid's Delaunay triangulation is the cell-wise one the kernel
-builds (all flows here).  Flows whose point mask has holes are a documented deviation:
-SciPy re-triangulates the hole, the kernel leaves it uncovered; the tests pin exactly that.
+practice ~1e-6 -- wherever SciPy's own Delaunay triangulation is unique (scatter_util.nonunique_nodes marks the
+simplices with a fourth site on their circumcircle: exact squares of translations / axis-aligned scalings and the
+~13 % of cells of a similarity transform whose float32 rounding is identical at all four corners; Qhull's choice
+there is arbitrary).  Holes of the point mask, curved borders, folds and sheared cells are triangulated exactly
+like SciPy does (round 2: certified mesh path + Delaunay path, see test_gpu_scatter_exact.py).
 """
 import numpy as np
 import pytest
 
 from test_oracle import (golden_tags, k7_flows, K7_VALID_TARGET_S, K7_VALID_SOURCE_T,
                          K7_VALID_TARGET_S_MASKED, K7_VALID_SOURCE_T_MASKED)
+from scatter_util import ambiguous_for
 
 pytestmark = pytest.mark.gpu
 
@@ -43,19 +46,12 @@ def ambiguous_nodes(flow, sign=1, tol=1e-9):
     return out
 
 
-def assert_close_outside_ambiguous(got, want, amb, tag="", covered=None):
-    """Values agree except in co-circular cells and (non-affine data only) in the gap nodes between the
-    warped mesh and its convex hull, where SciPy's long border triangles and the kernel's continuation
-    of the nearest cell triangle are different interpolants.  Returns the mismatching fraction."""
-    from scipy import ndimage
+def assert_close_outside_ambiguous(got, want, amb, tag=""):
+    """Values agree everywhere except where SciPy's triangulation is not unique.  Returns the mismatching fraction."""
     bad = ~np.isclose(got, want, rtol=RTOL, atol=ATOL)
     if bad.ndim == 3:
         bad = bad.any(-1)
-    allowed = amb.copy()
-    if covered is not None:
-        allowed |= covered & ~ndimage.binary_erosion(covered, iterations=2)
-    assert not (bad & ~allowed).any(), "{}: {} values differ outside co-circular cells / border gaps".format(
-        tag, int((bad & ~allowed).sum()))
+    assert not (bad & ~amb).any(), "{}: {} values differ outside non-unique simplices".format(tag, int((bad & ~amb).sum()))
     return bad.mean()
 
 
@@ -93,34 +89,38 @@ def has_holes(g, tag):
     return not g[tag + '/in_mask'].all()
 
 
+def case_ambiguity(golden, tag):
+    """non-unique nodes of the point set SciPy received in this case"""
+    sign = -1 if tag.startswith(('valid_source', 'k7/valid_source')) else 1
+    if str(golden[tag + '/in_ref']) == 't' and tag.split('/')[0] in ('invert', 'switch_ref'):
+        sign = -1                                   # t -> s / t -> t go through points x - f (flow_class.py:725, 753)
+    keep = golden[tag + '/in_mask'] if has_holes(golden, tag) else None
+    return ambiguous_for(golden[tag + '/in_vecs'], keep, sign)
+
+
 def check_case(of, golden, tag):
-    from scipy import ndimage
     r = run_product(of, golden, tag)
-    amb = ambiguous_nodes(golden[tag + '/in_vecs'], -1 if tag.startswith('valid_source') else 1)
-    speckled = not golden[tag + '/in_mask'].all()      # only reaches here with consider_mask=False
+    amb = case_ambiguity(golden, tag)
+    speckled = not golden[tag + '/in_mask'].all()      # the mask VALUES are interpolated: which triangle covers a node matters
     if isinstance(r, of.Flow):
         assert r.ref == str(golden[tag + '/out_ref']), tag
         np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
-        sel = np.ones(r.mask.shape, bool)
-        if 'wobble' in tag:     # non-affine data: the gap nodes next to the curved mesh border differ
-            sel = ~r.mask | ndimage.binary_erosion(r.mask, iterations=2)
+        sel = ~amb if 'wobble' in tag else np.ones(r.mask.shape, bool)      # flow-valued data is affine for the affine fields
+        if tag == 'combine2_wobble/t':
+            # mode 2 / ref 't' samples at arbitrary QUERY positions (flow_class.py:1398-1410): that entry still locates
+            # its triangles through the owner map of the cell-wise mesh, whose border pockets differ from SciPy's
+            from scipy import ndimage
+            sel &= ~r.mask | ndimage.binary_erosion(r.mask, iterations=2)
         np.testing.assert_allclose(r.vecs[sel], golden[tag + '/out_vecs'][sel], rtol=RTOL, atol=ATOL, err_msg=tag)
     elif isinstance(r, tuple):
-        # random image content (not affine in position): exact wherever the Delaunay diagonal is unique
-        if speckled:   # validity depends on which triangle covers a node
-            np.testing.assert_array_equal(r[1][~amb], golden[tag + '/out_valid'][~amb], err_msg=tag)
-        else:
-            np.testing.assert_array_equal(r[1], golden[tag + '/out_valid'], err_msg=tag)
-        frac = assert_close_outside_ambiguous(r[0], golden[tag + '/out'], amb, tag, covered=r[1])
-        assert frac < (0.03 if 'wobble' in tag else 0.6), tag    # exact similarities: most cells are co-circular
+        # random image content (not affine in position): exact wherever the triangulation is unique
+        sel = ~amb if speckled else np.ones(amb.shape, bool)
+        np.testing.assert_array_equal(r[1][sel], golden[tag + '/out_valid'][sel], err_msg=tag)
+        assert_close_outside_ambiguous(r[0], golden[tag + '/out'], amb, tag)
     elif r.dtype == bool:
-        if speckled:
-            np.testing.assert_array_equal(r[~amb], golden[tag + '/out'][~amb], err_msg=tag)
-        else:
-            np.testing.assert_array_equal(r, golden[tag + '/out'], err_msg=tag)
+        sel = ~amb if speckled else np.ones(amb.shape, bool)
+        np.testing.assert_array_equal(r[sel], golden[tag + '/out'][sel], err_msg=tag)
     else:   # uint8 image: a value that lands within 1e-6 of x.5 may round the other way
-        cov = of.Flow(golden[tag + '/in_vecs'], 's').valid_target()
-        amb |= cov & ~ndimage.binary_erosion(cov, iterations=2)      # border gap nodes, see above
         d = np.abs(r.astype(int) - golden[tag + '/out'].astype(int)).max(-1)
         assert (d[~amb] <= 1).all() and (d[~amb] > 0).mean() < 1e-3, tag
 
@@ -141,28 +141,16 @@ def test_reference_outputs_without_holes(gpu, golden):
 
 
 def test_reference_outputs_with_holes(gpu, golden):
-    """Point sets with dropped points (consider_mask=True and a mask with holes / speckle): SciPy
-    re-triangulates the gaps; the kernel continues the nearest cell triangle into them.  Masks are the
-    same (inside the convex hull of the kept points), and so are the values wherever the data is affine
-    across the gap -- true for every flow-valued case here; image-valued cases differ inside the gaps."""
+    """Point sets with dropped points (consider_mask=True and a mask with holes / speckle): SciPy triangulates
+    across the gaps, and so does the Delaunay path.  Masks bit-exact; flow-valued AND image-valued results agree
+    wherever SciPy's triangulation is unique."""
     of = gpu
     n = 0
     for tag in golden_tags(golden):
-        if not has_holes(golden, tag) or tag.startswith('apply_u8'):
+        if not has_holes(golden, tag):
             continue
         n += 1
-        r = run_product(of, golden, tag)
-        if isinstance(r, of.Flow):
-            np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
-            m = r.mask
-            np.testing.assert_allclose(r.vecs[m], golden[tag + '/out_vecs'][m], rtol=RTOL, atol=1e-4, err_msg=tag)
-        elif isinstance(r, tuple):
-            np.testing.assert_array_equal(r[1], golden[tag + '/out_valid'], err_msg=tag)
-            keep = golden[tag + '/in_mask']
-            bad = ~np.isclose(r[0], golden[tag + '/out'], rtol=RTOL, atol=ATOL).all(-1)
-            assert bad.mean() < 0.45, tag           # random image content: gap nodes are interpolated differently
-        else:
-            np.testing.assert_array_equal(r, golden[tag + '/out'], err_msg=tag)
+        check_case(of, golden, tag)
     assert n >= 10
 
 
@@ -232,8 +220,11 @@ def test_combine_modes_vs_oracle(gpu, oracle, ref):
         got = a.combine_with(b, mode)
         want = oracle.OFlow(a.vecs, ref, a.mask).combine_with(oracle.OFlow(b.vecs, ref, b.mask), mode)
         both = got.mask & want.mask
-        # chained scatters inherit ragged (non-convex) masks: borders may differ by the hull fill
-        assert (got.mask ^ want.mask).mean() < 0.02
+        diff = got.mask ^ want.mask
+        print("mode", mode, ref, "mask mismatches", int(diff.sum()), "of", diff.size, np.argwhere(diff)[:8].tolist())
+        # mode 2 / ref 't' goes through the query-position entry (owner map of the cell-wise mesh): a node on the
+        # 0.99 threshold of the interpolated mask may fall the other way; every other combination is exact
+        assert diff.sum() <= (2 if (mode, ref) == (2, 't') else 0), (mode, ref, int(diff.sum()))
         assert both.sum() > 0.5 * want.mask.sum()
         np.testing.assert_allclose(got.vecs[both], want.vecs[both], rtol=1e-3, atol=2e-4)
 
@@ -255,18 +246,12 @@ def test_scatter_raw_abi(gpu, oracle):
     nat.check(lib.ofl_scatter_linear(p(flow), 1, 0, None, p(vals), C, None, H, W, None, p(out), p(valid), 0))
     want = oracle.scatter_griddata(flow, vals, None)
     hull = oracle.scatter_griddata(flow, np.ones((H, W), 'f'), None) == 1
-    # a non-affine flow bends the border of the warped grid: SciPy fills the slivers between the mesh and
-    # its convex hull with long boundary triangles; the kernel continues the nearest cell triangle there
-    # (same coverage, values differ in those few border nodes only)
+    # a non-affine flow bends the border of the warped grid: the pockets between the mesh and its convex hull are
+    # triangulated like SciPy triangulates them -- every node agrees
     v = valid.astype(bool)
     np.testing.assert_array_equal(v, hull)
-    assert not ambiguous_nodes(flow).any()
-    bad = ~np.isclose(out, want, rtol=RTOL, atol=ATOL).all(-1)
-    assert bad.mean() < 0.02
-    interior = np.zeros_like(bad)
-    from scipy import ndimage
-    interior = ndimage.binary_erosion(hull, iterations=2)
-    assert not (bad & interior).any()
+    assert not ambiguous_for(flow).any()
+    np.testing.assert_allclose(out, want, rtol=RTOL, atol=ATOL)
     none = np.zeros((H, W), np.uint8)
     rc = lib.ofl_scatter_linear(p(flow), 1, 0, p(none), p(vals), C, None, H, W, None, p(out), p(valid), 0)
     assert rc == nat.E_NOPOINTS
@@ -361,56 +346,39 @@ def test_apply_with_padding_both_refs(gpu, oracle):
                     np.testing.assert_array_equal(gw, ow)
                     np.testing.assert_array_equal(gv, ov)
                 else:
-                    from scipy import ndimage
-                    core = ndimage.binary_erosion(ov, iterations=2)       # gap nodes next to the curved mesh border differ
-                    if tm is None:
-                        np.testing.assert_array_equal(gv, ov)
-                    else:       # a speckled mask channel: validity depends on the covering triangle only at mask edges
-                        assert (gv ^ ov).mean() < 0.02
-                    np.testing.assert_allclose(gw[core], ow[core], rtol=RTOL, atol=ATOL)
+                    np.testing.assert_array_equal(gv, ov)
+                    np.testing.assert_allclose(gw, ow, rtol=RTOL, atol=ATOL)
         g2 = f.apply(img, padding=pad)
         o2 = o.apply(img, padding=pad)
         if ref == 't':
             np.testing.assert_array_equal(g2, o2)
         else:
-            assert np.isclose(g2, o2, rtol=RTOL, atol=ATOL).mean() > 0.97
+            np.testing.assert_allclose(g2, o2, rtol=RTOL, atol=ATOL)
 
 
 def test_discontinuous_fields_vs_reference(gpu, golden):
-    """Motion boundaries (a block moving over a static background; outputs of the real reference): the cells
-    along the boundary stretch or fold, where the global Delaunay triangulation of SciPy and the cell-wise
-    triangulation of the kernel legitimately differ (deviation c).  Away from a band around the
-    block outline -- both where it starts and where it lands -- results must agree; the band's share is bounded."""
-    from scipy import ndimage
+    """Motion boundaries (a block moving over a static background; outputs of the real reference): the cells along
+    the boundary stretch or fold.  The Delaunay path triangulates the points globally like SciPy: masks bit-exact
+    and values equal wherever SciPy's triangulation is unique.  (The static background is an exact lattice -- every
+    cell co-circular -- so for image values these two fixtures leave little to compare; the generic-background case
+    of test_gpu_scatter_exact.py::test_exact_path_matches_reference_outputs[block_generic] has no such cells.)"""
     from test_oracle import disc_tags
     of = gpu
     for tag in disc_tags(golden):
         op, name = tag.split('/')
         vecs = golden[tag + '/in_vecs']
         f = of.Flow(vecs, 's', golden[tag + '/in_mask'])
-        moving = (vecs != 0).any(-1)
-        du, dv = vecs[moving][0]
-        landed = ndimage.shift(moving.astype(float), (dv, du), order=1) > 0
-        outline = (ndimage.binary_dilation(moving, iterations=2) & ~ndimage.binary_erosion(moving, iterations=2)) | \
-                  (ndimage.binary_dilation(landed, iterations=2) & ~ndimage.binary_erosion(landed, iterations=2))
-        # the disoccluded / doubly covered strip between the two outlines also belongs to the boundary region
-        band = ndimage.binary_dilation(outline | (moving ^ landed), iterations=1)
-        assert band.mean() < 0.45, tag
+        amb = ambiguous_for(vecs)
         if op == 'disc_apply':
             w, v = f.apply(golden['disc/' + name + '/img'], return_valid_area=True)
-            np.testing.assert_array_equal(v[~band], golden[tag + '/out_valid'][~band], err_msg=tag)
-            sel = ~band
-            if du != round(du) or dv != round(dv):
-                # a rigidly shifted block keeps square (co-circular) cells: both diagonals are Delaunay and random
-                # image content tells them apart (deviation a) -- values are compared on the background only
-                sel &= ~ndimage.binary_dilation(landed, iterations=1)
-            np.testing.assert_allclose(w[sel], golden[tag + '/out'][sel], rtol=RTOL, atol=ATOL, err_msg=tag)
+            np.testing.assert_array_equal(v, golden[tag + '/out_valid'], err_msg=tag)
+            np.testing.assert_allclose(w[~amb], golden[tag + '/out'][~amb], rtol=RTOL, atol=ATOL, err_msg=tag)
         elif op == 'disc_invert':
             r = f.invert()
-            np.testing.assert_array_equal(r.mask[~band], golden[tag + '/out_mask'][~band], err_msg=tag)
-            np.testing.assert_allclose(r.vecs[~band], golden[tag + '/out_vecs'][~band], rtol=RTOL, atol=1e-5, err_msg=tag)
+            np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
+            np.testing.assert_allclose(r.vecs[~amb], golden[tag + '/out_vecs'][~amb], rtol=RTOL, atol=1e-5, err_msg=tag)
         else:
-            np.testing.assert_array_equal(f.valid_target()[~band], golden[tag + '/out'][~band], err_msg=tag)
+            np.testing.assert_array_equal(f.valid_target(), golden[tag + '/out'], err_msg=tag)
 
 
 def test_apply_entry_points_agree_both_refs(gpu):
@@ -519,7 +487,7 @@ def test_speckled_mask_with_dropped_corners(gpu, oracle):
     t0 = time.perf_counter()
     r = d.invert()
     of.native.check(of.native.load().ofl_device_sync())
-    assert time.perf_counter() - t0 < 0.02, "hull candidates were not filtered on the device"
+    assert time.perf_counter() - t0 < 0.2, "the Delaunay path fell off the device"
     assert r.to_host()[1].mean() > 0.5
 
 
@@ -620,9 +588,9 @@ def test_randomised_masks_against_scipy(gpu, oracle):
 
 
 def test_large_hole_in_point_mask_matches_scipy(gpu, oracle):
-    """A hole of the point mask much wider than the ring search (70 x 100 px in 160 x 220): SciPy bridges it with long
-    triangles and reports the bridged nodes valid; the kernel finds the nearest covered node of the deep nodes by jump
-    flooding and continues its triangle.  Masks are bit-exact; an affine field is reproduced across the hole; row bands
+    """A hole of the point mask much wider than any ring search (70 x 100 px in 160 x 220): SciPy bridges it with long
+    triangles and reports the bridged nodes valid; the Delaunay path builds the same triangles (the rim points finish
+    in the wave / workgroup star passes).  Masks are bit-exact; an affine field is reproduced across the hole; row bands
     still concatenate to the full result."""
     of, O = gpu, oracle
     from oflibnumpy_amd import device as dev, sharding
@@ -680,16 +648,10 @@ def test_float64_targets_keep_their_precision(gpu, oracle):
     np.testing.assert_array_equal(valid, v32)
     np.testing.assert_array_equal(v32, O.OFlow(vecs, 's').apply(img.astype(np.float32), return_valid_area=True)[1])
     assert not (wvalid & ~valid).any() and (valid & ~wvalid).mean() < 0.08
-    inner = ndimage_erode(valid, 2)
-    np.testing.assert_allclose(got[inner], want[inner], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(got[valid], want[valid], rtol=1e-11, atol=1e-9)
     got32 = f.apply(img.astype(np.float32))
     assert got32.dtype == np.float32
-    np.testing.assert_allclose(got32[inner], want[inner], rtol=2e-6, atol=1e-4)
-
-
-def ndimage_erode(mask, it):
-    from scipy import ndimage
-    return ndimage.binary_erosion(mask, iterations=it)
+    np.testing.assert_allclose(got32[valid], want[valid], rtol=2e-6, atol=1e-4)
 
 
 def test_integer_targets_valid_area_s(gpu, oracle):
@@ -723,11 +685,11 @@ def test_integer_targets_valid_area_s(gpu, oracle):
         w_flt = o.apply(img.astype(np.float32), tm, return_valid_area=True)[1]
         assert w_int.sum() > w_flt.sum() + 20
         assert abs(int(v_int.sum()) - int(w_int.sum())) < 0.25 * (w_int.sum() - w_flt.sum())
-        # values (all points kept: dropped points leave gaps that random image content fills differently, deviation b)
+        # values with all points kept
         got, valid = of.Flow(vecs, 's').apply(img, tm, return_valid_area=True)
         want, wvalid = O.OFlow(vecs, 's').apply(img, tm, return_valid_area=True)
         sel = ~ndimage.binary_dilation(edge, iterations=4)
         np.testing.assert_array_equal(valid[sel], wvalid[sel])
-        inner = ndimage_erode(of.Flow(vecs, 's').valid_target(), 2)
+        inner = of.Flow(vecs, 's').valid_target()
         d = np.abs(got.astype(int) - want.astype(int)).max(-1)
         assert (d[inner] <= 1).all() and (d[inner] > 0).mean() < 0.02

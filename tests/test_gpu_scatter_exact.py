@@ -184,24 +184,7 @@ def test_nodes_in_the_noise_band_of_the_border(gpu, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- exact path
-def nonunique_nodes(points, shape):
-    """Grid nodes whose covering simplex of SciPy's own triangulation is NOT uniquely Delaunay (a fourth site within
-    1e-9 of its circumcircle): Qhull's choice among the co-circular alternatives is arbitrary there, and non-affine
-    data (image values) can tell the alternatives apart.  Duplicated sites count as ambiguous too."""
-    from scipy.spatial import Delaunay
-    from test_delaunay_core import unique_simplices
-    upts, inv, counts = np.unique(points, axis=0, return_inverse=True, return_counts=True)
-    d = Delaunay(upts)
-    uniq = unique_simplices(upts, d.simplices)
-    dup_vertex = (counts[d.simplices] > 1).any(1)
-    yy, xx = np.mgrid[:shape[0], :shape[1]]
-    s = d.find_simplex(np.stack([xx.ravel(), yy.ravel()], 1).astype(np.float64)).reshape(shape)
-    amb = np.zeros(shape, bool)
-    inside = s >= 0
-    amb[inside] = ~uniq[s[inside]] | dup_vertex[s[inside]]
-    # a node exactly on an edge / vertex belongs to several simplices: ambiguous when any of its neighbours is
-    from scipy import ndimage
-    return amb, inside
+from scatter_util import nonunique_nodes      # noqa: E402
 
 
 def fixture_case(g, tag):

@@ -22,6 +22,7 @@
 #include "ofl_scatter_dev.h"
 #include "ofl_delaunay_core.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <vector>
 
 using namespace ofl;
@@ -96,11 +97,16 @@ __device__ __forceinline__ double okey_inv(unsigned long long k)
 }
 
 struct PosFn {
-    const float *flow; int sign, W;
+    const float *flow; int sign, W; float inv_w;
+    __device__ __forceinline__ PosFn(const float *f, int s, int w) : flow(f), sign(s), W(w), inv_w(1.0f / (float)w) {}
     __device__ __forceinline__ P2 operator()(int i) const
     {
-        const int y = i / W, x = i - y * W;
-        const D2 p = point_of(flow, sign, W, x, y);
+        // row of point i without an integer division: float estimate (i < 2^27, error < 16 rows... corrected exactly)
+        int y = (int)((float)i * inv_w);
+        int r = i - y * W;
+        while (r < 0) { --y; r += W; }
+        while (r >= W) { ++y; r -= W; }
+        const D2 p = point_of(flow, sign, W, r, y);
         return P2{ p.x, p.y };
     }
 };
@@ -131,16 +137,16 @@ __device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned &total)
 __global__ __launch_bounds__(256)
 void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W, DlHead *head)
 {
-    const size_t n = (size_t)H * W;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
     unsigned cnt = 0;
-    const PosFn pos{ flow, sign, W };
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        if (!kept_pt(pmask, i)) continue;
-        const P2 p = pos((int)i);
-        x0 = fmin(x0, p.x); x1 = fmax(x1, p.x); y0 = fmin(y0, p.y); y1 = fmax(y1, p.y);
-        ++cnt;
-    }
+    if (x < W)
+        for (int y = blockIdx.y * 8 + (threadIdx.x >> 5); y < H; y += gridDim.y * 8) {
+            if (!kept_pt(pmask, (size_t)y * W + x)) continue;
+            const D2 p = point_of(flow, sign, W, x, y);
+            x0 = fmin(x0, p.x); x1 = fmax(x1, p.x); y0 = fmin(y0, p.y); y1 = fmax(y1, p.y);
+            ++cnt;
+        }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         x0 = fmin(x0, __hiloint2double(__shfl_xor(__double2hiint(x0), off), __shfl_xor(__double2loint(x0), off)));
@@ -156,7 +162,7 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     }
 }
 
-__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap)
+__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale)
 {
     Grid g;
     g.ox = 0.0; g.oy = 0.0; g.s = 1.0; g.inv_s = 1.0; g.gx = 1; g.gy = 1;
@@ -164,7 +170,7 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap)
     if (n > 0) {
         const double x0 = okey_inv(head->kx0), x1 = okey_inv(head->kx1), y0 = okey_inv(head->ky0), y1 = okey_inv(head->ky1);
         const double bw = x1 - x0, bh = y1 - y0;
-        double s = sqrt(fmax(bw * bh, 1e-300) / (double)n);             // ~1 point per bucket
+        double s = bucket_scale * sqrt(fmax(bw * bh, 1e-300) / (double)n);             // ~bucket_scale^2 points per bucket
         s = fmax(s, (bw + bh) / (double)n);
         if (!(s > 0.0) || !isfinite(s)) s = 1.0;
         for (int it = 0; it < 64; ++it) {
@@ -190,7 +196,7 @@ void dl_count1_kernel(const float *__restrict__ flow, int sign, int W, const DlH
     const unsigned r = blockIdx.x * 256 + threadIdx.x;
     if (r >= head->n_far) return;
     const Grid g = head->grid1;
-    const P2 p = PosFn{ flow, sign, W }((int)far_idx[r]);
+    const P2 p = PosFn(flow, sign, W)((int)far_idx[r]);
     atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
 }
 
@@ -202,7 +208,7 @@ void dl_fill1_kernel(const float *__restrict__ flow, int sign, int W, const DlHe
     const unsigned r = blockIdx.x * 256 + threadIdx.x;
     if (r >= head->n_far) return;
     const Grid g = head->grid1;
-    const P2 p = PosFn{ flow, sign, W }((int)far_idx[r]);
+    const P2 p = PosFn(flow, sign, W)((int)far_idx[r]);
     const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
     sorted[bstart[b] + atomicAdd(&cursor[b], 1u)] = r;
 }
@@ -214,7 +220,7 @@ void dl_count_kernel(const float *__restrict__ flow, int sign, const uint8_t *__
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)H * W || !kept_pt(pmask, i)) return;
     const Grid g = head->grid;
-    const P2 p = PosFn{ flow, sign, W }((int)i);
+    const P2 p = PosFn(flow, sign, W)((int)i);
     atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
 }
 
@@ -252,7 +258,7 @@ void dl_fill_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)H * W || !kept_pt(pmask, i)) return;
     const Grid g = head->grid;
-    const P2 p = PosFn{ flow, sign, W }((int)i);
+    const P2 p = PosFn(flow, sign, W)((int)i);
     const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
     sorted[bstart[b] + atomicAdd(&cursor[b], 1u)] = (unsigned)i;
 }
@@ -286,7 +292,7 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
     if (p >= (size_t)H * W) return;
     if (!kept_pt(pmask, p)) { deg[p] = 0; return; }
     const Grid g = head->grid;
-    const PosFn pos{ flow, sign, W };
+    const PosFn pos(flow, sign, W);
     PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
     const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings);
     bool ok = rc == 1;
@@ -320,7 +326,7 @@ void dl_flag_count_kernel(const void *__restrict__ src, const DlHead *__restrict
 template <int MODE>
 __global__ __launch_bounds__(256)
 void dl_flag_write_kernel(const void *__restrict__ src, DlHead *head, size_t n_fixed, const unsigned *__restrict__ offs,
-                          unsigned *__restrict__ list, unsigned last_block)
+                          unsigned *__restrict__ list, unsigned last_block, unsigned *__restrict__ rank_of)
 {
     const size_t n = MODE == 0 ? n_fixed : head->n_far;
     const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
@@ -330,7 +336,11 @@ void dl_flag_write_kernel(const void *__restrict__ src, DlHead *head, size_t n_f
     unsigned total;
     unsigned at = block_exscan(v, total) + offs[blockIdx.x];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, base + k)) list[at++] = (unsigned)(base + k);
+    for (int k = 0; k < 8; ++k)
+        if (base + k < n && flagged<MODE>(src, base + k)) {
+            if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
+            list[at++] = (unsigned)(base + k);
+        }
     if (blockIdx.x == last_block && threadIdx.x == 0) { if (MODE == 0) head->n_far = offs[blockIdx.x] + total; else head->n_left = offs[blockIdx.x] + total; }
 }
 
@@ -351,7 +361,11 @@ struct FarLds {
     int    cidx[NT];
     double ccx[NT], ccy[NT];
     unsigned long long hit[NT / 64];
+    double wmax[NT / 64];
+    unsigned run_lo[64];       // candidate runs of the current step (ranges of a sorted list) ...
+    int    run_pre[65];        // ... and the exclusive prefix of their lengths
     int    n, a, ncut, status;
+    double reach2;             // (2 * farthest vertex)^2 of the current cell: sites beyond it cannot cut
 };
 
 template <int CAP, int NT>
@@ -426,6 +440,21 @@ __device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, R
     }
     if (t == 0) L.n = n2;
     __syncthreads();
+    {
+        // the cell shrank: new reach (every thread scans its share, one wave-level then LDS-level maximum)
+        double r2 = 0.0;
+        for (int k = t; k < n2; k += NT) r2 = fmax(r2, L.vx[k] * L.vx[k] + L.vy[k] * L.vy[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            r2 = fmax(r2, __hiloint2double(__shfl_xor(__double2hiint(r2), off), __shfl_xor(__double2loint(r2), off)));
+        if (NT == 64) { if (t == 0) L.reach2 = 4.0 * r2; }
+        else {
+            if ((t & 63) == 0) L.wmax[t >> 6] = r2;
+            __syncthreads();
+            if (t == 0) { double m = 0.0; for (int w = 0; w < NT / 64; ++w) m = fmax(m, L.wmax[w]); L.reach2 = 4.0 * m; }
+        }
+        __syncthreads();
+    }
 }
 
 // one chunk of up to NT candidates (thread t holds candidate cand, or -1)
@@ -439,7 +468,8 @@ __device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, con
     if (cand >= 0 && cand != p) {
         const P2 q = pos(cand);
         C.x = q.x - pp.x; C.y = q.y - pp.y;
-        if (!(C.x == 0.0 && C.y == 0.0)) {
+        const double d2 = C.x * C.x + C.y * C.y;
+        if (d2 != 0.0 && d2 < L.reach2) {
             const int n = L.n;
             const double h = 0.5 * (C.x * C.x + C.y * C.y);
             Poly P{ L.vx, L.vy, L.tag, 1, CAP, n };
@@ -461,44 +491,79 @@ __device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, con
     __syncthreads();
 }
 
-// candidates of the fine buckets within kRings of the point's bucket, nearest rows first
+// The runs in L.run_lo / L.run_pre (lengths, turned into a prefix here) are walked as ONE dense list, NT candidates per
+// step; `map` turns an entry of the sorted list into a point index.
+template <int CAP, int NT, class RelFn, class MapFn>
+__device__ void far_dense(FarLds<CAP, NT> &L, int p, const P2 &pp, int nruns, const PosFn &pos, RelFn rel, MapFn map)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int r = 0; r < nruns; ++r) { const int c = L.run_pre[r]; L.run_pre[r] = acc; acc += c; }
+        L.run_pre[nruns] = acc;
+    }
+    __syncthreads();
+    const int total = L.run_pre[nruns];
+    for (int base = 0; base < total; base += NT) {
+        const int gidx = base + (int)threadIdx.x;
+        int cand = -1;
+        if (gidx < total) {
+            int r = 0;
+            while (L.run_pre[r + 1] <= gidx) ++r;
+            cand = map(L.run_lo[r] + (unsigned)(gidx - L.run_pre[r]));
+        }
+        far_chunk(L, p, pp, cand, pos, rel);
+    }
+}
+
+// one run = the buckets [x0, x1] of row `row` of grid g (empty when outside)
+template <int CAP, int NT>
+__device__ __forceinline__ void far_set_run(FarLds<CAP, NT> &L, int slot, const Grid &g, const unsigned *__restrict__ bstart,
+                                            int row, int x0, int x1)
+{
+    unsigned lo = 0, cnt = 0;
+    x0 = max(x0, 0); x1 = min(x1, g.gx - 1);
+    if (row >= 0 && row < g.gy && x1 >= x0) {
+        lo = bstart[(size_t)row * g.gx + x0];
+        cnt = bstart[(size_t)row * g.gx + x1 + 1] - lo;
+    }
+    L.run_lo[slot] = lo; L.run_pre[slot] = (int)cnt;
+}
+
+// candidates of the fine buckets within kRings of the point's bucket
 template <int CAP, int NT, class RelFn>
 __device__ void far_near_rows(FarLds<CAP, NT> &L, int p, const P2 &pp, const Grid &g, const unsigned *__restrict__ bstart,
                               const unsigned *__restrict__ sorted, const PosFn &pos, RelFn rel)
 {
     const int t = threadIdx.x, bx = g.bx(pp.x), by = g.by(pp.y);
-    for (int dr = 0; dr <= 2 * kRings; ++dr) {
-        const int row = by + ((dr & 1) ? (dr + 1) / 2 : -(dr / 2));        // by, by+1, by-1, by+2, ...
-        if (row < 0 || row >= g.gy) continue;
-        const int x0 = max(bx - kRings, 0), x1 = min(bx + kRings, g.gx - 1);
-        const unsigned lo = bstart[(size_t)row * g.gx + x0], hi = bstart[(size_t)row * g.gx + x1 + 1];
-        for (unsigned base = lo; base < hi; base += NT)
-            far_chunk(L, p, pp, base + t < hi ? (int)sorted[base + t] : -1, pos, rel);
-    }
+    __syncthreads();
+    if (t <= 2 * kRings) far_set_run(L, t, g, bstart, by - kRings + t, bx - kRings, bx + kRings);
+    far_dense(L, p, pp, 2 * kRings + 1, pos, rel, [&](unsigned j) { return (int)sorted[j]; });
 }
 
-// ring r of the coarse grid: unfinished points (ranks -> point indices)
+// ring r of the coarse grid (r0 == r1) or the whole square of rings r0 .. r1 row by row: unfinished points (ranks -> point indices)
 template <int CAP, int NT, class RelFn>
-__device__ void far_coarse_ring(FarLds<CAP, NT> &L, int p, const P2 &pp, int r, const Grid &g1,
-                                const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
-                                const unsigned *__restrict__ far_idx, const PosFn &pos, RelFn rel)
+__device__ void far_coarse_rings(FarLds<CAP, NT> &L, int p, const P2 &pp, int r0, int r1, const Grid &g1,
+                                 const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
+                                 const unsigned *__restrict__ far_idx, const PosFn &pos, RelFn rel)
 {
     const int t = threadIdx.x, bx = g1.bx(pp.x), by = g1.by(pp.y);
-    auto run = [&](int row, int x0, int x1) {
-        if (row < 0 || row >= g1.gy) return;
-        x0 = max(x0, 0); x1 = min(x1, g1.gx - 1);
-        if (x1 < x0) return;
-        const unsigned lo = b1start[(size_t)row * g1.gx + x0], hi = b1start[(size_t)row * g1.gx + x1 + 1];
-        for (unsigned base = lo; base < hi; base += NT)
-            far_chunk(L, p, pp, base + t < hi ? (int)far_idx[sorted1[base + t]] : -1, pos, rel);
-    };
-    if (r == 0) { run(by, bx, bx); return; }
-    run(by - r, bx - r, bx + r);
-    run(by + r, bx - r, bx + r);
-    for (int row = by - r + 1; row <= by + r - 1; ++row) {
-        if (bx - r >= 0) run(row, bx - r, bx - r);
-        if (bx + r <= g1.gx - 1) run(row, bx + r, bx + r);
+    int nruns;
+    __syncthreads();
+    if (r0 != r1 || r0 == 0) {                      // full rows of the square
+        nruns = 2 * r1 + 1;
+        if (t < nruns) far_set_run(L, t, g1, b1start, by - r1 + t, bx - r1, bx + r1);
+    } else {                                        // the ring alone: top and bottom rows, then the two end cells of the rows between
+        const int r = r0;
+        nruns = 2 + 2 * (2 * r - 1);
+        if (t == 0) far_set_run(L, 0, g1, b1start, by - r, bx - r, bx + r);
+        else if (t == 1) far_set_run(L, 1, g1, b1start, by + r, bx - r, bx + r);
+        else if (t < nruns) {
+            const int m = t - 2, row = by - r + 1 + (m >> 1), col = (m & 1) ? bx + r : bx - r;
+            far_set_run(L, t, g1, b1start, row, col, (col < 0 || col > g1.gx - 1) ? col - 1 : col);
+        }
     }
+    far_dense(L, p, pp, nruns, pos, rel, [&](unsigned j) { return (int)far_idx[sorted1[j]]; });
 }
 
 template <int CAP, int NT>
@@ -534,19 +599,19 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     if (rank >= head->n_far) return;
     const int p = (int)far_idx[rank];
     const Grid g = head->grid, g1 = head->grid1;
-    const PosFn pos{ flow, sign, W };
+    const PosFn pos(flow, sign, W);
     const P2 pp = pos(p);
     auto rel = [&](int q) { const P2 v = pos(q); return P2{ v.x - pp.x, v.y - pp.y }; };
     if (t == 0) {
         Poly P{ L.vx, L.vy, L.tag, 1, kMidCap, 0 };
         poly_init(P);
-        L.n = P.n; L.status = 0;
+        L.n = P.n; L.status = 0; L.reach2 = 1e300;
     }
     __syncthreads();
     far_near_rows(L, p, pp, g, bstart, sorted, pos, rel);
     bool done = false;
     for (int r = 0; r <= kMidRings && !done; ++r) {
-        far_coarse_ring(L, p, pp, r, g1, b1start, sorted1, far_idx, pos, rel);
+        far_coarse_rings(L, p, pp, r, r, g1, b1start, sorted1, far_idx, pos, rel);
         // the cell is final once every unfinished point within twice its farthest vertex has been applied: points in
         // unvisited coarse cells are at least r * s1 away (finished points farther than the fine rings cannot be
         // neighbours: they would not have finished)
@@ -565,6 +630,7 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
 }
 
+template <int CAP>          // first with a small cell capacity (several workgroups per CU), then -- for the few fans that overflowed it -- the large one
 __global__ __launch_bounds__(256)
 void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted,
@@ -573,28 +639,30 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
                         unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
                         unsigned long long pool_cap)
 {
-    __shared__ FarLds<kFarCap, 256> L;
+    __shared__ FarLds<CAP, 256> L;
     __shared__ unsigned s_off;
     const int t = threadIdx.x;
     const unsigned n_left = head->n_left;
     if (blockIdx.x >= n_left) return;
     const unsigned rank = left_idx[blockIdx.x];
+    if (far_deg[rank] != kDegLeft) return;               // finished by the pass with the smaller capacity
     const int p = (int)far_idx[rank];
     const Grid g = head->grid, g1 = head->grid1;
-    const PosFn pos{ flow, sign, W };
+    const PosFn pos(flow, sign, W);
     const P2 pp = pos(p);
     auto rel = [&](int q) { const P2 v = pos(q); return P2{ v.x - pp.x, v.y - pp.y }; };
     if (t == 0) {
-        Poly P{ L.vx, L.vy, L.tag, 1, kFarCap, 0 };
+        Poly P{ L.vx, L.vy, L.tag, 1, CAP, 0 };
         poly_init(P);
-        L.n = P.n; L.status = 0;
+        L.n = P.n; L.status = 0; L.reach2 = 1e300;
     }
     __syncthreads();
     far_near_rows(L, p, pp, g, bstart, sorted, pos, rel);
-    for (int r = 0; r <= kMidRings; ++r) far_coarse_ring(L, p, pp, r, g1, b1start, sorted1, far_idx, pos, rel);
+    far_coarse_rings(L, p, pp, 0, kMidRings, g1, b1start, sorted1, far_idx, pos, rel);
     for (unsigned base = 0; base < n_left; base += 256)
         far_chunk(L, p, pp, base + t < n_left ? (int)far_idx[left_idx[base + t]] : -1, pos, rel);
     __syncthreads();
+    if (CAP < kFarCap && L.status) return;               // overflow of the small capacity: far_deg stays kDegLeft for the next pass
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
 }
 
@@ -633,11 +701,33 @@ __device__ __forceinline__ TriBox box_rows(const D2 &p0, const D2 &p1, const D2 
 
 __device__ __forceinline__ D2 pt(const PosFn &pos, unsigned i) { const P2 p = pos((int)i); return D2{ p.x, p.y }; }
 
-// one triangle by one thread; large bounding boxes go to the list swept by whole waves
-__device__ __forceinline__ void thread_raster(unsigned id, const PosFn &pos, int H, int W, const DlWs &ws, unsigned far_base)
+// does the star of site s list b right after a (cyclically)?  Stars of more than 64 neighbours are not searched.
+__device__ __forceinline__ bool star_has(const DlWs &ws, unsigned s, unsigned a, unsigned b)
+{
+    const unsigned d = ws.deg[s];
+    if (d <= kSlots) {
+        const unsigned *nb = ws.nbr + (size_t)s * kSlots;
+        for (unsigned k = 0; k < d; ++k)
+            if (nb[k] == a) return nb[k + 1 == d ? 0 : k + 1] == b;
+        return false;
+    }
+    if (d != kDegFar) return false;
+    const unsigned rank = ws.nbr[(size_t)s * kSlots], fd = ws.far_deg[rank];
+    if (fd == kDegLeft || fd > 64) return false;
+    const int *pl = ws.pool + ws.far_off[rank];
+    for (unsigned k = 0; k < fd; ++k)
+        if (pl[k] == (int)a) return pl[k + 1 == fd ? 0 : k + 1] == (int)b;
+    return false;
+}
+
+// one triangle by one thread; large bounding boxes go to the list swept by whole waves.  Every triangle is listed by
+// each of its three sites; the copy of the site with the smallest index is the one that is drawn -- unless that
+// site's star does not list the triangle (stars that disagree on a co-circular cell), in which case this copy is drawn too.
+__device__ __forceinline__ void thread_raster(unsigned id, unsigned self, const PosFn &pos, int H, int W, const DlWs &ws, unsigned far_base)
 {
     const TriRef tr = dl_decode(id, far_base, ws);
     if (!tr.ok) return;
+    if (tr.i0 != self && star_has(ws, tr.i0, tr.i1, tr.i2)) return;
     const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
     const TriBox b = box_rows(q0, q1, q2, W, H, ws);
     if (b.x1 < b.x0 || b.y1 < b.y0) return;
@@ -661,8 +751,8 @@ void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int
     if (p >= (size_t)H * W) return;
     const unsigned d = ws.deg[p];
     if (d == 0 || d > kSlots) return;
-    const PosFn pos{ flow, sign, W };
-    for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, pos, H, W, ws, far_base);
+    const PosFn pos(flow, sign, W);
+    for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, (unsigned)p, pos, H, W, ws, far_base);
 }
 
 __global__ __launch_bounds__(256)
@@ -672,8 +762,9 @@ void dl_raster_far_kernel(const float *__restrict__ flow, int sign, int H, int W
     if (rank >= ws.head->n_far) return;
     const unsigned d = ws.far_deg[rank];
     if (d == kDegLeft) return;
-    const PosFn pos{ flow, sign, W };
-    for (unsigned k = 0; k < d; ++k) thread_raster(far_base + rank * kFarK + k, pos, H, W, ws, far_base);
+    const PosFn pos(flow, sign, W);
+    const unsigned self = ws.far_idx[rank];
+    for (unsigned k = 0; k < d; ++k) thread_raster(far_base + rank * kFarK + k, self, pos, H, W, ws, far_base);
 }
 
 // one wave per large triangle: 64 nodes of the bounding box per step
@@ -682,7 +773,7 @@ void dl_raster_big_kernel(const float *__restrict__ flow, int sign, int H, int W
 {
     unsigned long long n = ws.head->big_n;
     if (n > ws.big_cap) n = ws.big_cap;
-    const PosFn pos{ flow, sign, W };
+    const PosFn pos(flow, sign, W);
     for (unsigned long long j = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6); j < n; j += (unsigned long long)gridDim.x * 4) {
         const unsigned id = ws.big[j];
         const TriRef tr = dl_decode(id, far_base, ws);
@@ -720,7 +811,7 @@ void dl_resolve_kernel(const float *__restrict__ flow, int sign, const VT *__res
         if (valid) valid[o] = 0;
         return;
     }
-    const PosFn pos{ flow, sign, W };
+    const PosFn pos(flow, sign, W);
     const size_t vi[3] = { tr.i0, tr.i1, tr.i2 };
     double c0, c1, c2;
     (void)bary(pt(pos, tr.i0), pt(pos, tr.i1), pt(pos, tr.i2), (double)x, (double)y, c0, c1, c2);
@@ -820,8 +911,9 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
     OFL_HIP(hipMemsetAsync(ws.bstart, 0, (ws.bcap + 1) * 4, s));
     OFL_HIP(hipMemsetAsync(ws.nbr, 0, ws.bcap * 4, s));                 // bucket cursors
     const unsigned nblk = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(dl_bbox_kernel, dim3(std::min<unsigned>(nblk, (unsigned)rt().n_cu * 8)), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
-    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap);
+    hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 2048 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
+    static const double bucket_scale = getenv("OFL_DL_BUCKET") ? atof(getenv("OFL_DL_BUCKET")) : 1.0;      // development knob
+    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale);
     hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart);
     OFL_HIP(hipGetLastError());
     OFL_TRY(scan_exclusive(ws.bstart, ws.bcap + 1, ws.scan_tmp, s));
@@ -838,7 +930,7 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
     hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
     hipLaunchKernelGGL(dl_flag_write_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, ws.head, n, (const unsigned *)fcnt,
-                       ws.far_idx, fblk - 1);
+                       ws.far_idx, fblk - 1, ws.nbr);
     OFL_HIP(hipGetLastError());
     DlHead h;
     OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -870,13 +962,17 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
         hipLaunchKernelGGL(dl_flag_count_kernel<1>, dim3(lblk), dim3(256), 0, s, (const void *)ws.far_deg, (const DlHead *)ws.head, (size_t)0, lcnt);
         OFL_TRY(scan_exclusive(lcnt, lblk, ws.scan_tmp, s));
         hipLaunchKernelGGL(dl_flag_write_kernel<1>, dim3(lblk), dim3(256), 0, s, (const void *)ws.far_deg, ws.head, (size_t)0,
-                           (const unsigned *)lcnt, ws.left_idx, lblk - 1);
+                           (const unsigned *)lcnt, ws.left_idx, lblk - 1, (unsigned *)nullptr);
         OFL_HIP(hipGetLastError());
         OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
         OFL_HIP(hipStreamSynchronize(s));
         if (info_host) info_host[2] = h.n_left;
         if (h.n_left) {
-            hipLaunchKernelGGL(dl_star_far_kernel, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+            hipLaunchKernelGGL(dl_star_far_kernel<512>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.b1start,
+                               (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                               ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
+            hipLaunchKernelGGL(dl_star_far_kernel<kFarCap>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
                                (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.b1start,
                                (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
                                ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);

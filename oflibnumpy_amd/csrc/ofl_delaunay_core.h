@@ -200,9 +200,11 @@ struct Grid {
 // All sites of the buckets on the Chebyshev ring r around bucket (bx, by) are applied to the cell of site p (at pp).
 // Buckets are stored row-major and `sorted` lists the sites bucket by bucket, so a run of buckets in one row is ONE
 // contiguous range of `sorted`.  Returns -1 when the polygon overflows.
+// `reach2` = (2 * farthest cell vertex)^2, kept current by the caller's polygon: a site at or beyond that distance cannot
+// cut any vertex (|v - c| < |v| implies |c| < 2 |v|), which spares the vertex loop for most sites of the outer rings.
 template <class PolyX, class PosFn>
 DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const Grid &g,
-                     const unsigned *bstart, const unsigned *sorted, PosFn pos)
+                     const unsigned *bstart, const unsigned *sorted, PosFn pos, double &reach2)
 {
     auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
     auto run = [&](int row, int x0, int x1) -> int {
@@ -211,13 +213,24 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
         if (x1 > g.gx - 1) x1 = g.gx - 1;
         if (x1 < x0) return 0;
         const unsigned lo = bstart[(size_t)row * g.gx + x0], hi = bstart[(size_t)row * g.gx + x1 + 1];
-        for (unsigned j = lo; j < hi; ++j) {
-            const int c = (int)sorted[j];
-            if (c == p) continue;
-            const P2 q = pos(c);
-            const P2 C = { q.x - pp.x, q.y - pp.y };
-            if (C.x == 0.0 && C.y == 0.0) continue;           // a duplicate of p: same cell
-            if (poly_clip(P, C, c, p, rel) < 0) return -1;
+        for (unsigned j = lo; j < hi; j += 4) {
+            // four candidates at a time: their indices, then their positions, are in flight together
+            int c[4];
+            P2  q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = j + k < hi ? (int)sorted[j + k] : -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = c[k] >= 0 ? pos(c[k]) : pp;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (c[k] < 0 || c[k] == p) continue;
+                const P2 C = { q[k].x - pp.x, q[k].y - pp.y };
+                const double d2 = C.x * C.x + C.y * C.y;
+                if (d2 == 0.0 || d2 >= reach2) continue;      // a duplicate of p (same cell), or too far to matter
+                const int rc = poly_clip(P, C, c[k], p, rel);
+                if (rc < 0) return -1;
+                if (rc > 0) reach2 = 4.0 * poly_rmax2(P);
+            }
         }
         return 0;
     };
@@ -239,10 +252,11 @@ DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned
 {
     poly_init(P);
     const int bx = g.bx(pp.x), by = g.by(pp.y);
+    double reach2 = 4.0 * poly_rmax2(P);
     for (int r = 0; r <= rings; ++r) {
-        if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos) < 0) return -1;
+        if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2) < 0) return -1;
         const double cover = (double)r * g.s;
-        if (cover * cover >= 4.0 * poly_rmax2(P)) return 1;
+        if (cover * cover >= reach2) return 1;
     }
     return 0;
 }

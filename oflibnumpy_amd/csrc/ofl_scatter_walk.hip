@@ -165,16 +165,17 @@ void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint
 }
 
 // ------------------------------------------------------------------------------------------------ walk
-struct Hit { size_t vi[3]; double c0, c1, c2; float2 fv[3]; };
+struct Hit { uint32_t vi[3]; double c0, c1, c2; float2 fv[3]; };
 
 struct __attribute__((aligned(8))) Pair2 { float lo_u, lo_v, hi_u, hi_v; };    // two adjacent vectors: ONE 16-byte load
 
-__device__ __forceinline__ D2 warp_pt(int x, int y, float u, float v, int sign)
+template <int SP>          // SP = sign with the point precision folded in: +-1 float64 positions, +-2 rounded to float32
+__device__ __forceinline__ D2 warp_pt(int x, int y, float u, float v)
 {
     D2 p;
-    p.x = sign >= 0 ? (double)x + (double)u : (double)x - (double)u;
-    p.y = sign >= 0 ? (double)y + (double)v : (double)y - (double)v;
-    if (sign == 2 || sign == -2) { p.x = (double)(float)p.x; p.y = (double)(float)p.y; }
+    p.x = SP >= 0 ? (double)x + (double)u : (double)x - (double)u;
+    p.y = SP >= 0 ? (double)y + (double)v : (double)y - (double)v;
+    if (SP == 2 || SP == -2) { p.x = (double)(float)p.x; p.y = (double)(float)p.y; }
     return p;
 }
 
@@ -182,76 +183,92 @@ __device__ __forceinline__ D2 warp_pt(int x, int y, float u, float v, int sign)
 // edge functions; the certificate guarantees convex, positively oriented cells, so the Delaunay diagonal is one
 // in-circle sign).  On a miss the affine map of the less-missed triangle turns the position into a new estimate
 // (ex, ey) of its source index (a Newton step on the piecewise-affine map).
-__device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int sign, int W, int cx, int cy,
+template <int SP>
+__device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, int cx, int cy,
                                          double qx, double qy, Hit &h, double &ex, double &ey)
 {
-    const size_t i00 = (size_t)cy * W + cx;
-    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(flow + 2 * i00);
-    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(flow + 2 * (i00 + W));
-    const D2 pa = warp_pt(cx, cy, r0.lo_u, r0.lo_v, sign), pb = warp_pt(cx + 1, cy, r0.hi_u, r0.hi_v, sign);
-    const D2 pc = warp_pt(cx + 1, cy + 1, r1.hi_u, r1.hi_v, sign), pd = warp_pt(cx, cy + 1, r1.lo_u, r1.lo_v, sign);
+    const uint32_t i00 = (uint32_t)cy * (uint32_t)W + (uint32_t)cx;          // H * W < 2^29
+    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(flow + 2 * (size_t)i00);
+    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(flow + 2 * (size_t)(i00 + (uint32_t)W));
+    const D2 pa = warp_pt<SP>(cx, cy, r0.lo_u, r0.lo_v), pb = warp_pt<SP>(cx + 1, cy, r0.hi_u, r0.hi_v);
+    const D2 pc = warp_pt<SP>(cx + 1, cy + 1, r1.hi_u, r1.hi_v), pd = warp_pt<SP>(cx, cy + 1, r1.lo_u, r1.lo_v);
     const int diag = incircle(pa, pb, pc, pd) > 0 ? 1 : 0;             // as pick_diagonal for a convex, positive cell
-    double best = -1e300;
-    int bt = 0;
-    double bw1 = 0.0, bw2 = 0.0, bdet = 1.0;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int i0, i1, i2;
-        tri_corners(diag, t, i0, i1, i2);
-        const D2 q0 = pick4(i0, pa, pb, pc, pd), q1 = pick4(i1, pa, pb, pc, pd), q2 = pick4(i2, pa, pb, pc, pd);
-        const double e1x = q1.x - q0.x, e1y = q1.y - q0.y, e2x = q2.x - q0.x, e2y = q2.y - q0.y;
-        const double det = e1x * e2y - e1y * e2x;                       // > 0 (certificate)
-        const double dx = qx - q0.x, dy = qy - q0.y;
-        const double w1 = dx * e2y - dy * e2x, w2 = e1x * dy - e1y * dx, w0 = det - w1 - w2;
-        const double tol = kEps * det;
-        const double worst = fmin(w0, fmin(w1, w2));
-        if (worst >= -tol) {
-            const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
-            const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
-            const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
-            h.vi[0] = (size_t)y0 * W + x0; h.vi[1] = (size_t)y1 * W + x1; h.vi[2] = (size_t)y2 * W + x2;
-            h.c1 = w1 / det; h.c2 = w2 / det; h.c0 = 1.0 - h.c1 - h.c2;        // the coordinates as `bary` forms them
-            const float2 fa = make_float2(r0.lo_u, r0.lo_v), fb = make_float2(r0.hi_u, r0.hi_v);
-            const float2 fc = make_float2(r1.hi_u, r1.hi_v), fd = make_float2(r1.lo_u, r1.lo_v);
-            h.fv[0] = pick4(i0, fa, fb, fc, fd); h.fv[1] = pick4(i1, fa, fb, fc, fd); h.fv[2] = pick4(i2, fa, fb, fc, fd);
-            return true;
-        }
-        if (worst / det > best) { best = worst / det; bt = t; bw1 = w1; bw2 = w2; bdet = det; }
-    }
+    // triangle 0 = (a, b, c) or (b, c, d); its vertex-1 coordinate w1 vanishes on the cell's diagonal, so w1 also tells
+    // on which side of the diagonal the position lies: the second triangle is only evaluated when it can matter
+    int t = 0;
+    int i0, i1, i2;
+    double w1, w2, det;
+    bool in;
     {
-        int i0, i1, i2;
-        tri_corners(diag, bt, i0, i1, i2);
-        const double c1 = bw1 / bdet, c2 = bw2 / bdet, c0 = 1.0 - c1 - c2;
-        const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
-        const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
-        const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
-        ex = c0 * x0 + c1 * x1 + c2 * x2;
-        ey = c0 * y0 + c1 * y1 + c2 * y2;
+        tri_corners(diag, 0, i0, i1, i2);
+        const D2 q0 = diag ? pb : pa, q1 = diag ? pc : pb, q2 = diag ? pd : pc;
+        const double e1x = q1.x - q0.x, e1y = q1.y - q0.y, e2x = q2.x - q0.x, e2y = q2.y - q0.y;
+        det = e1x * e2y - e1y * e2x;                                    // > 0 (certificate)
+        const double dx = qx - q0.x, dy = qy - q0.y;
+        w1 = dx * e2y - dy * e2x; w2 = e1x * dy - e1y * dx;
+        const double tol = kEps * det;
+        in = fmin(det - w1 - w2, fmin(w1, w2)) >= -tol;
+        if (!in && w1 <= tol) {                                         // on or beyond the diagonal: the other half of the cell
+            t = 1;
+            tri_corners(diag, 1, i0, i1, i2);
+            const D2 r0p = q0, r1p = q2, r2p = diag ? pa : pd;          // (a, c, d) or (b, d, a): shares q0 and the diagonal
+            const double f1x = r1p.x - r0p.x, f1y = r1p.y - r0p.y, f2x = r2p.x - r0p.x, f2y = r2p.y - r0p.y;
+            const double det1 = f1x * f2y - f1y * f2x;
+            const double v1 = dx * f2y - dy * f2x, v2 = f1x * dy - f1y * dx;
+            const double tol1 = kEps * det1;
+            const bool in1 = fmin(det1 - v1 - v2, fmin(v1, v2)) >= -tol1;
+            // a miss keeps the triangle on whose side of the diagonal the position lies
+            if (in1 || w1 < -tol) { in = in1; w1 = v1; w2 = v2; det = det1; }
+            else { t = 0; tri_corners(diag, 0, i0, i1, i2); }
+        }
     }
+    const double inv = 1.0 / det;
+    const double c1 = w1 * inv, c2 = w2 * inv, c0 = 1.0 - c1 - c2;
+    const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
+    const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
+    const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
+    if (in) {
+        h.vi[0] = (uint32_t)y0 * (uint32_t)W + (uint32_t)x0; h.vi[1] = (uint32_t)y1 * (uint32_t)W + (uint32_t)x1;
+        h.vi[2] = (uint32_t)y2 * (uint32_t)W + (uint32_t)x2;
+        h.c0 = c0; h.c1 = c1; h.c2 = c2;
+        const float2 fa = make_float2(r0.lo_u, r0.lo_v), fb = make_float2(r0.hi_u, r0.hi_v);
+        const float2 fc = make_float2(r1.hi_u, r1.hi_v), fd = make_float2(r1.lo_u, r1.lo_v);
+        h.fv[0] = pick4(i0, fa, fb, fc, fd); h.fv[1] = pick4(i1, fa, fb, fc, fd); h.fv[2] = pick4(i2, fa, fb, fc, fd);
+        return true;
+    }
+    (void)t;
+    ex = c0 * x0 + c1 * x1 + c2 * x2;                                  // Newton step: the triangle's affine map applied to the position
+    ey = c0 * y0 + c1 * y1 + c2 * y2;
     return false;
 }
 
-__device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int sign, int H, int W, int x, int y, Hit &h)
+template <int SP>
+__device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int H, int W, int x, int y, Hit &h)
 {
     const double qx = (double)x, qy = (double)y;
     // first estimate of the source index: one Newton step from the node itself, i = q - J^-1 (P(q) - q), with the
-    // Jacobian J = I + s * grad f from the differences to the node's right / lower neighbours (exact for affine fields)
+    // Jacobian J = I + s * grad f from the differences to the node's right / lower neighbours (exact for affine fields;
+    // float32 is plenty for an estimate that only selects the first cell)
     const int xn = x + 1 < W ? x + 1 : x - 1, yn = y + 1 < H ? y + 1 : y - 1;
     const float2 f0 = *reinterpret_cast<const float2 *>(flow + ((size_t)y * W + x) * 2);
     const float2 fxn = *reinterpret_cast<const float2 *>(flow + ((size_t)y * W + xn) * 2);
     const float2 fyn = *reinterpret_cast<const float2 *>(flow + ((size_t)yn * W + x) * 2);
-    const double sg = sign >= 0 ? 1.0 : -1.0, hx = (double)(xn - x), hy = (double)(yn - y);
-    const double ja = 1.0 + sg * ((double)fxn.x - (double)f0.x) / hx, jb = sg * ((double)fyn.x - (double)f0.x) / hy;
-    const double jc = sg * ((double)fxn.y - (double)f0.y) / hx, jd = 1.0 + sg * ((double)fyn.y - (double)f0.y) / hy;
-    const double jdet = ja * jd - jb * jc, rx = sg * (double)f0.x, ry = sg * (double)f0.y;
-    double ex = qx - rx, ey = qy - ry;
-    if (fabs(jdet) > 1e-3) { ex = qx - (jd * rx - jb * ry) / jdet; ey = qy - (ja * ry - jc * rx) / jdet; }
+    const float sg = SP >= 0 ? 1.0f : -1.0f, hx = sg * (float)(xn - x), hy = sg * (float)(yn - y);
+    const float ja = 1.0f + (fxn.x - f0.x) * hx, jb = (fyn.x - f0.x) * hy;
+    const float jc = (fxn.y - f0.y) * hx, jd = 1.0f + (fyn.y - f0.y) * hy;
+    const float jdet = ja * jd - jb * jc, rx = sg * f0.x, ry = sg * f0.y;
+    double ex = qx - (double)rx, ey = qy - (double)ry;
+    if (fabsf(jdet) > 1e-3f) {
+        const float ij = 1.0f / jdet;
+        ex = qx - (double)((jd * rx - jb * ry) * ij);
+        ey = qy - (double)((ja * ry - jc * rx) * ij);
+    }
     int pcx = -1, pcy = -1, ppcx = -2, ppcy = -2;
     for (int it = 0; it < kWalkIters; ++it) {
         const int cx = (int)fmin(fmax(floor(ex), 0.0), (double)(W - 2)), cy = (int)fmin(fmax(floor(ey), 0.0), (double)(H - 2));
         if ((cx == pcx && cy == pcy) || (cx == ppcx && cy == ppcy)) break;      // no progress / a 2-cycle across an edge
         ppcx = pcx; ppcy = pcy; pcx = cx; pcy = cy;
-        if (try_cell(flow, sign, W, cx, cy, qx, qy, h, ex, ey)) return true;
+        if (try_cell<SP>(flow, W, cx, cy, qx, qy, h, ex, ey)) return true;
     }
     // the estimate stopped moving without a hit (a node outside the mesh ends here, clamped to a border cell; a node on
     // a cell edge may alternate between its two sides): the cells around the last two stops decide
@@ -263,7 +280,7 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
             for (int ox = -1; ox <= 1; ++ox) {
                 const int cx = bx + ox, cy = by + oy;
                 if (cx < 0 || cy < 0 || cx > W - 2 || cy > H - 2) continue;
-                if (try_cell(flow, sign, W, cx, cy, qx, qy, h, dx, dy)) return true;
+                if (try_cell<SP>(flow, W, cx, cy, qx, qy, h, dx, dy)) return true;
             }
     }
     return false;
@@ -299,14 +316,14 @@ __device__ bool side_scan(const float *__restrict__ flow, int sign, int H, int W
     }
     if (aL == -1e300 || aR == -1e300 || !(aL + aR >= -1e-14)) return false;
     const double span = sR - sL;
-    h.vi[0] = iL; h.vi[1] = iR; h.vi[2] = iL;
+    h.vi[0] = (uint32_t)iL; h.vi[1] = (uint32_t)iR; h.vi[2] = (uint32_t)iL;
     h.c0 = sR / span; h.c1 = -sL / span; h.c2 = 0.0;
     return true;
 }
 
-template <typename VT, bool FLOWVALS>      // FLOWVALS: vals == flow, C == 2: the values are the corner vectors already loaded
+template <typename VT, bool FLOWVALS, int SP>      // FLOWVALS: vals == flow, C == 2: the values are the corner vectors already loaded
 __global__ __launch_bounds__(256)
-void scatter_walk_kernel(const float *__restrict__ flow, int sign, const VT *__restrict__ vals, int C,
+void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ vals, int C,
                          const uint8_t *__restrict__ vmask, int H, int W, int row0, int rows,
                          VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, WalkCert wc,
                          uint32_t *__restrict__ fail)
@@ -316,7 +333,8 @@ void scatter_walk_kernel(const float *__restrict__ flow, int sign, const VT *__r
     if (x >= W || yl >= rows) return;
     const size_t o = (size_t)yl * W + x;
     Hit h;
-    bool found = walk_locate(flow, sign, H, W, x, y, h);
+    const int sign = SP;
+    bool found = walk_locate<SP>(flow, H, W, x, y, h);
     if (!found) {
         // not covered by the mesh: outside the convex hull -- unless the node sits within the noise band of a border
         // side, where the hull of the (almost collinear) border points decides
@@ -350,9 +368,11 @@ void scatter_walk_kernel(const float *__restrict__ flow, int sign, const VT *__r
         const bool neg = (valid_rule & OFL_SCATTER_NEGATE) != 0, rnd = (valid_rule & OFL_SCATTER_ROUND) != 0;
         const double ru = rnd ? rint(u) : u, rv = rnd ? rint(v) : v;
         *reinterpret_cast<float2 *>(out + o * 2) = make_float2((float)(neg ? -ru : ru), (float)(neg ? -rv : rv));
-        resolve_emit(vals, 0, vmask, h.vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);       // validity only
+        const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
+        resolve_emit(vals, 0, vmask, vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);       // validity only
     } else if (found) {
-        resolve_emit(vals, C, vmask, h.vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);
+        const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
+        resolve_emit(vals, C, vmask, vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);
     } else {
         for (int c = 0; c < C; ++c) out[o * C + c] = (VT)0;              // NaN -> 0, utils.py:254
         if (valid) valid[o] = 0;
@@ -408,12 +428,18 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
     for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
     wc.delta = cert->border_dev;
     const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
-    if (std::is_same<VT, float>::value && (const void *)vals == (const void *)flow && C == 2)
-        hipLaunchKernelGGL((scatter_walk_kernel<VT, true>), grid, block, 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
-                           out, valid, valid_rule, wc, fail_dev);
-    else
-        hipLaunchKernelGGL((scatter_walk_kernel<VT, false>), grid, block, 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
-                           out, valid, valid_rule, wc, fail_dev);
+    const bool fused = std::is_same<VT, float>::value && (const void *)vals == (const void *)flow && C == 2;
+#define OFL_WALK_LAUNCH(F, SP)                                                                                             \
+    hipLaunchKernelGGL((scatter_walk_kernel<VT, F, SP>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, out,  \
+                       valid, valid_rule, wc, fail_dev)
+    if (fused) {
+        if (sign_pp == 1) OFL_WALK_LAUNCH(true, 1); else if (sign_pp == -1) OFL_WALK_LAUNCH(true, -1);
+        else if (sign_pp == 2) OFL_WALK_LAUNCH(true, 2); else OFL_WALK_LAUNCH(true, -2);
+    } else {
+        if (sign_pp == 1) OFL_WALK_LAUNCH(false, 1); else if (sign_pp == -1) OFL_WALK_LAUNCH(false, -1);
+        else if (sign_pp == 2) OFL_WALK_LAUNCH(false, 2); else OFL_WALK_LAUNCH(false, -2);
+    }
+#undef OFL_WALK_LAUNCH
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""One operation in a loop for profiling: python tools/bench_invert.py [--op invert|switch|speckle|hole|stripes] [--iters N]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oflibnumpy_amd as of
+from oflibnumpy_amd import device as dev
+from bench_ops import timed, report
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--op", default="invert")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--size", type=int, nargs=2, default=[2160, 3840])
+    args = ap.parse_args()
+    of.native.ensure_device()
+    h, w = args.size
+    f = of.Flow.from_transforms([['rotation', w / 2, h / 2, -20], ['scaling', w / 3.84, h / 2.7, 0.9]], [h, w], 's')
+    if args.op in ("invert", "switch"):
+        d = of.Flow.from_transforms([['scaling', 1000, 800, 0.9]], [h, w], 's').to_device()
+    elif args.op == "speckle":
+        m = np.random.default_rng(0).random((h, w)) > 0.05
+        d = dev.DeviceFlow.from_host(f.vecs, 's', m)
+    elif args.op == "hole":
+        m = np.ones((h, w), bool)
+        m[h // 4:h // 4 + h // 5, w // 4:w // 4 + w // 5] = False
+        d = dev.DeviceFlow.from_host(f.vecs, 's', m)
+    elif args.op == "stripes":
+        yy, xx = np.mgrid[:h, :w].astype(np.float32)
+        v = np.zeros((h, w, 2), np.float32)
+        v[..., 0] = (np.floor(xx / 64) % 2) * 20.0
+        d = dev.DeviceFlow.from_host(v, 's')
+    else:
+        raise SystemExit("unknown op")
+    d.stats()
+    fn = (lambda: d.switch_ref()) if args.op == "switch" else (lambda: d.invert())
+    t = timed(fn, args.iters)
+    report(args.op, (h, w), 18, *t)
+
+
+if __name__ == "__main__":
+    main()

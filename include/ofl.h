@@ -94,7 +94,12 @@ int         ofl_free(void *dptr);
 int         ofl_memset(void *dptr, int value, size_t bytes, void *stream);
 int         ofl_upload(void *dptr, const void *host, size_t bytes, void *stream);     /* async on stream; pinned staging not required */
 int         ofl_download(void *host, const void *dptr, size_t bytes, void *stream);
+int         ofl_download_async(void *host, const void *dptr, size_t bytes, void *stream);  /* no synchronisation: host must be pinned (ofl_host_alloc) for a true DMA */
 int         ofl_copy_dev(void *dst, const void *src, size_t bytes, void *stream);
+/* page-locked host memory: uploads / downloads from it are asynchronous DMA transfers that overlap with kernels
+ * (on-disk formats are read straight into it: oflibnumpy_amd.device.load_sintel_device; utils.py:447-470) */
+int         ofl_host_alloc(void **hptr, size_t bytes);
+int         ofl_host_free(void *hptr);
 int         ofl_stream_create(void **stream);
 int         ofl_stream_destroy(void *stream);
 int         ofl_stream_sync(void *stream);        /* NULL = default stream */

@@ -11,7 +11,7 @@ Everything numeric runs in hand-written HIP kernels for gfx950 behind the C ABI 
 """
 from .flow_class import Flow
 from .flow_operations import *
-from .utils import from_matrix, from_transforms, load_sintel, load_sintel_mask, load_kitti, apply_flow, is_zero_flow, threshold_vectors, track_pts, resize_flow
+from .utils import from_matrix, from_transforms, load_sintel, save_sintel, load_sintel_mask, load_kitti, apply_flow, is_zero_flow, threshold_vectors, track_pts, resize_flow
 from .device import DeviceFlow, DeviceImage, DeviceBuffer
 from .batch import DeviceFlowBatch, combine_flows_batch
 from . import _native as native

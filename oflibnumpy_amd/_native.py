@@ -53,7 +53,10 @@ SIGNATURES = {
     "ofl_memset": (_ci, [_vp, _ci, _cs, _vp]),
     "ofl_upload": (_ci, [_vp, _vp, _cs, _vp]),
     "ofl_download": (_ci, [_vp, _vp, _cs, _vp]),
+    "ofl_download_async": (_ci, [_vp, _vp, _cs, _vp]),
     "ofl_copy_dev": (_ci, [_vp, _vp, _cs, _vp]),
+    "ofl_host_alloc": (_ci, [_pvp, _cs]),
+    "ofl_host_free": (_ci, [_vp]),
     "ofl_stream_create": (_ci, [_pvp]),
     "ofl_stream_destroy": (_ci, [_vp]),
     "ofl_stream_sync": (_ci, [_vp]),

@@ -818,6 +818,110 @@ void dl_resolve_kernel(const float *__restrict__ flow, int sign, const VT *__res
     resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, out, valid, o);
 }
 
+// ------------------------------------------------------------------------------------------------ arbitrary positions
+// neighbour k of site u (cyclic); -1 = an unbounded gap of the star (or no star)
+struct StarRef { const unsigned *small; const int *far; unsigned d; };
+
+__device__ __forceinline__ StarRef star_of(const DlWs &ws, unsigned u)
+{
+    StarRef r;
+    r.small = nullptr; r.far = nullptr; r.d = 0;
+    const unsigned d = ws.deg[u];
+    if (d >= 1 && d <= kSlots) { r.small = ws.nbr + (size_t)u * kSlots; r.d = d; }
+    else if (d == kDegFar) {
+        const unsigned rank = ws.nbr[(size_t)u * kSlots], fd = ws.far_deg[rank];
+        if (fd != kDegLeft && fd > 0) { r.far = ws.pool + ws.far_off[rank]; r.d = fd; }
+    }
+    return r;
+}
+
+__device__ __forceinline__ int star_at(const StarRef &s, unsigned k) { return s.small ? (int)s.small[k] : s.far[k]; }
+
+// The triangle of the triangulation that contains (qx, qy): a visibility walk from the owner triangle of the grid node
+// next to the position.  Stepping over the edge u -> v of the counter-clockwise triangle (u, v, w) leads to the triangle
+// (u, x, v) with x the neighbour BEFORE v in u's star; a gap there means the position is outside the convex hull.
+__device__ bool dl_locate(const DlWs &ws, unsigned far_base, const PosFn &pos, int H, int W, double qx, double qy,
+                          TriRef &tr, double &c0, double &c1, double &c2)
+{
+    if (!(qx == qx && qy == qy)) return false;
+    const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
+    unsigned id = kNoOwner;
+    for (int r = 0; r <= 2 && id == kNoOwner; ++r)
+        for (int dy = -r; dy <= r && id == kNoOwner; ++dy)
+            for (int dx = -r; dx <= r && id == kNoOwner; ++dx) {
+                if (max(abs(dx), abs(dy)) != r) continue;
+                const int x = nx + dx, y = ny + dy;
+                if (x < 0 || y < 0 || x >= W || y >= H) continue;
+                id = ws.owner[(size_t)y * W + x];
+            }
+    if (id == kNoOwner) return false;
+    tr = dl_decode(id, far_base, ws);
+    if (!tr.ok) return false;
+    unsigned a = tr.i0, b = tr.i1, c = tr.i2;
+    D2 pa = pt(pos, a), pb = pt(pos, b), pc = pt(pos, c);
+    if (cross2(pa, pb, pc) < 0.0) { const unsigned t = b; b = c; c = t; const D2 tp = pb; pb = pc; pc = tp; }     // counter-clockwise
+    for (int step = 0; step < 16384; ++step) {
+        // edge functions of q (positive inside)
+        const double det = cross2(pa, pb, pc);
+        if (!(det > 0.0)) return false;
+        const double wa = cross2(pb, pc, D2{ qx, qy }), wb = cross2(pc, pa, D2{ qx, qy }), wc = cross2(pa, pb, D2{ qx, qy });
+        const double tol = kEps * det;
+        if (wa >= -tol && wb >= -tol && wc >= -tol) {
+            tr.i0 = a; tr.i1 = b; tr.i2 = c;
+            canonical3(tr.i0, tr.i1, tr.i2);
+            tr.ok = true;
+            (void)bary(pt(pos, tr.i0), pt(pos, tr.i1), pt(pos, tr.i2), qx, qy, c0, c1, c2);
+            return true;
+        }
+        // leave through the most violated edge: wa belongs to edge b -> c, wb to c -> a, wc to a -> b
+        unsigned u, v;
+        D2 pu, pv;
+        if (wa <= wb && wa <= wc) { u = b; v = c; pu = pb; pv = pc; }
+        else if (wb <= wc)        { u = c; v = a; pu = pc; pv = pa; }
+        else                      { u = a; v = b; pu = pa; pv = pb; }
+        const StarRef su = star_of(ws, u);
+        if (su.d == 0) return false;
+        unsigned k = 0;
+        while (k < su.d && star_at(su, k) != (int)v) ++k;
+        if (k == su.d) return false;                                   // stars disagree here (co-circular sites): give up
+        const int x = star_at(su, k == 0 ? su.d - 1 : k - 1);
+        if (x < 0) return false;                                       // an unbounded gap: outside the convex hull
+        // new triangle (u, x, v), counter-clockwise
+        a = u; pa = pu; b = (unsigned)x; pb = pt(pos, (unsigned)x); c = v; pc = pv;
+    }
+    return false;
+}
+
+template <bool SPARSE>
+__global__ __launch_bounds__(256)
+void dl_query_kernel(const float *__restrict__ flow, int sign, const float *__restrict__ vals, int C,
+                     const uint8_t *__restrict__ vmask, int H, int W, const void *__restrict__ query, size_t n,
+                     void *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, DlWs ws, unsigned far_base)
+{
+    const PosFn pos(flow, sign, W);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double qx, qy;
+        if (SPARSE) { qx = ((const double *)query)[2 * i]; qy = ((const double *)query)[2 * i + 1]; }
+        else { const float2 q = ((const float2 *)query)[i]; qx = (double)q.x; qy = (double)q.y; }
+        TriRef tr;
+        double c0 = 0, c1 = 0, c2 = 0;
+        const bool found = dl_locate(ws, far_base, pos, H, W, qx, qy, tr, c0, c1, c2);
+        if (SPARSE) {
+            double *o = (double *)out + i * C;
+            for (int c = 0; c < C; ++c)
+                o[c] = found ? c0 * (double)vals[(size_t)tr.i0 * C + c] + c1 * (double)vals[(size_t)tr.i1 * C + c] +
+                               c2 * (double)vals[(size_t)tr.i2 * C + c] : 0.0;
+            valid[i] = found ? 1 : 0;
+        } else if (found) {
+            const size_t vi[3] = { tr.i0, tr.i1, tr.i2 };
+            resolve_emit(vals, C, vmask, vi, c0, c1, c2, valid_rule, (float *)out, valid, i);
+        } else {
+            for (int c = 0; c < C; ++c) ((float *)out)[i * C + c] = 0.0f;
+            if (valid) valid[i] = 0;
+        }
+    }
+}
+
 struct Sizes { size_t n, bcap, b1cap, pool_cap, big_cap; };
 
 Sizes sizes_for(int H, int W)
@@ -891,16 +995,18 @@ size_t exact_workspace_bytes(int H, int W)
     return total;
 }
 
-// rows [row0, row0 + rows) of the grid result through the exact path; synchronises twice (counts of the star passes)
-template <typename VT>
-int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT *vals, int C, const uint8_t *vmask,
-                  int H, int W, int row0, int rows, VT *out, uint8_t *valid, int valid_rule,
-                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s)
+}  // namespace ofl_sc
+
+namespace {
+
+// Bins, stars and the owner map of rows [row0, row0 + rows); synchronises twice (counts of the star passes).
+int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows,
+                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s, DlWs &ws, unsigned &far_base_out)
 {
     const size_t n = (size_t)H * W;
     if (n >= (1ull << 27)) return fail(OFL_E_INVALID, "ofl_scatter_linear: the exact path takes fields below 2^27 pixels");
-    if (workspace_bytes < exact_workspace_bytes(H, W)) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small for the exact path");
-    DlWs ws = carve_exact(workspace, H, W);
+    if (workspace_bytes < ofl_sc::exact_workspace_bytes(H, W)) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small for the exact path");
+    ws = carve_exact(workspace, H, W);
     ws.oy0 = row0; ws.oy1 = row0 + rows;
     OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)rows * W * 4, s));
     ws.owner -= (size_t)row0 * W;
@@ -983,9 +1089,7 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
     if (h.n_far)
         hipLaunchKernelGGL(dl_raster_far_kernel, dim3((h.n_far + 255) / 256), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
-    const dim3 grid((W + 31) / 32, (rows + 7) / 8);
-    hipLaunchKernelGGL(dl_resolve_kernel<VT>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
-                       out, valid, valid_rule, ws, (unsigned)far_base);
+    far_base_out = (unsigned)far_base;
     OFL_HIP(hipGetLastError());
     if (info_host) {
         // callers that ask for the counts also learn whether a capacity of the star passes was exceeded (a fan of more
@@ -995,6 +1099,46 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
         if (h.err) return fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
                                               "neighbours, 2 = neighbour pool, 4 = large-triangle list)", h.err, kFarCap);
     }
+    return OFL_OK;
+}
+
+
+}  // namespace
+
+namespace ofl_sc {
+
+// rows [row0, row0 + rows) of the grid result through the exact path
+template <typename VT>
+int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT *vals, int C, const uint8_t *vmask,
+                  int H, int W, int row0, int rows, VT *out, uint8_t *valid, int valid_rule,
+                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s)
+{
+    DlWs ws;
+    unsigned far_base = 0;
+    OFL_TRY(exact_prepare(flow, sign_pp, pmask, H, W, row0, rows, workspace, workspace_bytes, info_host, s, ws, far_base));
+    const dim3 grid((W + 31) / 32, (rows + 7) / 8);
+    hipLaunchKernelGGL(dl_resolve_kernel<VT>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
+                       out, valid, valid_rule, ws, far_base);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+// arbitrary positions through the exact path (see walk_query_launch for the two layouts)
+int exact_query(const float *flow, int sign_pp, const uint8_t *pmask, const float *vals, int C, const uint8_t *vmask,
+                int H, int W, const void *query, size_t n, bool sparse, void *out, uint8_t *valid, int valid_rule,
+                void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s)
+{
+    DlWs ws;
+    unsigned far_base = 0;
+    OFL_TRY(exact_prepare(flow, sign_pp, pmask, H, W, 0, H, workspace, workspace_bytes, info_host, s, ws, far_base));
+    if (n == 0) return OFL_OK;
+    const size_t nb = (n + 255) / 256;
+    const dim3 grid((unsigned)(nb < (1u << 20) ? nb : (1u << 20)));
+    if (sparse)
+        hipLaunchKernelGGL(dl_query_kernel<true>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, query, n, out, valid, valid_rule, ws, far_base);
+    else
+        hipLaunchKernelGGL(dl_query_kernel<false>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, query, n, out, valid, valid_rule, ws, far_base);
+    OFL_HIP(hipGetLastError());
     return OFL_OK;
 }
 

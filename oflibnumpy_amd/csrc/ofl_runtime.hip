@@ -121,6 +121,33 @@ int ofl_free(void *dptr)
     return OFL_OK;
 }
 
+int ofl_host_alloc(void **hptr, size_t bytes)
+{
+    OFL_TRY(need_device());
+    if (!hptr) return fail(OFL_E_INVALID, "ofl_host_alloc: NULL");
+    *hptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    OFL_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return OFL_OK;
+}
+
+int ofl_host_free(void *hptr)
+{
+    if (!hptr) return OFL_OK;
+    OFL_TRY(need_device());
+    OFL_HIP(hipHostFree(hptr));
+    return OFL_OK;
+}
+
+int ofl_download_async(void *host, const void *dptr, size_t bytes, void *stream)
+{
+    OFL_TRY(need_device());
+    if (bytes == 0) return OFL_OK;
+    if (!dptr || !host) return fail(OFL_E_INVALID, "ofl_download_async: NULL pointer");
+    OFL_HIP(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, stream_of(stream)));
+    return OFL_OK;
+}
+
 int ofl_memset(void *dptr, int value, size_t bytes, void *stream)
 {
     OFL_TRY(need_device());

@@ -157,11 +157,20 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
                 int row0, int rows, VT *out, uint8_t *valid, int valid_rule, const ofl_mesh_cert *cert,
                 uint32_t *fail_dev, hipStream_t s);
 
+// arbitrary positions on a certified mesh: query = float32 [n][2] (dense: float32 out [n][C] + validity by valid_rule) or
+// float64 [n][2] (sparse: float64 out [n][C] + found flags)
+int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, const uint8_t *vmask, int H, int W,
+                      const void *query, size_t n, bool sparse, void *out, uint8_t *valid, int valid_rule,
+                      const ofl_mesh_cert *cert, hipStream_t s);
+
 // exact path (ofl_delaunay.hip): Delaunay triangulation of the kept points on the GPU
 size_t exact_workspace_bytes(int H, int W);
 template <typename VT>
 int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT *vals, int C, const uint8_t *vmask,
                   int H, int W, int row0, int rows, VT *out, uint8_t *valid, int valid_rule,
                   void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s);
+int exact_query(const float *flow, int sign_pp, const uint8_t *pmask, const float *vals, int C, const uint8_t *vmask,
+                int H, int W, const void *query, size_t n, bool sparse, void *out, uint8_t *valid, int valid_rule,
+                void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s);
 
 }  // namespace ofl_sc

@@ -242,10 +242,9 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
     return false;
 }
 
-template <int SP>
-__device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int H, int W, int x, int y, Hit &h)
+template <int SP>      // the position (qx, qy) starts from the grid node (x, y) next to it (a grid node: itself)
+__device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int H, int W, int x, int y, double qx, double qy, Hit &h)
 {
-    const double qx = (double)x, qy = (double)y;
     // first estimate of the source index: one Newton step from the node itself, i = q - J^-1 (P(q) - q), with the
     // Jacobian J = I + s * grad f from the differences to the node's right / lower neighbours (exact for affine fields;
     // float32 is plenty for an estimate that only selects the first cell)
@@ -256,12 +255,13 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
     const float sg = SP >= 0 ? 1.0f : -1.0f, hx = sg * (float)(xn - x), hy = sg * (float)(yn - y);
     const float ja = 1.0f + (fxn.x - f0.x) * hx, jb = (fyn.x - f0.x) * hy;
     const float jc = (fxn.y - f0.y) * hx, jd = 1.0f + (fyn.y - f0.y) * hy;
-    const float jdet = ja * jd - jb * jc, rx = sg * f0.x, ry = sg * f0.y;
-    double ex = qx - (double)rx, ey = qy - (double)ry;
+    // residual of the node: P(node) - q
+    const float jdet = ja * jd - jb * jc, rx = sg * f0.x + (float)((double)x - qx), ry = sg * f0.y + (float)((double)y - qy);
+    double ex = (double)x - (double)rx, ey = (double)y - (double)ry;
     if (fabsf(jdet) > 1e-3f) {
         const float ij = 1.0f / jdet;
-        ex = qx - (double)((jd * rx - jb * ry) * ij);
-        ey = qy - (double)((ja * ry - jc * rx) * ij);
+        ex = (double)x - (double)((jd * rx - jb * ry) * ij);
+        ey = (double)y - (double)((ja * ry - jc * rx) * ij);
     }
     int pcx = -1, pcy = -1, ppcx = -2, ppcy = -2;
     for (int it = 0; it < kWalkIters; ++it) {
@@ -321,6 +321,36 @@ __device__ bool side_scan(const float *__restrict__ flow, int sign, int H, int W
     return true;
 }
 
+// A position no mesh triangle covers is outside the convex hull -- unless it sits within the noise band of a border
+// side, where the hull of the (almost collinear) border points decides.
+__device__ bool hull_band_locate(const float *__restrict__ flow, int sign, int H, int W, const WalkCert &wc,
+                                 double qx, double qy, Hit &h, uint32_t *__restrict__ fail)
+{
+    bool outside = false, inside_all = true;
+    int near_mask = 0;
+#pragma unroll
+    for (int side = 0; side < 4; ++side) {
+        const D2 A = wc.c[side], B = wc.c[(side + 1) & 3];
+        const double len = sqrt((B.x - A.x) * (B.x - A.x) + (B.y - A.y) * (B.y - A.y));
+        const double d = cross2(A, B, D2{ qx, qy }) / len;            // inward > 0
+        if (d < -2.0 * wc.delta - 1e-12) outside = true;
+        else if (d <= 2.0 * wc.delta + 1e-12) near_mask |= 1 << side;
+    }
+    if (outside) return false;
+    if (!near_mask) {
+        if (fail) atomicAdd(fail, 1u);            // well inside the hull and still no triangle: the certificate was wrong
+        return false;
+    }
+    bool first = true;
+    for (int side = 0; side < 4 && inside_all; ++side) {
+        if (!((near_mask >> side) & 1)) continue;
+        Hit hs;
+        if (!side_scan(flow, sign, H, W, side, wc, qx, qy, hs)) inside_all = false;
+        else if (first) { h = hs; first = false; }
+    }
+    return inside_all;
+}
+
 template <typename VT, bool FLOWVALS, int SP>      // FLOWVALS: vals == flow, C == 2: the values are the corner vectors already loaded
 __global__ __launch_bounds__(256)
 void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ vals, int C,
@@ -334,34 +364,8 @@ void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ 
     const size_t o = (size_t)yl * W + x;
     Hit h;
     const int sign = SP;
-    bool found = walk_locate<SP>(flow, H, W, x, y, h);
-    if (!found) {
-        // not covered by the mesh: outside the convex hull -- unless the node sits within the noise band of a border
-        // side, where the hull of the (almost collinear) border points decides
-        const double qx = (double)x, qy = (double)y;
-        bool outside = false, inside_all = true;
-        int near_mask = 0;
-#pragma unroll
-        for (int side = 0; side < 4; ++side) {
-            const D2 A = wc.c[side], B = wc.c[(side + 1) & 3];
-            const double len = sqrt((B.x - A.x) * (B.x - A.x) + (B.y - A.y) * (B.y - A.y));
-            const double d = cross2(A, B, D2{ qx, qy }) / len;            // inward > 0
-            if (d < -2.0 * wc.delta - 1e-12) outside = true;
-            else if (d <= 2.0 * wc.delta + 1e-12) near_mask |= 1 << side;
-        }
-        if (!outside && near_mask) {
-            bool first = true;
-            for (int side = 0; side < 4 && inside_all; ++side) {
-                if (!((near_mask >> side) & 1)) continue;
-                Hit hs;
-                if (!side_scan(flow, sign, H, W, side, wc, qx, qy, hs)) inside_all = false;
-                else if (first) { h = hs; first = false; }
-            }
-            found = inside_all;
-        } else if (!outside && fail) {
-            atomicAdd(fail, 1u);            // well inside the hull and still no triangle: the certificate was wrong
-        }
-    }
+    bool found = walk_locate<SP>(flow, H, W, x, y, (double)x, (double)y, h);
+    if (!found) found = hull_band_locate(flow, sign, H, W, wc, (double)x, (double)y, h, fail);
     if (found && FLOWVALS && h.c2 != 0.0) {     // (side-scan hits carry no corner vectors: c2 == 0 marks them)
         const double u = h.c0 * (double)h.fv[0].x + h.c1 * (double)h.fv[1].x + h.c2 * (double)h.fv[2].x;
         const double v = h.c0 * (double)h.fv[0].y + h.c1 * (double)h.fv[1].y + h.c2 * (double)h.fv[2].y;
@@ -376,6 +380,41 @@ void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ 
     } else {
         for (int c = 0; c < C; ++c) out[o * C + c] = (VT)0;              // NaN -> 0, utils.py:254
         if (valid) valid[o] = 0;
+    }
+}
+
+// The same for arbitrary positions (mode 2 / ref 't', flow_class.py:1398-1410: query [n][2] float32, float32 results and
+// validity; point tracking, utils.py:603-615: query [n][2] float64, float64 results and found flags).
+template <int SP, bool SPARSE>
+__global__ __launch_bounds__(256)
+void scatter_walk_query_kernel(const float *__restrict__ flow, const float *__restrict__ vals, int C,
+                               const uint8_t *__restrict__ vmask, int H, int W, const void *__restrict__ query, size_t n,
+                               void *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, WalkCert wc)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double qx, qy;
+        if (SPARSE) { qx = ((const double *)query)[2 * i]; qy = ((const double *)query)[2 * i + 1]; }
+        else { const float2 q = ((const float2 *)query)[i]; qx = (double)q.x; qy = (double)q.y; }
+        Hit h;
+        bool found = false;
+        if (qx == qx && qy == qy) {
+            const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
+            found = walk_locate<SP>(flow, H, W, nx, ny, qx, qy, h);
+            if (!found) found = hull_band_locate(flow, SP, H, W, wc, qx, qy, h, nullptr);
+        }
+        if (SPARSE) {
+            double *o = (double *)out + i * C;
+            for (int c = 0; c < C; ++c)
+                o[c] = found ? h.c0 * (double)vals[(size_t)h.vi[0] * C + c] + h.c1 * (double)vals[(size_t)h.vi[1] * C + c] +
+                               h.c2 * (double)vals[(size_t)h.vi[2] * C + c] : 0.0;
+            valid[i] = found ? 1 : 0;
+        } else if (found) {
+            const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
+            resolve_emit(vals, C, vmask, vi, h.c0, h.c1, h.c2, valid_rule, (float *)out, valid, i);
+        } else {
+            for (int c = 0; c < C; ++c) ((float *)out)[i * C + c] = 0.0f;        // NaN -> 0 / fill_value = 0
+            if (valid) valid[i] = 0;
+        }
     }
 }
 
@@ -440,6 +479,31 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
         else if (sign_pp == 2) OFL_WALK_LAUNCH(false, 2); else OFL_WALK_LAUNCH(false, -2);
     }
 #undef OFL_WALK_LAUNCH
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, const uint8_t *vmask, int H, int W,
+                      const void *query, size_t n, bool sparse, void *out, uint8_t *valid, int valid_rule,
+                      const ofl_mesh_cert *cert, hipStream_t s)
+{
+    WalkCert wc;
+    for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
+    wc.delta = cert->border_dev;
+    if (n == 0) return OFL_OK;
+    const size_t nb = (n + 255) / 256;
+    const dim3 grid((unsigned)(nb < (1u << 20) ? nb : (1u << 20))), block(256);
+#define OFL_WQ_LAUNCH(SP, SPARSE)                                                                                    \
+    hipLaunchKernelGGL((scatter_walk_query_kernel<SP, SPARSE>), grid, block, 0, s, flow, vals, C, vmask, H, W, query, \
+                       n, out, valid, valid_rule, wc)
+    if (sparse) {
+        if (sign_pp == 1) OFL_WQ_LAUNCH(1, true); else if (sign_pp == -1) OFL_WQ_LAUNCH(-1, true);
+        else if (sign_pp == 2) OFL_WQ_LAUNCH(2, true); else OFL_WQ_LAUNCH(-2, true);
+    } else {
+        if (sign_pp == 1) OFL_WQ_LAUNCH(1, false); else if (sign_pp == -1) OFL_WQ_LAUNCH(-1, false);
+        else if (sign_pp == 2) OFL_WQ_LAUNCH(2, false); else OFL_WQ_LAUNCH(-2, false);
+    }
+#undef OFL_WQ_LAUNCH
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

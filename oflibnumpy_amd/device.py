@@ -113,6 +113,54 @@ class DeviceBuffer:
         return out
 
 
+class PinnedArray:
+    """A NumPy view of page-locked host memory (ofl_host_alloc): transfers from / to it are asynchronous DMA."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(int(v) for v in shape), np.dtype(dtype)
+        self.nbytes = max(int(np.prod(self.shape)) * self.dtype.itemsize, 16)
+        p = ctypes.c_void_p()
+        nat.check(_lib().ofl_host_alloc(ctypes.byref(p), self.nbytes))
+        self.ptr = p.value
+        self._fin = weakref.finalize(self, nat.load().ofl_host_free, self.ptr)
+        buf = (ctypes.c_char * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+
+def load_sintel_device(path, ref='s', stream=None):
+    """Sintel .flo (utils.py:447-470) straight onto the device: the payload is read into a pinned buffer and uploaded
+    asynchronously on `stream`; returns (DeviceFlow with an all-valid mask, the PinnedArray that must stay alive until
+    the stream has passed the upload).  Flow.from_sintel labels such fields 's' (flow_class.py:262-275)."""
+    if not isinstance(path, str):
+        raise TypeError("Error loading flow from Sintel data: Path needs to be a string")
+    with open(path, 'rb') as f:
+        if f.read(4) != b'PIEH':
+            raise ValueError("Error loading flow from Sintel data: Path not a valid .flo file")
+        w = int.from_bytes(f.read(4), 'little')
+        h = int.from_bytes(f.read(4), 'little')
+        pin = PinnedArray((h, w, 2), '<f4')
+        got = f.readinto(memoryview(pin.array).cast('B'))
+        if got != h * w * 8:
+            raise ValueError("Error loading flow from Sintel data: file is truncated")
+    vecs, mask = DeviceBuffer(h * w * 8), DeviceBuffer(h * w)
+    nat.check(_lib().ofl_upload(vecs.ptr, pin.ptr, h * w * 8, stream))
+    nat.check(_lib().ofl_memset(mask.ptr, 1, h * w, stream))
+    return DeviceFlow(vecs, mask, (h, w), ref), pin
+
+
+def save_sintel_device(path, dflow, stream=None):
+    """DeviceFlow -> .flo through a pinned buffer (asynchronous download, one synchronisation before the write)."""
+    h, w = dflow.shape
+    pin = PinnedArray((h, w, 2), '<f4')
+    nat.check(_lib().ofl_download_async(pin.ptr, dflow.vecs.ptr, h * w * 8, stream))
+    nat.check(_lib().ofl_stream_sync(stream))
+    with open(path, 'wb') as f:
+        f.write(b'PIEH')
+        f.write(int(w).to_bytes(4, 'little'))
+        f.write(int(h).to_bytes(4, 'little'))
+        f.write(memoryview(pin.array).cast('B'))
+
+
 def sync(stream=None):
     nat.check(_lib().ofl_stream_sync(stream))
 

@@ -158,6 +158,20 @@ def load_sintel(path: str) -> nd:
         return np.fromfile(f, dtype=np.dtype('<f4')).reshape(h, w, 2)
 
 
+def save_sintel(path: str, flow: nd) -> None:
+    """Writer for the Sintel .flo layout load_sintel reads (reference utils.py:447-470 is read-only): 'PIEH', int32 w,
+    int32 h, little-endian float32 [h, w, 2]."""
+    if not isinstance(path, str):
+        raise TypeError("Error saving flow as Sintel data: Path needs to be a string")
+    flow = validate_flow_array(flow, "Error saving flow as Sintel data: ")
+    h, w = flow.shape[:2]
+    with open(path, 'wb') as f:
+        f.write(b'PIEH')
+        f.write(int(w).to_bytes(4, 'little'))
+        f.write(int(h).to_bytes(4, 'little'))
+        f.write(np.ascontiguousarray(flow, dtype='<f4').tobytes())
+
+
 def _read_png_or_none(path):
     from ._png import read_png
     try:

@@ -106,11 +106,6 @@ def check_case(of, golden, tag):
         assert r.ref == str(golden[tag + '/out_ref']), tag
         np.testing.assert_array_equal(r.mask, golden[tag + '/out_mask'], err_msg=tag)
         sel = ~amb if 'wobble' in tag else np.ones(r.mask.shape, bool)      # flow-valued data is affine for the affine fields
-        if tag == 'combine2_wobble/t':
-            # mode 2 / ref 't' samples at arbitrary QUERY positions (flow_class.py:1398-1410): that entry still locates
-            # its triangles through the owner map of the cell-wise mesh, whose border pockets differ from SciPy's
-            from scipy import ndimage
-            sel &= ~r.mask | ndimage.binary_erosion(r.mask, iterations=2)
         np.testing.assert_allclose(r.vecs[sel], golden[tag + '/out_vecs'][sel], rtol=RTOL, atol=ATOL, err_msg=tag)
     elif isinstance(r, tuple):
         # random image content (not affine in position): exact wherever the triangulation is unique
@@ -222,11 +217,33 @@ def test_combine_modes_vs_oracle(gpu, oracle, ref):
         both = got.mask & want.mask
         diff = got.mask ^ want.mask
         print("mode", mode, ref, "mask mismatches", int(diff.sum()), "of", diff.size, np.argwhere(diff)[:8].tolist())
-        # mode 2 / ref 't' goes through the query-position entry (owner map of the cell-wise mesh): a node on the
-        # 0.99 threshold of the interpolated mask may fall the other way; every other combination is exact
-        assert diff.sum() <= (2 if (mode, ref) == (2, 't') else 0), (mode, ref, int(diff.sum()))
+        # mode 2 / ref 't' triangulates float32-ROUNDED points (flow_class.py:1398-1400): the warped border is ragged at
+        # the 1e-6 px level, and a query position inside that band (here one: 4e-7 px inside the convex hull) is found
+        # or not by Qhull's handling of the sliver facets there; everything else is exact
+        assert diff.sum() <= (1 if (mode, ref) == (2, 't') else 0), (mode, ref, int(diff.sum()))
         assert both.sum() > 0.5 * want.mask.sum()
         np.testing.assert_allclose(got.vecs[both], want.vecs[both], rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("ref", ['s', 't'])
+def test_config3_mode1_full_size(gpu, ref):
+    """BASELINE config 3 at full size (2160 x 3840): f2.combine_with(f3, mode=1) recovers the analytic rotation within
+    the reference's own tolerance (tests/test_flow_class.py:1020-1057: atol 5e-2 inside both masks).  'sigma' = 1 scatter
+    + 2 gathers (flow_class.py:1369-1370), 't' = 4 scatters + 1 gather (:1383-1385); HBM-resident end to end."""
+    of = gpu
+    shape = [2160, 3840]
+    t_rot, t_scale = [['rotation', 1920, 1080, -20]], [['scaling', 1000, 800, 0.9]]
+    f1 = of.Flow.from_transforms(t_rot, shape, ref)
+    f2 = of.Flow.from_transforms(t_scale, shape, ref).to_device()
+    f3 = of.Flow.from_transforms(t_rot + t_scale, shape, ref).to_device()
+    got = f2.combine_with(f3, 1)
+    assert got.ref == ref
+    vecs, mask = got.to_host()
+    assert mask.mean() > 0.3
+    m = mask & f1.mask
+    np.testing.assert_allclose(vecs[m], f1.vecs[m], atol=5e-2)
+    # every scatter of the chain runs on a certified mesh or on the Delaunay path: no owner-map fallback
+    assert f2.mesh_cert(+1 if ref == 's' else -1).certified == 1
 
 
 def test_scatter_raw_abi(gpu, oracle):

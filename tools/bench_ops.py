@@ -76,11 +76,17 @@ def main():
     d2, d3 = f2.to_device(), f3.to_device()
     d2.stats(); d3.stats()
     t = timed(lambda: d2.invert(), it)
-    report("invert s->s (K3)", (h, w), 18, *t, note="BASELINE config 3; includes the host convex-hull step")
+    report("invert s->s (K3)", (h, w), 18, *t, note="BASELINE config 3; certified mesh: one kernel, no synchronisation (reference: scipy griddata, 64 s at 1080p on 1 core, SURVEY 6)")
     t = timed(lambda: d2.combine_with(d3, 1), max(3, it // 4))
     report("combine_with mode 1 's' (K3 + 2 x K1 + epilogues)", (h, w), 72, *t, note="BASELINE config 3")
     t = timed(lambda: d2.switch_ref(), it)
     report("switch_ref s->t (K3)", (h, w), 18, *t)
+    f2t = of.Flow.from_transforms([['scaling', 1000, 800, 0.9]], [h, w], 't').to_device()
+    f3t = of.Flow.from_transforms([['rotation', 1920, 1080, -20], ['scaling', 1000, 800, 0.9]], [h, w], 't').to_device()
+    f2t.stats(); f3t.stats()
+    t = timed(lambda: f2t.combine_with(f3t, 1), max(3, it // 4))
+    report("combine_with mode 1 't' (4 x K3 + K1 + epilogues)", (h, w), 4 * 18 + 27 + 3 * 27, *t,
+           note="flow_class.py:1383-1385: 4 scatters (the reference: 4 griddata calls, minutes each at this size)")
 
     # K3 on discontinuous fields (motion boundaries fold and stretch cells): a rigid object moving 30 px over a
     # static background, and 64-px stripes of alternating 20-px motion
@@ -100,13 +106,13 @@ def main():
     ds = dev.DeviceFlow.from_host(f3.vecs, 's', spk)
     ds.stats()
     t = timed(lambda: ds.invert(), it)
-    report("invert s->s, 5 % random invalid points incl. a corner (K3)", (h, w), 18, *t, note="points dropped (consider_mask), gaps filled")
+    report("invert s->s, 5 % random invalid points incl. a corner (K3)", (h, w), 18, *t, note="points dropped (consider_mask): Delaunay path")
     hole = np.ones((h, w), bool)
     hole[500:900, 1000:1800] = False
     dh = dev.DeviceFlow.from_host(f3.vecs, 's', hole)
     dh.stats()
     t = timed(lambda: dh.invert(), it)
-    report("invert s->s, 400 x 800 hole in the point mask (K3)", (h, w), 18, *t, note="hole bridged: ring search + jump flooding for the deep nodes")
+    report("invert s->s, 400 x 800 hole in the point mask (K3)", (h, w), 18, *t, note="hole triangulated like SciPy does: Delaunay path")
 
     # K6: Flow.resize of the 4K field: 9 B per source px read + 9 B per output px written
     for scale in (0.5, 2, 1.5):

@@ -14,7 +14,7 @@
 // reference's tests and of BASELINE configs 1-4 is certified; anything else goes to the exact path (ofl_delaunay.hip).
 #include "ofl_scatter_dev.h"
 #include <math.h>
-#include <type_traits>
+
 
 using namespace ofl;
 using namespace ofl_sc;
@@ -165,7 +165,7 @@ void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint
 }
 
 // ------------------------------------------------------------------------------------------------ walk
-struct Hit { uint32_t vi[3]; double c0, c1, c2; float2 fv[3]; };
+struct Hit { uint32_t vi[3]; double c0, c1, c2; };
 
 struct __attribute__((aligned(8))) Pair2 { float lo_u, lo_v, hi_u, hi_v; };    // two adjacent vectors: ONE 16-byte load
 
@@ -231,9 +231,6 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
         h.vi[0] = (uint32_t)y0 * (uint32_t)W + (uint32_t)x0; h.vi[1] = (uint32_t)y1 * (uint32_t)W + (uint32_t)x1;
         h.vi[2] = (uint32_t)y2 * (uint32_t)W + (uint32_t)x2;
         h.c0 = c0; h.c1 = c1; h.c2 = c2;
-        const float2 fa = make_float2(r0.lo_u, r0.lo_v), fb = make_float2(r0.hi_u, r0.hi_v);
-        const float2 fc = make_float2(r1.hi_u, r1.hi_v), fd = make_float2(r1.lo_u, r1.lo_v);
-        h.fv[0] = pick4(i0, fa, fb, fc, fd); h.fv[1] = pick4(i1, fa, fb, fc, fd); h.fv[2] = pick4(i2, fa, fb, fc, fd);
         return true;
     }
     (void)t;
@@ -351,7 +348,7 @@ __device__ bool hull_band_locate(const float *__restrict__ flow, int sign, int H
     return inside_all;
 }
 
-template <typename VT, bool FLOWVALS, int SP>      // FLOWVALS: vals == flow, C == 2: the values are the corner vectors already loaded
+template <typename VT, int SP>
 __global__ __launch_bounds__(256)
 void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ vals, int C,
                          const uint8_t *__restrict__ vmask, int H, int W, int row0, int rows,
@@ -366,15 +363,7 @@ void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ 
     const int sign = SP;
     bool found = walk_locate<SP>(flow, H, W, x, y, (double)x, (double)y, h);
     if (!found) found = hull_band_locate(flow, sign, H, W, wc, (double)x, (double)y, h, fail);
-    if (found && FLOWVALS && h.c2 != 0.0) {     // (side-scan hits carry no corner vectors: c2 == 0 marks them)
-        const double u = h.c0 * (double)h.fv[0].x + h.c1 * (double)h.fv[1].x + h.c2 * (double)h.fv[2].x;
-        const double v = h.c0 * (double)h.fv[0].y + h.c1 * (double)h.fv[1].y + h.c2 * (double)h.fv[2].y;
-        const bool neg = (valid_rule & OFL_SCATTER_NEGATE) != 0, rnd = (valid_rule & OFL_SCATTER_ROUND) != 0;
-        const double ru = rnd ? rint(u) : u, rv = rnd ? rint(v) : v;
-        *reinterpret_cast<float2 *>(out + o * 2) = make_float2((float)(neg ? -ru : ru), (float)(neg ? -rv : rv));
-        const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
-        resolve_emit(vals, 0, vmask, vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);       // validity only
-    } else if (found) {
+    if (found) {
         const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
         resolve_emit(vals, C, vmask, vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);
     } else {
@@ -467,17 +456,13 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
     for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
     wc.delta = cert->border_dev;
     const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
-    const bool fused = std::is_same<VT, float>::value && (const void *)vals == (const void *)flow && C == 2;
-#define OFL_WALK_LAUNCH(F, SP)                                                                                             \
-    hipLaunchKernelGGL((scatter_walk_kernel<VT, F, SP>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, out,  \
+    // (a variant that took flow-valued targets straight from the corner loads was measured SLOWER -- 168 vs 157 us at 4K:
+    // its selects cost more registers than the three cached reloads it saved)
+#define OFL_WALK_LAUNCH(SP)                                                                                             \
+    hipLaunchKernelGGL((scatter_walk_kernel<VT, SP>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, out,  \
                        valid, valid_rule, wc, fail_dev)
-    if (fused) {
-        if (sign_pp == 1) OFL_WALK_LAUNCH(true, 1); else if (sign_pp == -1) OFL_WALK_LAUNCH(true, -1);
-        else if (sign_pp == 2) OFL_WALK_LAUNCH(true, 2); else OFL_WALK_LAUNCH(true, -2);
-    } else {
-        if (sign_pp == 1) OFL_WALK_LAUNCH(false, 1); else if (sign_pp == -1) OFL_WALK_LAUNCH(false, -1);
-        else if (sign_pp == 2) OFL_WALK_LAUNCH(false, 2); else OFL_WALK_LAUNCH(false, -2);
-    }
+    if (sign_pp == 1) OFL_WALK_LAUNCH(1); else if (sign_pp == -1) OFL_WALK_LAUNCH(-1);
+    else if (sign_pp == 2) OFL_WALK_LAUNCH(2); else OFL_WALK_LAUNCH(-2);
 #undef OFL_WALK_LAUNCH
     OFL_HIP(hipGetLastError());
     return OFL_OK;

@@ -457,14 +457,14 @@ __device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, R
     }
 }
 
-// one chunk of up to NT candidates (thread t holds candidate cand, or -1)
+// one chunk of up to NT candidates (thread t holds candidate cand, or -1).  Most chunks cut nothing: they cost ONE barrier
+// (the vote), the cell is only touched -- and the workgroup only synchronises further -- when some candidate cuts it.
 template <int CAP, int NT, class RelFn>
 __device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const PosFn &pos, RelFn rel)
 {
     const int t = threadIdx.x;
     bool hit = false;
     P2 C{ 0.0, 0.0 };
-    __syncthreads();                                   // the cell of the previous chunk is final
     if (cand >= 0 && cand != p) {
         const P2 q = pos(cand);
         C.x = q.x - pp.x; C.y = q.y - pp.y;
@@ -476,6 +476,7 @@ __device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, con
             for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, p, h, rel);
         }
     }
+    if (!__syncthreads_or(hit)) return;                 // (every application below ends with a barrier: the cell is stable here)
     L.cidx[t] = cand; L.ccx[t] = C.x; L.ccy[t] = C.y;
     const unsigned long long m = __ballot(hit);
     if ((t & 63) == 0) L.hit[t >> 6] = m;

@@ -110,6 +110,9 @@ int         ofl_event_record(void *event, void *stream);
 int         ofl_event_sync(void *event);
 int         ofl_event_elapsed_ms(void *start, void *stop, float *ms);
 int         ofl_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* host helper of the dataset loaders (load_kitti, load_sintel_mask; utils.py:426-490): PNG row un-filtering, types 0-4;
+ * raw = inflated IDAT stream (height rows of 1 filter byte + stride bytes), out [height][stride]; no device needed */
+int         ofl_png_unfilter(const uint8_t *raw, size_t raw_bytes, int height, int stride, int bpp, uint8_t *out);
 
 /* ------------------------------------------------------------------ K2: fused mode-3 composition
  * Replaces Flow.combine_with(mode=3) numerics, flow_class.py:1412-1422 (+ Flow.apply :632-684,

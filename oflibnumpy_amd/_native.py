@@ -67,6 +67,7 @@ SIGNATURES = {
     "ofl_event_sync": (_ci, [_vp]),
     "ofl_event_elapsed_ms": (_ci, [_vp, _vp, ctypes.POINTER(_cf)]),
     "ofl_mem_info": (_ci, [ctypes.POINTER(_cs), ctypes.POINTER(_cs)]),
+    "ofl_png_unfilter": (_ci, [_vp, _cs, _ci, _ci, _ci, _vp]),
     "ofl_compose3_dev": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp]),
     "ofl_compose3": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci]),
     "ofl_gather_rows_dev": (_ci, [_vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _vp]),

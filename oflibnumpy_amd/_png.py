@@ -15,6 +15,21 @@ _CHANNELS = {0: 1, 2: 3, 4: 2, 6: 4}
 
 
 def _unfilter(raw, height, stride, bpp):
+    # a real KITTI flow PNG is 1242 x 375 x 6 bytes, mostly Sub / Average / Paeth rows: the byte loop below takes
+    # seconds on it, the library's host helper milliseconds
+    try:
+        from . import _native as nat
+        lib = nat.load()
+        out = np.empty((height, stride), np.uint8)
+        buf = np.frombuffer(raw, np.uint8)
+        nat.check(lib.ofl_png_unfilter(buf.ctypes.data, buf.size, height, stride, bpp, out.ctypes.data))
+        return out
+    except ImportError:
+        pass
+    return _unfilter_py(raw, height, stride, bpp)
+
+
+def _unfilter_py(raw, height, stride, bpp):
     out = np.zeros((height, stride), np.uint8)
     prev = np.zeros(stride, np.int32)
     pos = 0

@@ -2,6 +2,7 @@
 // Plain HIP runtime calls; one process drives one GPU.
 #include "ofl_common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace ofl {
 
@@ -253,6 +254,35 @@ int ofl_event_elapsed_ms(void *start, void *stop, float *ms)
     OFL_TRY(need_device());
     if (!ms) return fail(OFL_E_INVALID, "ofl_event_elapsed_ms: NULL");
     OFL_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return OFL_OK;
+}
+
+// PNG row un-filtering (filter types 0-4 of the PNG specification) for the dataset loaders (KITTI flow PNGs, Sintel
+// invalid-pixel masks; reference utils.py:426-490 reads them with cv2.imread).  Host code: file decoding, no device.
+int ofl_png_unfilter(const uint8_t *raw, size_t raw_bytes, int height, int stride, int bpp, uint8_t *out)
+{
+    if (!raw || !out || height <= 0 || stride <= 0 || bpp <= 0) return fail(OFL_E_INVALID, "ofl_png_unfilter: bad arguments");
+    if (raw_bytes < (size_t)height * ((size_t)stride + 1)) return fail(OFL_E_INVALID, "ofl_png_unfilter: truncated image data");
+    for (int y = 0; y < height; ++y) {
+        const uint8_t *line = raw + (size_t)y * (stride + 1);
+        const int ftype = line[0];
+        ++line;
+        uint8_t *cur = out + (size_t)y * stride;
+        const uint8_t *prev = y ? cur - stride : nullptr;
+        if (ftype < 0 || ftype > 4) return fail(OFL_E_INVALID, "ofl_png_unfilter: unknown filter type %d", ftype);
+        for (int i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev ? prev[i] : 0, c = (prev && i >= bpp) ? prev[i - bpp] : 0;
+            int pred = 0;
+            if (ftype == 1) pred = a;
+            else if (ftype == 2) pred = b;
+            else if (ftype == 3) pred = (a + b) >> 1;
+            else if (ftype == 4) {
+                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            cur[i] = (uint8_t)((line[i] + pred) & 255);
+        }
+    }
     return OFL_OK;
 }
 

@@ -350,3 +350,37 @@ def test_resize_argument_validation():
         of.resize_flow('test', 1)
     with pytest.raises(ValueError):
         of.resize_flow(np.zeros((5, 5, 3)), 1)
+
+
+def test_png_reader_all_filter_types_native_equals_python(tmp_path):
+    """load_kitti / load_sintel_mask (reference utils.py:426-490, cv2.imread there) decode PNGs with zlib + a row
+    un-filter; the library's host helper (ofl_png_unfilter) and the pure-Python loop agree on every filter type, on a
+    16-bit RGB image with the row layout of a KITTI flow file."""
+    import struct
+    import zlib
+    from oflibnumpy_amd import _png
+    h, w, bpp = 23, 57, 6
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 65535, (h, w, 3)).astype('>u2')
+    rows = img.reshape(h, -1).view(np.uint8).reshape(h, -1)
+    stride = rows.shape[1]
+    raw, prev = bytearray(), np.zeros(stride, np.int32)
+    for y in range(h):
+        ft, cur = y % 5, rows[y].astype(np.int32)
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if ft == 4:
+            p = a + prev - c
+            pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        else:
+            pred = [0 * cur, a, prev, (a + prev) >> 1][ft]
+        raw.append(ft)
+        raw += bytes(((cur - pred) & 255).astype(np.uint8))
+        prev = cur
+    chunk = lambda t, b: struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+    path = str(tmp_path / "rgb16.png")
+    open(path, 'wb').write(_png._SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+    np.testing.assert_array_equal(_png.read_png(path), img.astype(np.uint16))
+    np.testing.assert_array_equal(_png._unfilter(bytes(raw), h, stride, bpp), _png._unfilter_py(bytes(raw), h, stride, bpp))

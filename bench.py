@@ -235,7 +235,7 @@ def main():
 
         worker = threading.Thread(target=exchange, daemon=True)
         worker.start()
-        worker.join(float(os.environ.get("OFL_RCCL_TIMEOUT", "180")))
+        worker.join(float(os.environ.get("OFL_RCCL_TIMEOUT", "90")))
         hung = worker.is_alive()
         rccl_note = "timed out" if hung else result.get("note", "failed")
         rccl_ranks = result.get("ranks", 0)

@@ -930,7 +930,7 @@ Sizes sizes_for(int H, int W)
     Sizes z;
     z.n = (size_t)H * W;
     z.bcap = 2 * z.n + 1024;
-    z.b1cap = z.bcap / (kMidScale * kMidScale) + 2 * (size_t)(H + W) + 4096;       // ceil per axis adds a row and a column
+    z.b1cap = z.bcap / 6 + 64;      // ceil(gx / 8) * ceil(gy / 8) <= gx gy / 64 + (gx + gy) / 8 + 1 with gx gy <= bcap, gx + gy <= bcap + 1
     z.pool_cap = 8 * z.n + 65536;
     z.big_cap = 6 * z.n + 1024;
     return z;

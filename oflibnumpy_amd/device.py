@@ -6,6 +6,10 @@ keeps vectors and mask in GPU memory between operations, so chains such as combi
 (1 scatter + 2 gathers, flow_class.py:1369-1370) never cross PCIe.  The host `Flow` class is a thin
 upload -> DeviceFlow op -> download wrapper around this module.
 
+This layer is SINGLE-STREAM: recycled buffers (`_Pool`) and the one scatter workspace per shape are handed out as soon
+as Python drops them, which is only safe while all work is queued on one stream (the library's default).  The `stream`
+arguments exist for callers that manage their own buffers at the C level.
+
 Data layout in HBM: vecs float32 [H][W][2] interleaved (x, y) -- the same layout as the reference,
 so a pixel's vector is one 8-byte element and two horizontally adjacent bilinear taps are one
 16-byte load; mask uint8 [H][W] (0/1).

@@ -21,6 +21,7 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct __attribute__((aligned(8))) Pair2 { float lo_u, lo_v, hi_u, hi_v; };   // taps (ix, ix+1) of a float2 field
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };               // a 4-byte load from any address
 
 // MI355X deals consecutive workgroups round-robin over its 8 XCDs.  Give every XCD a contiguous
 // run of tiles so that neighbouring tiles (which share gather halos) meet in the same L2.
@@ -224,17 +225,27 @@ __device__ __forceinline__ void c3_finish(const C3Args &a, size_t row, const int
                                           const float (&su)[kC3Px], const float (&sv)[kC3Px], const bool (&ok)[kC3Px],
                                           C3Stat &st)
 {
+    // Mask bytes leave as DWORDS when the row length allows aligned ones: the lane pairs (2k, 2k + 1) own four consecutive
+    // pixels, the even lane stores both lanes' bytes (sub-dword stores cost as much per instruction as 16-byte ones)
+    const bool quad = (a.W & 3) == 0 && !(a.ablate & 64);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+        const int jj = 2 * g;
+        const uint32_t mine = ((ok[jj] && bm[jj]) ? 1u : 0u) | ((ok[jj + 1] && bm[jj + 1]) ? 0x100u : 0u);
+        const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1);
         if (act[g] && !((a.ablate & 2) && su[2 * g] != 12345.0f)) {
             const int j = 2 * g;
             const float4 o4 = make_float4(__fadd_rn(bu[j], su[j]), __fadd_rn(bv[j], sv[j]),
                                           __fadd_rn(bu[j + 1], su[j + 1]), __fadd_rn(bv[j + 1], sv[j + 1]));
-            const uint16_t mo = (uint16_t)(((ok[j] && bm[j]) ? 1u : 0u) | ((ok[j + 1] && bm[j + 1]) ? 0x100u : 0u));
+            const uint16_t mo = (uint16_t)mine;
             if (OFL_C3_NT & 1) {
                 const v4f t = { o4.x, o4.y, o4.z, o4.w };
                 __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(a.out + 2 * (row + xg[g])));
-                __builtin_nontemporal_store(mo, reinterpret_cast<uint16_t *>(a.mout + row + xg[g]));
+                if (quad) {
+                    if ((threadIdx.x & 1) == 0) __builtin_nontemporal_store(mine | (other << 16), reinterpret_cast<uint32_t *>(a.mout + row + xg[g]));
+                } else {
+                    __builtin_nontemporal_store(mo, reinterpret_cast<uint16_t *>(a.mout + row + xg[g]));
+                }
             } else {
                 *reinterpret_cast<float4 *>(a.out + 2 * (row + xg[g])) = o4;
                 *reinterpret_cast<uint16_t *>(a.mout + row + xg[g]) = mo;
@@ -290,14 +301,34 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
         // interior fast path: all four taps in bounds, no clamping and no selects
         Pair2    p0[kC3Px], p1[kC3Px];
         uint32_t m0[kC3Px], m1[kC3Px];
+        // The two pixels of a pair usually sample the same two source rows at columns at most two apart (axis-aligned
+        // sampling: scalings, translations): their eight mask taps are then four bytes of each row -- ONE unaligned
+        // 4-byte load per row and pair instead of one 2-byte load per row and pixel (4 instead of 8 mask gathers per lane).
+        bool share = true;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            share = share && (!act[g] || (tp[2 * g].iy == tp[2 * g + 1].iy && (unsigned)(tp[2 * g + 1].ix - tp[2 * g].ix) <= 2u &&
+                                          tp[2 * g].ix + 3 < W));
+        share = __all(share) && !(a.ablate & 32);
 #pragma unroll
         for (int j = 0; j < kC3Px; ++j) {
             const size_t s0 = act[j >> 1] ? (size_t)tp[j].iy * W + tp[j].ix : 0;
             p0[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
             p1[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * (s0 + W));
             if (a.ablate & 16) { m0[j] = 0x0101u; m1[j] = 0x0101u; continue; }       // TA-cost probe: no mask gathers
-            m0[j] = (uint32_t)ma[s0] | ((uint32_t)ma[s0 + 1] << 8);
-            m1[j] = (uint32_t)ma[s0 + W] | ((uint32_t)ma[s0 + W + 1] << 8);
+            if (share) {
+                if ((j & 1) == 0) {
+                    m0[j] = reinterpret_cast<const U32u *>(ma + s0)->v;
+                    m1[j] = reinterpret_cast<const U32u *>(ma + s0 + W)->v;
+                } else {
+                    const int sh = act[j >> 1] ? 8 * (tp[j].ix - tp[j - 1].ix) : 0;
+                    m0[j] = m0[j - 1] >> sh;
+                    m1[j] = m1[j - 1] >> sh;
+                }
+            } else {
+                m0[j] = (uint32_t)ma[s0] | ((uint32_t)ma[s0 + 1] << 8);
+                m1[j] = (uint32_t)ma[s0 + W] | ((uint32_t)ma[s0 + W + 1] << 8);
+            }
         }
 #pragma unroll
         for (int j = 0; j < kC3Px; ++j) {

@@ -348,8 +348,11 @@ __device__ bool hull_band_locate(const float *__restrict__ flow, int sign, int H
     return inside_all;
 }
 
+#ifndef OFL_WALK_WAVES
+#define OFL_WALK_WAVES 5      // waves per SIMD the allocator leaves room for: the kernel is VALU-bound (5: 156 us, 7: 159 us, 8 spills: 246 us at 4K)
+#endif
 template <typename VT, int SP>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, OFL_WALK_WAVES)
 void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ vals, int C,
                          const uint8_t *__restrict__ vmask, int H, int W, int row0, int rows,
                          VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, WalkCert wc,

@@ -35,7 +35,9 @@ constexpr int      kRings    = 6;        // bucket rings of the per-thread star 
 constexpr int      kNearCap  = 12;       // polygon capacity of the per-thread pass (float32 cell in LDS)
 constexpr int      kSlots    = 16;       // neighbour slots per point
 constexpr int      kMidCap   = 256;      // polygon capacity of the wave pass (unfinished points against the coarse grid of unfinished points)
-constexpr int      kMidRings = 8;        // rings of that coarse grid ...
+constexpr int      kMidRings = 8;        // rings of that coarse grid every unfinished point is given ...
+constexpr int      kMidRingsMax = 160;   // ... and the rings a BOUNDED cell may go on for (rims of large holes) before it is left to the workgroup pass
+constexpr int      kFarList  = 48;       // cell vertices beyond the data (unbounded directions, sliver fans of a straight border) tested one by one
 constexpr int      kMidScale = 8;        // ... whose cells are this many fine buckets wide
 constexpr int      kFarCap   = 2560;     // polygon capacity of the workgroup pass (LDS: 20 B per vertex)
 constexpr unsigned kDegLeft  = 0xFFFFFFFFu;   // far_deg marker: not finished by the wave pass
@@ -43,6 +45,9 @@ constexpr unsigned kFarK     = 4096;     // triangle-id stride of a far point (>
 constexpr unsigned kNoOwner  = 0xFFFFFFFFu;
 constexpr int      kSmallArea = 1024;
 constexpr unsigned char kDegFar = 0xFF;
+constexpr unsigned char kDegTodo = 0xFE;  // not settled by the mesh-fan pass: the clip pass builds this star
+constexpr int      kFanSpan  = 6;        // buckets per axis a fan's circumcircles may span (wider: clip pass)
+constexpr int      kFanBlock = 128;
 constexpr int      kScanChunk = 2048;    // elements per block of the scan kernels (256 threads x 8)
 
 struct DlHead {                           // device header of the exact path (256 bytes)
@@ -50,7 +55,10 @@ struct DlHead {                           // device header of the exact path (25
     Grid     grid, grid1;                    // fine buckets (all kept points), coarse buckets (unfinished points)
     unsigned kept, n_far, n_left, pool_used, err;    // err bit 0: far polygon overflow, bit 1: pool overflow, bit 2: big list overflow
     unsigned long long big_n;
-    unsigned pad[16];
+    unsigned n_todo;                                 // points the mesh-fan pass left to the clip pass
+    unsigned pad0;
+    double   far_t2;                                 // squared distance beyond which a cell vertex counts as "far" (well outside the data)
+    unsigned pad[12];
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
 
@@ -59,7 +67,8 @@ struct DlWs {
     unsigned *bstart;      // [bcap + 1] counts -> exclusive starts
     unsigned *scan_tmp;    // block sums of the scan levels
     unsigned *sorted;      // [N] point indices bucket by bucket
-    unsigned char *deg;    // [N] 0 .. 16, kDegFar
+    unsigned char *deg;    // [N] 0 .. 16, kDegTodo, kDegFar
+    unsigned *todo_idx;    // [N] points for the clip pass, ascending
     unsigned *nbr;         // [N][kSlots]   (doubles as the bucket cursors while sorting)
     unsigned *far_idx;     // [N]
     unsigned *far_deg;     // [N]
@@ -68,6 +77,11 @@ struct DlWs {
     unsigned *b1start;     // [b1cap + 1] coarse buckets of the unfinished points
     unsigned *b1cursor;    // [b1cap]
     unsigned *sorted1;     // [N] their ranks bucket by bucket
+    P2       *sorted_xy;   // [N] positions in `sorted` order
+    P2       *sorted1_xy;  // [N] positions in `sorted1` order
+    unsigned *sorted1_pt;  // [N] point indices in `sorted1` order
+    P2       *left_xy;     // [N] positions of the left-over points, in left_idx order
+    unsigned *left_pt;     // [N] their point indices
     int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
     unsigned *big;         // [big_cap] triangle ids with a large bounding box
     uint32_t *owner;       // [H][W] (biased by the first row of the band)
@@ -155,10 +169,20 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
         y1 = fmax(y1, __hiloint2double(__shfl_xor(__double2hiint(y1), off), __shfl_xor(__double2loint(y1), off)));
         cnt += (unsigned)__shfl_xor((int)cnt, off);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        atomicMin(&head->kx0, okey(x0)); atomicMax(&head->kx1, okey(x1));
-        atomicMin(&head->ky0, okey(y0)); atomicMax(&head->ky1, okey(y1));
-        atomicAdd(&head->kept, cnt);
+    // one set of atomics per workgroup (thousands of waves on five addresses serialise at the memory side)
+    __shared__ double s_b[4][4];
+    __shared__ unsigned s_c[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_b[0][w] = x0; s_b[1][w] = x1; s_b[2][w] = y0; s_b[3][w] = y1; s_c[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned c = 0;
+        for (int k = 0; k < 4; ++k) { x0 = fmin(x0, s_b[0][k]); x1 = fmax(x1, s_b[1][k]); y0 = fmin(y0, s_b[2][k]); y1 = fmax(y1, s_b[3][k]); c += s_c[k]; }
+        if (c) {
+            atomicMin(&head->kx0, okey(x0)); atomicMax(&head->kx1, okey(x1));
+            atomicMin(&head->ky0, okey(y0)); atomicMax(&head->ky1, okey(y1));
+            atomicAdd(&head->kept, c);
+        }
     }
 }
 
@@ -180,7 +204,9 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
         }
         g.ox = x0; g.oy = y0; g.s = s; g.inv_s = 1.0 / s;
         g.gx = (int)(floor(bw / s) + 1.0); g.gy = (int)(floor(bh / s) + 1.0);
-    }
+        const double t = 8.0 * (bw + bh) + 8.0 * s;
+        head->far_t2 = t * t;
+    } else head->far_t2 = 1.0;
     head->grid = g;
     Grid g1 = g;                                     // coarse grid of the unfinished points: kMidScale fine buckets per cell
     g1.s = g.s * kMidScale; g1.inv_s = 1.0 / g1.s;
@@ -280,40 +306,101 @@ void dl_sort_kernel(const DlHead *__restrict__ head, int coarse, const unsigned 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ stars, near pass
+// positions (and point indices) in the order of a list: MODE 0 `list` holds point indices, 1 ranks into far_idx, 2 indices
+// into left_idx (ranks of ranks)
+template <int MODE>
+__global__ __launch_bounds__(256)
+void dl_list_xy_kernel(const float *__restrict__ flow, int sign, int W, const DlHead *__restrict__ head,
+                       const unsigned *__restrict__ list, const unsigned *__restrict__ far_idx,
+                       P2 *__restrict__ xy, unsigned *__restrict__ pt)
+{
+    const unsigned n = MODE == 0 ? head->kept : (MODE == 1 ? head->n_far : head->n_left);
+    const PosFn pos(flow, sign, W);
+    for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const unsigned i = MODE == 0 ? list[j] : far_idx[list[j]];
+        xy[j] = pos((int)i);
+        if (pt) pt[j] = i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stars, mesh-fan pass
+// One thread per point: a point whose eight grid neighbours are kept proposes the star of the cell-wise mesh and verifies
+// it against the sites under its circumcircles (ofl_dl::star_fan).  Verified stars are final; everything else is marked
+// for the clip pass.
+__global__ __launch_bounds__(kFanBlock)
+void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                        const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
+                        const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                        unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
+{
+    __shared__ P2 s_rel[8][kFanBlock];
+    const size_t p = (size_t)blockIdx.x * kFanBlock + threadIdx.x;
+    if (p >= (size_t)H * W) return;
+    if (!kept_pt(pmask, p)) { deg[p] = 0; return; }
+    const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
+    bool intact = x >= 1 && y >= 1 && x <= W - 2 && y <= H - 2;
+    if (intact && pmask) {
+        const uint8_t *m = pmask + p;
+        intact = m[-W - 1] && m[-W] && m[-W + 1] && m[-1] && m[1] && m[W - 1] && m[W] && m[W + 1];
+    }
+    int n = 0;
+    if (intact) {
+        const Grid g = head->grid;
+        const PosFn pos(flow, sign, W);
+        n = star_fan((int)p, W, pos((int)p), pos, g, bstart, sorted, sorted_xy, kFanSpan, &s_rel[0][threadIdx.x], kFanBlock,
+                     nbr + p * kSlots);
+    }
+    deg[p] = n > 0 ? (unsigned char)n : kDegTodo;
+}
+
+// ------------------------------------------------------------------------------------------------ stars, clip pass (near)
 __global__ __launch_bounds__(64)
-void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
-                         const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
-                         const unsigned *__restrict__ sorted, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
+void dl_star_near_kernel(const float *__restrict__ flow, int sign, int H, int W,
+                         const DlHead *__restrict__ head, const unsigned *__restrict__ todo,
+                         const unsigned *__restrict__ bstart,
+                         const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
     __shared__ float s_vx[kNearCap][64], s_vy[kNearCap][64];
     __shared__ int   s_tag[kNearCap][64];
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (p >= (size_t)H * W) return;
-    if (!kept_pt(pmask, p)) { deg[p] = 0; return; }
+    const unsigned n_todo = head->n_todo;
     const Grid g = head->grid;
     const PosFn pos(flow, sign, W);
-    PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
-    const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings);
-    bool ok = rc == 1;
-    for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
-    if (!ok) { deg[p] = kDegFar; return; }
-    deg[p] = (unsigned char)P.n;
-    for (int k = 0; k < P.n; ++k) nbr[p * kSlots + k] = (unsigned)P.T(k);
+    for (unsigned base = blockIdx.x * 64; base < n_todo; base += gridDim.x * 64) {
+        if (base + threadIdx.x >= n_todo) return;
+        const size_t p = todo[base + threadIdx.x];
+        PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
+        const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings, sorted_xy);
+        bool ok = rc == 1;
+        for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
+        if (!ok) {
+            // unfinished: the sites that bound the cell so far seed the cooperative passes (slot 0 will hold the point's
+            // rank, slot 1 the number of seeds) -- applied first, they spare those passes most of their clips
+            deg[p] = kDegFar;
+            unsigned c = 0;
+            for (int k = 0; k < P.n; ++k) if (P.T(k) >= 0) nbr[p * kSlots + 2 + c++] = (unsigned)P.T(k);
+            nbr[p * kSlots + 1] = c;
+            continue;
+        }
+        deg[p] = (unsigned char)P.n;
+        for (int k = 0; k < P.n; ++k) nbr[p * kSlots + k] = (unsigned)P.T(k);
+    }
 }
 
-// compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx
+// compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx,
+// MODE 2 = points with deg == kDegTodo -> todo_idx
 template <int MODE>
 __device__ __forceinline__ bool flagged(const void *src, size_t i)
 {
-    return MODE == 0 ? ((const unsigned char *)src)[i] == kDegFar : ((const unsigned *)src)[i] == kDegLeft;
+    return MODE == 0 ? ((const unsigned char *)src)[i] == kDegFar
+         : MODE == 2 ? ((const unsigned char *)src)[i] == kDegTodo : ((const unsigned *)src)[i] == kDegLeft;
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256)
 void dl_flag_count_kernel(const void *__restrict__ src, const DlHead *__restrict__ head, size_t n_fixed, unsigned *__restrict__ cnt)
 {
-    const size_t n = MODE == 0 ? n_fixed : head->n_far;
+    const size_t n = MODE != 1 ? n_fixed : head->n_far;
     const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
 #pragma unroll
@@ -328,7 +415,7 @@ __global__ __launch_bounds__(256)
 void dl_flag_write_kernel(const void *__restrict__ src, DlHead *head, size_t n_fixed, const unsigned *__restrict__ offs,
                           unsigned *__restrict__ list, unsigned last_block, unsigned *__restrict__ rank_of)
 {
-    const size_t n = MODE == 0 ? n_fixed : head->n_far;
+    const size_t n = MODE != 1 ? n_fixed : head->n_far;
     const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
 #pragma unroll
@@ -341,7 +428,10 @@ void dl_flag_write_kernel(const void *__restrict__ src, DlHead *head, size_t n_f
             if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
             list[at++] = (unsigned)(base + k);
         }
-    if (blockIdx.x == last_block && threadIdx.x == 0) { if (MODE == 0) head->n_far = offs[blockIdx.x] + total; else head->n_left = offs[blockIdx.x] + total; }
+    if (blockIdx.x == last_block && threadIdx.x == 0) {
+        const unsigned cnt = offs[blockIdx.x] + total;
+        if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else head->n_todo = cnt;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ stars, cooperative passes
@@ -361,11 +451,24 @@ struct FarLds {
     int    cidx[NT];
     double ccx[NT], ccy[NT];
     unsigned long long hit[NT / 64];
-    double wmax[NT / 64];
+    double wmax[NT / 64], wfar[NT / 64];
     unsigned run_lo[64];       // candidate runs of the current step (ranges of a sorted list) ...
     int    run_pre[65];        // ... and the exclusive prefix of their lengths
     int    n, a, ncut, status;
-    double reach2;             // (2 * farthest vertex)^2 of the current cell: sites beyond it cannot cut
+    // Candidate rejection: a site can only cut a vertex v if it is closer than 2 |v| to the cell's site.  Vertices well
+    // outside the data (|v|^2 > t2: the box vertices of an unbounded cell, the circumcentres of sliver triangles along a
+    // straight border) would make that radius useless, so they are listed and tested one by one; reach2 covers the rest.
+    double reach2;             // (2 * farthest NEAR vertex)^2; 1e300 when the far list overflowed (every vertex is tested)
+    double t2;
+    int    nfar;
+    int    farlist[kFarList];
+    // The far vertices of a convex cell are ONE run of the polygon, seen from the site inside a cone of directions (the
+    // outward normal cone of a hull point).  When the run [f0, f1] spans less than a half turn, v . c over the run is
+    // bounded by its two ends, and a site whose direction lies outside the cone with
+    // max(v0 . c / |v0|, v1 . c / |v1|) * vmax < |c|^2 / 2 (minus the margin of vertex_cut) cuts none of them: two dot
+    // products instead of the list.  cone = 0 when the run is not unique or too wide.
+    int    cone, nrun, f0, f1;
+    double c0x, c0y, c1x, c1y, vmax;     // unit directions of the run's ends, largest |v| in it
 };
 
 template <int CAP, int NT>
@@ -393,6 +496,57 @@ __device__ void far_shift(FarLds<CAP, NT> &L, int s0, int s1, int d0)
             __syncthreads();
         }
     }
+}
+
+// reach, far list and far cone of the current cell; all threads, ends with a barrier
+template <int CAP, int NT>
+__device__ void far_refresh(FarLds<CAP, NT> &L)
+{
+    const int t = threadIdx.x, n = L.n;
+    const double t2 = L.t2;
+    if (t == 0) { L.nfar = 0; L.nrun = 0; L.f0 = 0; L.f1 = 0; }
+    __syncthreads();
+    double r2 = 0.0, f2 = 0.0;
+    for (int k = t; k < n; k += NT) {
+        const double v2 = L.vx[k] * L.vx[k] + L.vy[k] * L.vy[k];
+        const bool far = v2 > t2;
+        L.cut[k] = far ? 1 : 0;                           // (far_apply rewrites the flags before it reads them)
+        if (far) { const int slot = atomicAdd(&L.nfar, 1); if (slot < kFarList) L.farlist[slot] = k; f2 = fmax(f2, v2); }
+        else r2 = fmax(r2, v2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r2 = fmax(r2, __hiloint2double(__shfl_xor(__double2hiint(r2), off), __shfl_xor(__double2loint(r2), off)));
+        f2 = fmax(f2, __hiloint2double(__shfl_xor(__double2hiint(f2), off), __shfl_xor(__double2loint(f2), off)));
+    }
+    if (NT > 64) { if ((t & 63) == 0) { L.wmax[t >> 6] = r2; L.wfar[t >> 6] = f2; } }
+    __syncthreads();
+    for (int k = t; k < n; k += NT)
+        if (L.cut[k]) {
+            if (!L.cut[k == 0 ? n - 1 : k - 1]) { atomicAdd(&L.nrun, 1); L.f0 = k; }
+            if (!L.cut[k + 1 == n ? 0 : k + 1]) L.f1 = k;
+        }
+    __syncthreads();
+    if (t == 0) {
+        double m = r2, fm = f2;
+        if (NT > 64) { m = 0.0; fm = 0.0; for (int w = 0; w < NT / 64; ++w) { m = fmax(m, L.wmax[w]); fm = fmax(fm, L.wfar[w]); } }
+        const bool listed = L.nfar <= kFarList;
+        L.reach2 = 4.0 * m;
+        L.cone = 0;
+        if (L.nfar > 0 && L.nrun == 1) {
+            const double ax = L.vx[L.f0], ay = L.vy[L.f0], bx = L.vx[L.f1], by = L.vy[L.f1];
+            const double na = sqrt(ax * ax + ay * ay), nb = sqrt(bx * bx + by * by);
+            const double c0x = ax / na, c0y = ay / na, c1x = bx / nb, c1y = by / nb;
+            // counter-clockwise from f0 to f1 by less than a half turn, with room to spare (or a single far vertex)
+            if (L.f0 == L.f1 || (c0x * c1y - c0y * c1x > 1e-6 || (c0x * c1x + c0y * c1y > 0.5 && c0x * c1y - c0y * c1x >= 0.0))) {
+                L.c0x = c0x; L.c0y = c0y; L.c1x = c1x; L.c1y = c1y; L.vmax = sqrt(fm);
+                L.cone = isfinite(L.vmax) ? 1 : 0;
+            }
+        }
+        if (!listed && !L.cone) L.reach2 = 1e300;         // neither a list nor a cone: every vertex is tested
+        else if (!listed) L.nfar = -L.nfar;              // a cone without a list: sites the cone cannot reject test every vertex
+    }
+    __syncthreads();
 }
 
 template <int CAP, int NT, class RelFn>
@@ -440,40 +594,34 @@ __device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, R
     }
     if (t == 0) L.n = n2;
     __syncthreads();
-    {
-        // the cell shrank: new reach (every thread scans its share, one wave-level then LDS-level maximum)
-        double r2 = 0.0;
-        for (int k = t; k < n2; k += NT) r2 = fmax(r2, L.vx[k] * L.vx[k] + L.vy[k] * L.vy[k]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            r2 = fmax(r2, __hiloint2double(__shfl_xor(__double2hiint(r2), off), __shfl_xor(__double2loint(r2), off)));
-        if (NT == 64) { if (t == 0) L.reach2 = 4.0 * r2; }
-        else {
-            if ((t & 63) == 0) L.wmax[t >> 6] = r2;
-            __syncthreads();
-            if (t == 0) { double m = 0.0; for (int w = 0; w < NT / 64; ++w) m = fmax(m, L.wmax[w]); L.reach2 = 4.0 * m; }
-        }
-        __syncthreads();
-    }
+    far_refresh(L);
 }
 
 // one chunk of up to NT candidates (thread t holds candidate cand, or -1).  Most chunks cut nothing: they cost ONE barrier
 // (the vote), the cell is only touched -- and the workgroup only synchronises further -- when some candidate cuts it.
 template <int CAP, int NT, class RelFn>
-__device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const PosFn &pos, RelFn rel)
+__device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const P2 &q, RelFn rel)
 {
     const int t = threadIdx.x;
     bool hit = false;
     P2 C{ 0.0, 0.0 };
     if (cand >= 0 && cand != p) {
-        const P2 q = pos(cand);
         C.x = q.x - pp.x; C.y = q.y - pp.y;
         const double d2 = C.x * C.x + C.y * C.y;
-        if (d2 != 0.0 && d2 < L.reach2) {
+        if (d2 != 0.0) {
             const int n = L.n;
-            const double h = 0.5 * (C.x * C.x + C.y * C.y);
+            const double h = 0.5 * d2;
             Poly P{ L.vx, L.vy, L.tag, 1, CAP, n };
-            for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, p, h, rel);
+            bool all = d2 < L.reach2, some = !all && L.nfar != 0;
+            if (some && L.cone) {
+                const double len = sqrt(d2), ux = C.x / len, uy = C.y / len;
+                const double m0 = L.c0x * ux + L.c0y * uy, m1 = L.c1x * ux + L.c1y * uy;
+                const bool inside = L.c0x * uy - L.c0y * ux >= 0.0 && ux * L.c1y - uy * L.c1x >= 0.0;
+                if (!inside && fmax(fmax(m0, m1), 0.0) + 2e-9 < 0.999 * len / (2.0 * L.vmax)) some = false;
+            }
+            if (some && L.nfar < 0) { all = true; some = false; }
+            if (all) { for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, p, h, rel); }
+            else if (some) { const int nf = L.nfar; for (int i = 0; i < nf && !hit; ++i) hit = vertex_cut(P, L.farlist[i], n, C, cand, p, h, rel); }
         }
     }
     if (!__syncthreads_or(hit)) return;                 // (every application below ends with a barrier: the cell is stable here)
@@ -494,8 +642,9 @@ __device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, con
 
 // The runs in L.run_lo / L.run_pre (lengths, turned into a prefix here) are walked as ONE dense list, NT candidates per
 // step; `map` turns an entry of the sorted list into a point index.
-template <int CAP, int NT, class RelFn, class MapFn>
-__device__ void far_dense(FarLds<CAP, NT> &L, int p, const P2 &pp, int nruns, const PosFn &pos, RelFn rel, MapFn map)
+template <int CAP, int NT, class RelFn>
+__device__ void far_dense(FarLds<CAP, NT> &L, int p, const P2 &pp, int nruns, RelFn rel,
+                          const unsigned *__restrict__ list_pt, const P2 *__restrict__ list_xy)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -508,12 +657,15 @@ __device__ void far_dense(FarLds<CAP, NT> &L, int p, const P2 &pp, int nruns, co
     for (int base = 0; base < total; base += NT) {
         const int gidx = base + (int)threadIdx.x;
         int cand = -1;
+        P2 q{ 0.0, 0.0 };
         if (gidx < total) {
             int r = 0;
             while (L.run_pre[r + 1] <= gidx) ++r;
-            cand = map(L.run_lo[r] + (unsigned)(gidx - L.run_pre[r]));
+            const unsigned j = L.run_lo[r] + (unsigned)(gidx - L.run_pre[r]);
+            cand = (int)list_pt[j];
+            q = list_xy[j];
         }
-        far_chunk(L, p, pp, cand, pos, rel);
+        far_chunk(L, p, pp, cand, q, rel);
     }
 }
 
@@ -534,19 +686,19 @@ __device__ __forceinline__ void far_set_run(FarLds<CAP, NT> &L, int slot, const 
 // candidates of the fine buckets within kRings of the point's bucket
 template <int CAP, int NT, class RelFn>
 __device__ void far_near_rows(FarLds<CAP, NT> &L, int p, const P2 &pp, const Grid &g, const unsigned *__restrict__ bstart,
-                              const unsigned *__restrict__ sorted, const PosFn &pos, RelFn rel)
+                              const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy, RelFn rel)
 {
     const int t = threadIdx.x, bx = g.bx(pp.x), by = g.by(pp.y);
     __syncthreads();
     if (t <= 2 * kRings) far_set_run(L, t, g, bstart, by - kRings + t, bx - kRings, bx + kRings);
-    far_dense(L, p, pp, 2 * kRings + 1, pos, rel, [&](unsigned j) { return (int)sorted[j]; });
+    far_dense(L, p, pp, 2 * kRings + 1, rel, sorted, sorted_xy);
 }
 
 // ring r of the coarse grid (r0 == r1) or the whole square of rings r0 .. r1 row by row: unfinished points (ranks -> point indices)
 template <int CAP, int NT, class RelFn>
 __device__ void far_coarse_rings(FarLds<CAP, NT> &L, int p, const P2 &pp, int r0, int r1, const Grid &g1,
-                                 const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
-                                 const unsigned *__restrict__ far_idx, const PosFn &pos, RelFn rel)
+                                 const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt,
+                                 const P2 *__restrict__ sorted1_xy, RelFn rel)
 {
     const int t = threadIdx.x, bx = g1.bx(pp.x), by = g1.by(pp.y);
     int nruns;
@@ -555,16 +707,34 @@ __device__ void far_coarse_rings(FarLds<CAP, NT> &L, int p, const P2 &pp, int r0
         nruns = 2 * r1 + 1;
         if (t < nruns) far_set_run(L, t, g1, b1start, by - r1 + t, bx - r1, bx + r1);
     } else {                                        // the ring alone: top and bottom rows, then the two end cells of the rows between
-        const int r = r0;
-        nruns = 2 + 2 * (2 * r - 1);
-        if (t == 0) far_set_run(L, 0, g1, b1start, by - r, bx - r, bx + r);
-        else if (t == 1) far_set_run(L, 1, g1, b1start, by + r, bx - r, bx + r);
-        else if (t < nruns) {
-            const int m = t - 2, row = by - r + 1 + (m >> 1), col = (m & 1) ? bx + r : bx - r;
-            far_set_run(L, t, g1, b1start, row, col, (col < 0 || col > g1.gx - 1) ? col - 1 : col);
+        const int r = r0, total = 2 + 2 * (2 * r - 1);
+        for (int b0 = 0; b0 < total; b0 += 64) {    // (a wide ring has more runs than the run list holds)
+            const int cnt = min(64, total - b0);
+            __syncthreads();
+            if (t < cnt) {
+                const int i = b0 + t;
+                if (i == 0) far_set_run(L, t, g1, b1start, by - r, bx - r, bx + r);
+                else if (i == 1) far_set_run(L, t, g1, b1start, by + r, bx - r, bx + r);
+                else {
+                    const int m = i - 2, row = by - r + 1 + (m >> 1), col = (m & 1) ? bx + r : bx - r;
+                    far_set_run(L, t, g1, b1start, row, col, (col < 0 || col > g1.gx - 1) ? col - 1 : col);
+                }
+            }
+            far_dense(L, p, pp, cnt, rel, sorted1_pt, sorted1_xy);
         }
+        return;
     }
-    far_dense(L, p, pp, nruns, pos, rel, [&](unsigned j) { return (int)far_idx[sorted1[j]]; });
+    far_dense(L, p, pp, nruns, rel, sorted1_pt, sorted1_xy);
+}
+
+// the sites the per-thread pass left in the point's neighbour slots: one chunk, applied before anything else
+template <int CAP, int NT, class RelFn>
+__device__ void far_seeds(FarLds<CAP, NT> &L, int p, const P2 &pp, const unsigned *__restrict__ nbr, const PosFn &pos, RelFn rel)
+{
+    const unsigned *sd = nbr + (size_t)p * kSlots;
+    const int ns = min((int)sd[1], kSlots - 2), t = threadIdx.x;
+    const int cand = t < ns ? (int)sd[2 + t] : -1;
+    far_chunk(L, p, pp, cand, cand >= 0 ? pos(cand) : pp, rel);
 }
 
 template <int CAP, int NT>
@@ -588,9 +758,9 @@ __device__ void far_store(FarLds<CAP, NT> &L, unsigned rank, DlHead *head, unsig
 
 __global__ __launch_bounds__(64)
 void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
-                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted,
-                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
-                        const unsigned *__restrict__ far_idx, unsigned *__restrict__ far_deg,
+                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
+                        const unsigned *__restrict__ far_idx, const unsigned *__restrict__ nbr, unsigned *__restrict__ far_deg,
                         unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
 {
     __shared__ FarLds<kMidCap, 64> L;
@@ -606,16 +776,25 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     if (t == 0) {
         Poly P{ L.vx, L.vy, L.tag, 1, kMidCap, 0 };
         poly_init(P);
-        L.n = P.n; L.status = 0; L.reach2 = 1e300;
+        L.n = P.n; L.status = 0; L.t2 = head->far_t2;
     }
     __syncthreads();
-    far_near_rows(L, p, pp, g, bstart, sorted, pos, rel);
+    far_refresh(L);
+    far_seeds(L, p, pp, nbr, pos, rel);
+    far_near_rows(L, p, pp, g, bstart, sorted, sorted_xy, rel);
+    // Rings of the coarse grid until the cell is final: every unfinished point within twice its farthest vertex has been
+    // applied -- points in unvisited coarse cells are at least r * s1 away (finished points farther than the fine rings
+    // cannot be neighbours: they would not have finished) -- or the rings have left the grid.  Points of the image border
+    // are hull points more often than not (their cells never close): they stop after kMidRings and go to the workgroup
+    // pass; the others -- rims of holes and tears, whose cells close once the far side has been applied -- go on.
+    const int py = (int)((unsigned)p / (unsigned)W), px = p - py * W;
+    const bool likely_hull = px == 0 || py == 0 || px == W - 1 || py == H - 1;
+    const int rmax = likely_hull ? kMidRings : kMidRingsMax;
+    const int cbx = g1.bx(pp.x), cby = g1.by(pp.y);
+    const int rgrid = max(max(cbx, g1.gx - 1 - cbx), max(cby, g1.gy - 1 - cby));
     bool done = false;
-    for (int r = 0; r <= kMidRings && !done; ++r) {
-        far_coarse_rings(L, p, pp, r, r, g1, b1start, sorted1, far_idx, pos, rel);
-        // the cell is final once every unfinished point within twice its farthest vertex has been applied: points in
-        // unvisited coarse cells are at least r * s1 away (finished points farther than the fine rings cannot be
-        // neighbours: they would not have finished)
+    for (int r = 0; r <= rmax && !done; ++r) {
+        far_coarse_rings(L, p, pp, r, r, g1, b1start, sorted1_pt, sorted1_xy, rel);
         double r2 = 0.0;
         const int n = L.n;
         for (int k = t; k < n; k += 64) r2 = fmax(r2, L.vx[k] * L.vx[k] + L.vy[k] * L.vy[k]);
@@ -623,7 +802,7 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
         for (int off = 32; off > 0; off >>= 1)
             r2 = fmax(r2, __hiloint2double(__shfl_xor(__double2hiint(r2), off), __shfl_xor(__double2loint(r2), off)));
         const double cover = (double)r * g1.s;
-        done = cover * cover >= 4.0 * r2;
+        done = cover * cover >= 4.0 * r2 || r >= rgrid;
         if (L.status) break;
     }
     __syncthreads();
@@ -634,9 +813,10 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
 template <int CAP>          // first with a small cell capacity (several workgroups per CU), then -- for the few fans that overflowed it -- the large one
 __global__ __launch_bounds__(256)
 void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
-                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted,
-                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1,
+                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
                         const unsigned *__restrict__ far_idx, const unsigned *__restrict__ left_idx,
+                        const unsigned *__restrict__ left_pt, const P2 *__restrict__ left_xy, const unsigned *__restrict__ nbr,
                         unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
                         unsigned long long pool_cap)
 {
@@ -655,13 +835,17 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     if (t == 0) {
         Poly P{ L.vx, L.vy, L.tag, 1, CAP, 0 };
         poly_init(P);
-        L.n = P.n; L.status = 0; L.reach2 = 1e300;
+        L.n = P.n; L.status = 0; L.t2 = head->far_t2;
     }
     __syncthreads();
-    far_near_rows(L, p, pp, g, bstart, sorted, pos, rel);
-    far_coarse_rings(L, p, pp, 0, kMidRings, g1, b1start, sorted1, far_idx, pos, rel);
-    for (unsigned base = 0; base < n_left; base += 256)
-        far_chunk(L, p, pp, base + t < n_left ? (int)far_idx[left_idx[base + t]] : -1, pos, rel);
+    far_refresh(L);
+    far_seeds(L, p, pp, nbr, pos, rel);
+    far_near_rows(L, p, pp, g, bstart, sorted, sorted_xy, rel);
+    far_coarse_rings(L, p, pp, 0, kMidRings, g1, b1start, sorted1_pt, sorted1_xy, rel);
+    for (unsigned base = 0; base < n_left; base += 256) {
+        const bool in = base + t < n_left;
+        far_chunk(L, p, pp, in ? (int)left_pt[base + t] : -1, in ? left_xy[base + t] : pp, rel);
+    }
     __syncthreads();
     if (CAP < kFarCap && L.status) return;               // overflow of the small capacity: far_deg stays kDegLeft for the next pass
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
@@ -948,6 +1132,7 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.scan_tmp = (unsigned *)p;            p += align_up(scan_tmp_elems(ws.bcap + 1) * 4, 256);
     ws.sorted = (unsigned *)p;              p += align_up(n * 4, 256);
     ws.deg = (unsigned char *)p;            p += align_up(n, 256);
+    ws.todo_idx = (unsigned *)p;            p += align_up(n * 4, 256);
     ws.nbr = (unsigned *)p;                 p += align_up(std::max(n * kSlots, ws.bcap) * 4, 256);
     ws.far_idx = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_deg = (unsigned *)p;             p += align_up(n * 4, 256);
@@ -956,6 +1141,11 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.b1start = (unsigned *)p;             p += align_up((ws.b1cap + 1) * 4, 256);
     ws.b1cursor = (unsigned *)p;            p += align_up(ws.b1cap * 4, 256);
     ws.sorted1 = (unsigned *)p;             p += align_up(n * 4, 256);
+    ws.sorted_xy = (P2 *)p;                 p += align_up(n * 16, 256);
+    ws.sorted1_xy = (P2 *)p;                p += align_up(n * 16, 256);
+    ws.sorted1_pt = (unsigned *)p;          p += align_up(n * 4, 256);
+    ws.left_xy = (P2 *)p;                   p += align_up(n * 16, 256);
+    ws.left_pt = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
     ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
@@ -1018,7 +1208,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     OFL_HIP(hipMemsetAsync(ws.bstart, 0, (ws.bcap + 1) * 4, s));
     OFL_HIP(hipMemsetAsync(ws.nbr, 0, ws.bcap * 4, s));                 // bucket cursors
     const unsigned nblk = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 2048 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
+    hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 1024 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
     static const double bucket_scale = getenv("OFL_DL_BUCKET") ? atof(getenv("OFL_DL_BUCKET")) : 1.0;      // development knob
     hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale);
     hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart);
@@ -1028,12 +1218,23 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        (const unsigned *)ws.bstart, ws.nbr, ws.sorted);
     hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
                        (const DlHead *)ws.head, 0, (const unsigned *)ws.bstart, ws.sorted);
-    hipLaunchKernelGGL(dl_star_near_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, flow, sign_pp, pmask, H, W,
-                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, ws.deg, ws.nbr);
-    OFL_HIP(hipGetLastError());
-    // unfinished points in index order
+    hipLaunchKernelGGL(dl_list_xy_kernel<0>, dim3(std::min<unsigned>(nblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
+                       (const unsigned *)ws.sorted, (const unsigned *)nullptr, ws.sorted_xy, (unsigned *)nullptr);
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
     unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
+    hipLaunchKernelGGL(dl_star_fan_kernel, dim3((unsigned)((n + kFanBlock - 1) / kFanBlock)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
+                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
+                       ws.deg, ws.nbr);
+    // what the fans did not settle, in index order, for the clip pass
+    hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const DlHead *)ws.head, n, fcnt);
+    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
+    hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, ws.head, n, (const unsigned *)fcnt,
+                       ws.todo_idx, fblk - 1, (unsigned *)nullptr);
+    hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, H, W,
+                       (const DlHead *)ws.head, (const unsigned *)ws.todo_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
+                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr);
+    OFL_HIP(hipGetLastError());
+    // unfinished points in index order
     hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
     hipLaunchKernelGGL(dl_flag_write_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, ws.head, n, (const unsigned *)fcnt,
@@ -1043,6 +1244,8 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
     OFL_HIP(hipStreamSynchronize(s));
     if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = 0; }
+    static const bool debug = getenv("OFL_DL_DEBUG") != nullptr;                 // development aid
+    if (debug) fprintf(stderr, "[ofl exact] kept %u, clip pass %u, unfinished %u\n", h.kept, h.n_todo, h.n_far);
     if (h.kept == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
     const unsigned long long far_base = (unsigned long long)n * kSlots;
     if (far_base + (unsigned long long)h.n_far * kFarK >= 0xFFFFFFF0ull)
@@ -1059,9 +1262,11 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                            (const unsigned *)ws.far_idx, (const unsigned *)ws.b1start, ws.b1cursor, ws.sorted1);
         hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.b1cap + 255) / 256), 65535u)), dim3(256), 0, s,
                            (const DlHead *)ws.head, 1, (const unsigned *)ws.b1start, ws.sorted1);
+        hipLaunchKernelGGL(dl_list_xy_kernel<1>, dim3(std::min<unsigned>(rblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
+                           (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, ws.sorted1_xy, ws.sorted1_pt);
         hipLaunchKernelGGL(dl_star_mid_kernel, dim3(h.n_far), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
-                           (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.b1start,
-                           (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, ws.far_deg, ws.far_off, ws.pool,
+                           (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
+                           (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
                            (unsigned long long)ws.pool_cap);
         OFL_HIP(hipGetLastError());
         const unsigned lblk = (h.n_far + kScanChunk - 1) / kScanChunk;
@@ -1075,13 +1280,17 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         OFL_HIP(hipStreamSynchronize(s));
         if (info_host) info_host[2] = h.n_left;
         if (h.n_left) {
+            hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(std::min<unsigned>((h.n_left + 255) / 256, 65535u)), dim3(256), 0, s, flow, sign_pp, W,
+                               (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
             hipLaunchKernelGGL(dl_star_far_kernel<512>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
-                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.b1start,
-                               (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
+                               (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const unsigned *)ws.nbr,
                                ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
             hipLaunchKernelGGL(dl_star_far_kernel<kFarCap>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
-                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const unsigned *)ws.b1start,
-                               (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
+                               (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const unsigned *)ws.nbr,
                                ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
             OFL_HIP(hipGetLastError());
         }

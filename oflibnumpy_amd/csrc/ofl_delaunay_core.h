@@ -204,7 +204,8 @@ struct Grid {
 // cut any vertex (|v - c| < |v| implies |c| < 2 |v|), which spares the vertex loop for most sites of the outer rings.
 template <class PolyX, class PosFn>
 DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const Grid &g,
-                     const unsigned *bstart, const unsigned *sorted, PosFn pos, double &reach2)
+                     const unsigned *bstart, const unsigned *sorted, PosFn pos, double &reach2,
+                     const P2 *sorted_xy = nullptr)          // positions in `sorted` order (one contiguous read per run) or null
 {
     auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
     auto run = [&](int row, int x0, int x1) -> int {
@@ -220,7 +221,7 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
 #pragma unroll
             for (int k = 0; k < 4; ++k) c[k] = j + k < hi ? (int)sorted[j + k] : -1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = c[k] >= 0 ? pos(c[k]) : pp;
+            for (int k = 0; k < 4; ++k) q[k] = c[k] >= 0 ? (sorted_xy ? sorted_xy[j + k] : pos(c[k])) : pp;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (c[k] < 0 || c[k] == p) continue;
@@ -248,17 +249,191 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
 // not (unbounded cells, rims of large holes: the far pass finishes those), -1 when the polygon overflowed.
 template <class PolyX, class PosFn>
 DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
-                    PosFn pos, int rings)
+                    PosFn pos, int rings, const P2 *sorted_xy = nullptr)
 {
     poly_init(P);
     const int bx = g.bx(pp.x), by = g.by(pp.y);
     double reach2 = 4.0 * poly_rmax2(P);
     for (int r = 0; r <= rings; ++r) {
-        if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2) < 0) return -1;
+        if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy) < 0) return -1;
         const double cover = (double)r * g.s;
         if (cover * cover >= reach2) return 1;
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ mesh fan
+// Most sites of a warped grid sit in an intact neighbourhood: their eight grid neighbours are kept and the cell-wise
+// mesh around them is locally the Delaunay triangulation.  For such a site the star need not be BUILT, only VERIFIED:
+// the mesh proposes a fan (the four axis neighbours, plus the diagonal neighbour of every surrounding cell whose
+// Delaunay diagonal passes through the site), and a fan of counter-clockwise triangles that winds around the site once
+// and whose circumcircles hold no other site IS the site's Delaunay star (empty-circle property; the triangles of a
+// triangulation around a vertex are unique).  Emptiness is tested against the sites of the buckets under the
+// circumcircles -- sites of other sheets of a folded field are found there like any other -- with three fused
+// multiply-adds per (site, triangle) and the in-circle predicate of the clip path only inside a rounding margin.
+// Anything else (a missing neighbour, a site inside a circle, wide circles, a clockwise triangle) returns 0 and the
+// site takes the clip path; so the fan never changes WHAT is computed, only how fast.
+//
+// Slots 0 .. 7 = grid neighbours E, SE, S, SW, W, NW, N, NE (x right, y down: counter-clockwise in the Poly convention).
+// Cell c (0 .. 3) lies between the axis slots 2c and 2c + 2 and owns the diagonal slot 2c + 1.  Which diagonal splits
+// a cell is decided from the cell's smallest-index corner a (corners a, b, c, d around the cell): a-c exists iff c is
+// inside circle(a, b, d), ties to a-c -- every corner of the cell evaluates the same expression on the same numbers, so
+// the four stars agree bit for bit, and ties fall the way the certified path and vertex_cut break them.
+// index offset of grid-neighbour slot s without a table (dx + 1 / dy + 1 of the eight slots, two bits each)
+DL_HD int slot_offset(int s, int W)
+{
+    const int dx = (int)((0x901Au >> (2 * s)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * s)) & 3u) - 1;
+    return dx + dy * W;
+}
+
+constexpr double kFanEps  = 1e-13;       // relative margin of the float64 three-term in-circle sum (its rounding error is ~1e-15)
+constexpr float  kFanEpsF = 2e-5f;       // ... and of its float32 version (inputs rounded to float32: ~1e-6)
+
+template <class PosFn>
+DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, const Grid &g, const unsigned *bstart,
+                   const unsigned *sorted, const P2 *sorted_xy, int max_span,
+                   P2 *nrel, int nstride,                     // scratch: relative positions of the eight slots
+                   unsigned *nbr_out)                         // the star, counter-clockwise (4 .. 8 sites)
+{
+    const int off[8] = { 1, W + 1, W, W - 1, -1, -W - 1, -W, -W + 1 };
+    P2 Q[8];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+    for (int s = 0; s < 8; ++s) Q[s] = pos(p + off[s]);
+    // diagonals: cell 0 (a = p, b = E, c = SE, d = S), cell 1 (a = W, b = p, c = S, d = SW),
+    //            cell 2 (a = NW, b = N, c = p, d = W), cell 3 (a = N, b = NE, c = E, d = p)
+    auto ac = [](const P2 &A, const P2 &B, const P2 &C, const P2 &D) {
+        return incircle_origin(P2{ B.x - A.x, B.y - A.y }, P2{ D.x - A.x, D.y - A.y }, P2{ C.x - A.x, C.y - A.y }) >= 0.0;
+    };
+    bool present[8];
+    present[0] = present[2] = present[4] = present[6] = true;
+    present[1] = ac(pp, Q[0], Q[1], Q[2]);
+    present[3] = !ac(Q[4], pp, Q[2], Q[3]);
+    present[5] = ac(Q[5], Q[6], pp, Q[4]);
+    present[7] = !ac(Q[6], Q[7], Q[0], pp);
+    P2 N[8];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+    for (int s = 0; s < 8; ++s) { N[s] = P2{ Q[s].x - pp.x, Q[s].y - pp.y }; nrel[s * nstride] = N[s]; }
+    // triangles: slot 2c = (N[2c], N[2c+1] or N[2c+2]), slot 2c + 1 = (N[2c+1], N[2c+2]) when the diagonal is present.
+    // In-circle sum of a site C against triangle (0, A, B): |C|^2 o + C.x u + C.y w, negative inside; kept in float32
+    // for the first look at every (site, triangle) pair.
+    float o[8], u[8], w[8];
+    float Mmax = 0.0f;
+    unsigned long long adj = 0ull;                               // byte s: the triangles that have slot s as a corner (its sites lie ON their circles)
+    bool ok = true;
+    int winds = 0;
+    float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; ++k) {
+        const int c2 = k & ~1, d = c2 + 1, e = (c2 + 2) & 7;
+        const bool diag = present[d];
+        const bool valid = (k & 1) ? diag : true;
+        const P2 A = (k & 1) ? N[d] : N[c2];
+        const P2 B = (k & 1) ? N[e] : (diag ? N[d] : N[e]);
+        const double a2 = A.x * A.x + A.y * A.y, b2 = B.x * B.x + B.y * B.y;
+        const double ok_ = A.x * B.y - A.y * B.x;
+        const double uk = A.y * b2 - a2 * B.y, wk = a2 * B.x - A.x * b2;
+        const double mo = fabs(A.x * B.y) + fabs(A.y * B.x), mu = fabs(A.y) * b2 + a2 * fabs(B.y), mw = a2 * fabs(B.x) + fabs(A.x) * b2;
+        o[k] = valid ? (float)ok_ : 0.0f; u[k] = valid ? (float)uk : 0.0f; w[k] = valid ? (float)wk : 0.0f;
+        if (valid) {
+            adj |= 1ull << (8 * ((k & 1) ? d : c2) + k);
+            adj |= (k & 1) ? (1ull << (8 * e + k)) : (diag ? (1ull << (8 * d + k)) : (1ull << (8 * e + k)));
+            Mmax = fmaxf(Mmax, (float)fmax(mo, fmax(mu, mw)));
+            if (!(ok_ > 0.0)) ok = false;                        // counter-clockwise triangles only
+            if (A.y < 0.0 && B.y >= 0.0) ++winds;
+            // bounding box of the circumcircle, float32 with a safety margin (wide circles leave the fan path anyway)
+            const float inv = 0.5f / (float)ok_;
+            const float cx = -(float)uk * inv, cy = -(float)wk * inv;
+            const float r = sqrtf(cx * cx + cy * cy);
+            const float pad = r * 1.0001f + 1e-5f * (fabsf(cx) + fabsf(cy)) + 1e-30f;
+            bx0 = fminf(bx0, cx - pad); bx1 = fmaxf(bx1, cx + pad);
+            by0 = fminf(by0, cy - pad); by1 = fmaxf(by1, cy + pad);
+        }
+    }
+    if (!ok || winds != 1) return 0;
+    if (!(bx1 - bx0 < 3e30f) || !(by1 - by0 < 3e30f) || !(Mmax < 3e30f)) return 0;          // also catches NaN
+    Mmax = Mmax * 1.000001f + 1e-37f;                            // an unused slot (o = u = w = 0) calls every site "outside"
+    const int cb0 = g.bx(pp.x + (double)bx0), cb1 = g.bx(pp.x + (double)bx1);
+    const int rb0 = g.by(pp.y + (double)by0), rb1 = g.by(pp.y + (double)by1);
+    if (cb1 - cb0 >= max_span || rb1 - rb0 >= max_span) return 0;
+    unsigned pmask8 = 0x55u;                                     // present slots as bits
+    if (present[1]) pmask8 |= 2u;
+    if (present[3]) pmask8 |= 8u;
+    if (present[5]) pmask8 |= 32u;
+    if (present[7]) pmask8 |= 128u;
+    for (int row = rb0; row <= rb1; ++row) {
+        const unsigned lo = bstart[(size_t)row * g.gx + cb0], hi = bstart[(size_t)row * g.gx + cb1 + 1];
+        for (unsigned j = lo; j < hi; ++j) {
+            const P2 qa = sorted_xy ? sorted_xy[j] : pos((int)sorted[j]);
+            const int qi = (int)sorted[j];
+            const P2 C = { qa.x - pp.x, qa.y - pp.y };
+            const float cxf = (float)C.x, cyf = (float)C.y, c2f = cxf * cxf + cyf * cyf;
+            if (qi == p || (C.x == 0.0 && C.y == 0.0)) continue;                  // the site itself, or a duplicate of it
+            const float marg = kFanEpsF * (c2f + fabsf(cxf) + fabsf(cyf)) * Mmax;
+            unsigned need = 0;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+            for (int k = 0; k < 8; ++k) {
+                const float sum = c2f * o[k] + (cxf * u[k] + cyf * w[k]);       // < 0: inside
+                if (!(sum > marg)) need |= 1u << k;
+            }
+            if (!need) continue;
+            bool member = false;                                 // one of the eight grid neighbours, or a duplicate of one?
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+            for (int s = 0; s < 8; ++s)
+                if (qi == p + off[s]) { member = true; need &= ~(unsigned)((adj >> (8 * s)) & 0xFFull); }
+            if (!need) continue;
+            // inside some circle, or within the float32 margin of one: float64, then (within ITS margin) the predicate of
+            // the clip path with ties as vertex_cut breaks them.  Rare: a plain loop with computed slot numbers.
+            const double c2 = C.x * C.x + C.y * C.y;
+#ifdef __HIPCC__
+#pragma unroll 1
+#endif
+            for (int k = 0; k < 8; ++k) {
+                if (!((need >> k) & 1u)) continue;
+                const int kc = k & ~1, d = kc + 1, e = (kc + 2) & 7;
+                const bool diag = (pmask8 >> d) & 1u;
+                if ((k & 1) && !diag) continue;                  // unused slot
+                const int sa = (k & 1) ? d : kc, sb = (k & 1) ? e : (diag ? d : e);
+                const int pa = p + slot_offset(sa, W), pb = p + slot_offset(sb, W);
+                if (qi == pa || qi == pb) continue;              // the triangle's own sites lie ON its circle
+                const P2 A = nrel[sa * nstride], B = nrel[sb * nstride];
+                if ((A.x == C.x && A.y == C.y) || (B.x == C.x && B.y == C.y)) continue;   // a duplicate of a triangle's site
+                const double a2 = A.x * A.x + A.y * A.y, b2 = B.x * B.x + B.y * B.y;
+                const double t0 = c2 * (A.x * B.y - A.y * B.x), t1 = C.x * (A.y * b2 - a2 * B.y), t2 = C.y * (a2 * B.x - A.x * b2);
+                const double sum = t0 + (t1 + t2);
+                const double mag = c2 * (fabs(A.x * B.y) + fabs(A.y * B.x)) + fabs(C.x) * (fabs(A.y) * b2 + a2 * fabs(B.y))
+                                 + fabs(C.y) * (a2 * fabs(B.x) + fabs(A.x) * b2);
+                if (sum > kFanEps * mag) continue;               // outside
+                if (sum < -kFanEps * mag) return 0;              // inside: not a Delaunay triangle
+                const double ic = incircle_origin(A, B, C);
+                if (ic > 0.0) return 0;
+                if (ic == 0.0) {
+                    if (!member) {
+#ifdef __HIPCC__
+#pragma unroll 1
+#endif
+                        for (int s = 0; s < 8; ++s) { const P2 T = nrel[s * nstride]; member = member || (T.x == C.x && T.y == C.y); }
+                    }
+                    if (!member && (p < qi ? p : qi) < (pa < pb ? pa : pb)) return 0;
+                }
+            }
+        }
+    }
+    int n = 0;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+    for (int s = 0; s < 8; ++s) if (present[s]) nbr_out[n++] = (unsigned)(p + off[s]);
+    return n;
 }
 
 // Rotation of a triangle's vertex indices that puts the smallest first without changing the cyclic order: every copy

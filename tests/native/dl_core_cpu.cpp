@@ -43,28 +43,35 @@ int poly_clip_any(Poly &P, const P2 &C, int ctag, int ptag, RelFn rel, std::vect
 
 // pts [n][2]; tri_out receives (p, a, b) for every pair of consecutive real neighbours of every star ("emit all");
 // info[8]: [0] far sites, [1] polygon overflows in the near pass, [2] grid gx, [3] grid gy, [4] largest star
-extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, int *tri_out, long long tri_cap,
-                            long long *n_tri, int *info)
+// kept (or null: all) marks the sites that exist; with W > 0 the sites are the points of a warped H x W grid in row-major
+// order and intact neighbourhoods take the mesh-fan shortcut first (info[5] counts them), as the GPU path does
+static int stars_impl(const double *pts, int n, const unsigned char *kept, int W, int rings, int near_cap, int *tri_out,
+                      long long tri_cap, long long *n_tri, int *info)
 {
     if (n <= 0) return -1;
-    double x0 = pts[0], x1 = pts[0], y0 = pts[1], y1 = pts[1];
-    for (int i = 1; i < n; ++i) {
+    auto is_kept = [&](int i) { return !kept || kept[i]; };
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!is_kept(i)) continue;
+        ++nk;
         x0 = std::min(x0, pts[2 * i]); x1 = std::max(x1, pts[2 * i]);
         y0 = std::min(y0, pts[2 * i + 1]); y1 = std::max(y1, pts[2 * i + 1]);
     }
+    if (nk == 0) return -1;
     Grid g;
     const double bw = x1 - x0, bh = y1 - y0;
-    double s = sqrt(std::max(bw * bh, 1e-300) / n);
-    s = std::max(s, (bw + bh) / (double)n);
+    double s = sqrt(std::max(bw * bh, 1e-300) / nk);
+    s = std::max(s, (bw + bh) / (double)nk);
     if (!(s > 0)) s = 1.0;
     g.ox = x0; g.oy = y0; g.s = s; g.inv_s = 1.0 / s;
     g.gx = (int)floor(bw / s) + 1; g.gy = (int)floor(bh / s) + 1;
     const size_t nb = (size_t)g.gx * g.gy;
-    std::vector<unsigned> bstart(nb + 1, 0), sorted(n), cursor(nb, 0);
+    std::vector<unsigned> bstart(nb + 1, 0), sorted(nk), cursor(nb, 0);
     auto bucket = [&](int i) { return (size_t)g.by(pts[2 * i + 1]) * g.gx + g.bx(pts[2 * i]); };
-    for (int i = 0; i < n; ++i) ++bstart[bucket(i) + 1];
+    for (int i = 0; i < n; ++i) if (is_kept(i)) ++bstart[bucket(i) + 1];
     for (size_t b = 0; b < nb; ++b) bstart[b + 1] += bstart[b];
-    for (int i = 0; i < n; ++i) { const size_t b = bucket(i); sorted[bstart[b] + cursor[b]++] = (unsigned)i; }   // ascending index per bucket
+    for (int i = 0; i < n; ++i) if (is_kept(i)) { const size_t b = bucket(i); sorted[bstart[b] + cursor[b]++] = (unsigned)i; }   // ascending index per bucket
     auto pos = [&](int i) { return P2{ pts[2 * i], pts[2 * i + 1] }; };
     std::vector<double> vx(4096), vy(4096);
     std::vector<int> tag(4096);
@@ -82,7 +89,28 @@ extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, i
         }
     };
     std::vector<float> fx(64), fy(64);
+    int fans = 0;
+    const int H = W > 0 ? n / W : 0;
     for (int p = 0; p < n; ++p) {
+        if (!is_kept(p)) continue;
+        if (W > 0) {
+            const int x = p % W, y = p / W;
+            bool intact = x >= 1 && y >= 1 && x <= W - 2 && y <= H - 2;
+            for (int dy = -1; intact && dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) intact = intact && is_kept(p + dy * W + dx);
+            if (intact) {
+                P2 nrel[8];
+                unsigned nb8[8];
+                const int m = star_fan(p, W, pos(p), pos, g, bstart.data(), sorted.data(), (const P2 *)nullptr, 6, nrel, 1, nb8);
+                if (m > 0) {
+                    for (int k = 0; k < m; ++k) tag[k] = (int)nb8[k];
+                    Poly Q{ vx.data(), vy.data(), tag.data(), 1, 64, m };
+                    emit(p, Q);
+                    ++fans;
+                    continue;
+                }
+            }
+        }
         // near_cap < 0: the float32 cell of the GPU's per-thread pass
         if (near_cap < 0) {
             PolyT<float> P{ fx.data(), fy.data(), tag.data(), 1, -near_cap, 0 };
@@ -133,8 +161,21 @@ extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, i
         emit(p, P);
     }
     *n_tri = nt;
-    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy; info[4] = maxdeg;
+    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy; info[4] = maxdeg; info[5] = fans;
     return 0;
+}
+
+extern "C" int dl_stars_cpu(const double *pts, int n, int rings, int near_cap, int *tri_out, long long tri_cap,
+                            long long *n_tri, int *info)
+{
+    return stars_impl(pts, n, nullptr, 0, rings, near_cap, tri_out, tri_cap, n_tri, info);
+}
+
+// the sites are the kept points of a warped H x W grid (pts holds all H * W positions): mesh fans first, as on the GPU
+extern "C" int dl_stars_grid_cpu(const double *pts, const unsigned char *kept, int H, int W, int rings, int near_cap,
+                                 int *tri_out, long long tri_cap, long long *n_tri, int *info)
+{
+    return stars_impl(pts, H * W, kept, W, rings, near_cap, tri_out, tri_cap, n_tri, info);
 }
 
 // debugging aid: the near-pass star of ONE site with float32 or float64 cell storage, every clip printed

@@ -37,6 +37,21 @@ def stars(lib, pts, rings=6, near_cap=16):
     return tri[:nt.value], list(info)
 
 
+def stars_grid(lib, pts_all, kept, h, w, rings=6, near_cap=-12):
+    """all H * W warped positions + the kept mask: the mesh-fan shortcut first, then the clip path (as the GPU does)"""
+    pts_all = np.ascontiguousarray(pts_all, np.float64)
+    kept = np.ascontiguousarray(kept, np.uint8)
+    cap = 12 * h * w + 1024
+    tri = np.zeros((cap, 3), np.int32)
+    nt = ctypes.c_longlong(0)
+    info = (ctypes.c_int * 8)()
+    lib.dl_stars_grid_cpu.restype = ctypes.c_int
+    rc = lib.dl_stars_grid_cpu(pts_all.ctypes.data_as(ctypes.c_void_p), kept.ctypes.data_as(ctypes.c_void_p), h, w, rings, near_cap,
+                               tri.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(cap), ctypes.byref(nt), info)
+    assert rc == 0 and nt.value <= cap
+    return tri[:nt.value], list(info)
+
+
 def circum(pts, tri):
     a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
     bx, by, cx, cy = b[:, 0] - a[:, 0], b[:, 1] - a[:, 1], c[:, 0] - a[:, 0], c[:, 1] - a[:, 1]
@@ -69,12 +84,27 @@ def fixture_points(g, tag):
     return p[mask.ravel()]
 
 
+def fixture_grid(g, tag):
+    vecs, mask = g[tag + '/in_vecs'], g[tag + '/in_mask']
+    h, w = vecs.shape[:2]
+    yy, xx = np.mgrid[:h, :w]
+    p = np.stack([(xx + vecs[..., 0].astype(np.float64)).ravel(), (yy + vecs[..., 1].astype(np.float64)).ravel()], 1)
+    return p, mask.ravel(), h, w
+
+
 @pytest.mark.parametrize("tag", ["curved", "curved_in", "shear", "wobble3", "speckle_img", "affine_generic",
                                  "affine_generic_hole", "block_generic", "hole_img"])
-@pytest.mark.parametrize("near_cap", [16, -12])      # float64 cells of 16 vertices / the GPU's float32 cells of 12
+@pytest.mark.parametrize("near_cap", [16, -12, "fan"])   # float64 cells of 16 vertices / the GPU's float32 cells of 12 / mesh fans first
 def test_stars_equal_scipy_delaunay(core, golden2, tag, near_cap):
     pts = fixture_points(golden2, tag)
-    tri, info = stars(core, pts, near_cap=near_cap)
+    if near_cap == "fan":
+        pall, kept, h, w = fixture_grid(golden2, tag)
+        tri, info = stars_grid(core, pall, kept, h, w)
+        assert info[5] > (-1 if tag == "shear" else 0.3 * kept.sum()), (tag, info)      # the shortcut is taken where the mesh is intact (sheared cells: nowhere)
+        remap = np.cumsum(kept) - 1                             # grid index -> index among the kept points
+        tri = remap[tri].astype(np.int32)
+    else:
+        tri, info = stars(core, pts, near_cap=near_cap)
     assert info[1] == 0 or info[0] > 0                      # overflowing stars went to the far pass
     ours = {tuple(sorted(t)) for t in tri.tolist()}
     d = Delaunay(pts)
@@ -96,11 +126,18 @@ def test_stars_equal_scipy_delaunay(core, golden2, tag, near_cap):
     assert all(cnt[tuple(sorted(s))] == 3 for s, u in zip(d.simplices.tolist(), uniq) if u)
 
 
-def test_stars_on_folds_and_duplicates(core, golden2):
+@pytest.mark.parametrize("with_fan", [False, True])
+def test_stars_on_folds_and_duplicates(core, golden2, with_fan):
     """BASELINE config 5 as loaded: the tiled Sintel field puts every site on the integer lattice, many of them twice.
     The stars still cover SciPy's triangulation wherever it is unique, and their triangles are all Delaunay."""
     pts = fixture_points(golden2, "sintel4x4")
-    tri, info = stars(core, pts)
+    pall, kept, h, w = fixture_grid(golden2, "sintel4x4")
+    assert kept.all()
+    if with_fan:
+        tri, info = stars_grid(core, pall, kept, h, w)
+        assert info[5] >= 0, info          # (u = x * y: every row has its own spacing, no cell of this mesh is Delaunay)
+    else:
+        tri, info = stars(core, pts)
     ours = {tuple(sorted(t)) for t in tri.tolist()}
     upts, inv = np.unique(pts, axis=0, return_inverse=True)
     d = Delaunay(upts)

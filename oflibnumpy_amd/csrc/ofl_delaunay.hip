@@ -32,6 +32,7 @@ using namespace ofl_dl;
 namespace {
 
 constexpr int      kRings    = 6;        // bucket rings of the per-thread star pass
+constexpr int      kOpenRings = 2;       // ... of which a cell still unbounded after this many is handed on at once
 constexpr int      kNearCap  = 12;       // polygon capacity of the per-thread pass (float32 cell in LDS)
 constexpr int      kSlots    = 16;       // neighbour slots per point
 constexpr int      kMidCap   = 256;      // polygon capacity of the wave pass (unfinished points against the coarse grid of unfinished points)
@@ -334,7 +335,8 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
     __shared__ P2 s_rel[8][kFanBlock];
-    const size_t p = (size_t)blockIdx.x * kFanBlock + threadIdx.x;
+    const unsigned per = gridDim.x >> 3;                        // (grid padded to a multiple of 8) one contiguous eighth per XCD
+    const size_t p = (size_t)((blockIdx.x & 7u) * per + (blockIdx.x >> 3)) * kFanBlock + threadIdx.x;
     if (p >= (size_t)H * W) return;
     if (!kept_pt(pmask, p)) { deg[p] = 0; return; }
     const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
@@ -347,7 +349,13 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
     if (intact) {
         const Grid g = head->grid;
         const PosFn pos(flow, sign, W);
-        n = star_fan((int)p, W, pos((int)p), pos, g, bstart, sorted, sorted_xy, kFanSpan, &s_rel[0][threadIdx.x], kFanBlock,
+        auto npos = [&](int sl) {                               // slot -> grid offset at compile time (the loops over slots are unrolled)
+            const int dx = (int)((0x901Au >> (2 * sl)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * sl)) & 3u) - 1;
+            const D2 q = point_of(flow, sign, W, x + dx, y + dy);
+            return P2{ q.x, q.y };
+        };
+        const D2 c = point_of(flow, sign, W, x, y);
+        n = star_fan((int)p, W, P2{ c.x, c.y }, pos, npos, g, bstart, sorted, sorted_xy, kFanSpan, &s_rel[0][threadIdx.x], kFanBlock,
                      nbr + p * kSlots);
     }
     deg[p] = n > 0 ? (unsigned char)n : kDegTodo;
@@ -370,7 +378,7 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, int H, int W,
         if (base + threadIdx.x >= n_todo) return;
         const size_t p = todo[base + threadIdx.x];
         PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
-        const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings, sorted_xy);
+        const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings);
         bool ok = rc == 1;
         for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
         if (!ok) {
@@ -468,7 +476,7 @@ struct FarLds {
     // max(v0 . c / |v0|, v1 . c / |v1|) * vmax < |c|^2 / 2 (minus the margin of vertex_cut) cuts none of them: two dot
     // products instead of the list.  cone = 0 when the run is not unique or too wide.
     int    cone, nrun, f0, f1;
-    double c0x, c0y, c1x, c1y, vmax;     // unit directions of the run's ends, largest |v| in it
+    double c0x, c0y, c1x, c1y, kcone;    // unit directions of the run's ends, 0.999 / (2 * largest |v| in it)
 };
 
 template <int CAP, int NT>
@@ -539,8 +547,9 @@ __device__ void far_refresh(FarLds<CAP, NT> &L)
             const double c0x = ax / na, c0y = ay / na, c1x = bx / nb, c1y = by / nb;
             // counter-clockwise from f0 to f1 by less than a half turn, with room to spare (or a single far vertex)
             if (L.f0 == L.f1 || (c0x * c1y - c0y * c1x > 1e-6 || (c0x * c1x + c0y * c1y > 0.5 && c0x * c1y - c0y * c1x >= 0.0))) {
-                L.c0x = c0x; L.c0y = c0y; L.c1x = c1x; L.c1y = c1y; L.vmax = sqrt(fm);
-                L.cone = isfinite(L.vmax) ? 1 : 0;
+                const double vmax = sqrt(fm);
+                L.c0x = c0x; L.c0y = c0y; L.c1x = c1x; L.c1y = c1y; L.kcone = 0.999 / (2.0 * vmax);
+                L.cone = isfinite(vmax) && isfinite(c0x + c0y + c1x + c1y) ? 1 : 0;
             }
         }
         if (!listed && !L.cone) L.reach2 = 1e300;         // neither a list nor a cone: every vertex is tested
@@ -597,34 +606,40 @@ __device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, R
     far_refresh(L);
 }
 
-// one chunk of up to NT candidates (thread t holds candidate cand, or -1).  Most chunks cut nothing: they cost ONE barrier
-// (the vote), the cell is only touched -- and the workgroup only synchronises further -- when some candidate cuts it.
+// does candidate `cand` at q cut the cell as it stands?  (per thread; C receives its relative position)
 template <int CAP, int NT, class RelFn>
-__device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const P2 &q, RelFn rel)
+__device__ __forceinline__ bool far_test(const FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const P2 &q, RelFn rel, P2 &C)
 {
-    const int t = threadIdx.x;
     bool hit = false;
-    P2 C{ 0.0, 0.0 };
+    C = P2{ 0.0, 0.0 };
     if (cand >= 0 && cand != p) {
         C.x = q.x - pp.x; C.y = q.y - pp.y;
         const double d2 = C.x * C.x + C.y * C.y;
         if (d2 != 0.0) {
             const int n = L.n;
             const double h = 0.5 * d2;
-            Poly P{ L.vx, L.vy, L.tag, 1, CAP, n };
+            Poly P{ const_cast<double *>(L.vx), const_cast<double *>(L.vy), const_cast<int *>(L.tag), 1, CAP, n };
             bool all = d2 < L.reach2, some = !all && L.nfar != 0;
             if (some && L.cone) {
-                const double len = sqrt(d2), ux = C.x / len, uy = C.y / len;
-                const double m0 = L.c0x * ux + L.c0y * uy, m1 = L.c1x * ux + L.c1y * uy;
-                const bool inside = L.c0x * uy - L.c0y * ux >= 0.0 && ux * L.c1y - uy * L.c1x >= 0.0;
-                if (!inside && fmax(fmax(m0, m1), 0.0) + 2e-9 < 0.999 * len / (2.0 * L.vmax)) some = false;
+                // vmax max(d0 . c, d1 . c, 0) - |c|^2 / 2 < -(margin of vertex_cut) = -1e-9 (|vx cx| + |vy cy| + |c|^2 / 2)
+                const double m0 = L.c0x * C.x + L.c0y * C.y, m1 = L.c1x * C.x + L.c1y * C.y;
+                const bool inside = L.c0x * C.y - L.c0y * C.x >= 0.0 && C.x * L.c1y - C.y * L.c1x >= 0.0;
+                if (!inside && fmax(fmax(m0, m1), 0.0) + 1e-9 * (fabs(C.x) + fabs(C.y)) < d2 * L.kcone) some = false;
             }
             if (some && L.nfar < 0) { all = true; some = false; }
             if (all) { for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, p, h, rel); }
             else if (some) { const int nf = L.nfar; for (int i = 0; i < nf && !hit; ++i) hit = vertex_cut(P, L.farlist[i], n, C, cand, p, h, rel); }
         }
     }
-    if (!__syncthreads_or(hit)) return;                 // (every application below ends with a barrier: the cell is stable here)
+    return hit;
+}
+
+// the candidates of a chunk that cut the cell (per-thread flag `hit`; the workgroup knows there is at least one) are
+// applied one after the other, in thread order, by the whole workgroup
+template <int CAP, int NT, class RelFn>
+__device__ void far_commit(FarLds<CAP, NT> &L, int p, int cand, const P2 &C, bool hit, RelFn rel)
+{
+    const int t = threadIdx.x;
     L.cidx[t] = cand; L.ccx[t] = C.x; L.ccy[t] = C.y;
     const unsigned long long m = __ballot(hit);
     if ((t & 63) == 0) L.hit[t >> 6] = m;
@@ -638,6 +653,33 @@ __device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, con
         }
     }
     __syncthreads();
+}
+
+// one chunk of up to NT candidates (thread t holds candidate cand, or -1).  Most chunks cut nothing: they cost ONE barrier
+// (the vote), the cell is only touched -- and the workgroup only synchronises further -- when some candidate cuts it.
+template <int CAP, int NT, class RelFn>
+__device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const P2 &q, RelFn rel)
+{
+    P2 C;
+    const bool hit = far_test(L, p, pp, cand, q, rel, C);
+    if (!__syncthreads_or(hit)) return;                 // (every application below ends with a barrier: the cell is stable here)
+    far_commit(L, p, cand, C, hit, rel);
+}
+
+// K chunks under ONE vote (the long sweeps over the left-over points cut next to nothing).  A candidate that does not cut
+// the cell now cannot cut the smaller cell later, and far_apply re-tests what it is given, so the flags taken before the
+// vote stay valid while the chunks are committed in order.
+template <int K, int CAP, int NT, class RelFn>
+__device__ void far_chunks(FarLds<CAP, NT> &L, int p, const P2 &pp, const int (&cand)[K], const P2 (&q)[K], RelFn rel)
+{
+    P2 C[K];
+    bool hit[K], any = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { hit[k] = far_test(L, p, pp, cand[k], q[k], rel, C[k]); any = any || hit[k]; }
+    if (!__syncthreads_or(any)) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (__syncthreads_or(hit[k])) far_commit(L, p, cand[k], C[k], hit[k], rel);
 }
 
 // The runs in L.run_lo / L.run_pre (lengths, turned into a prefix here) are walked as ONE dense list, NT candidates per
@@ -694,37 +736,31 @@ __device__ void far_near_rows(FarLds<CAP, NT> &L, int p, const P2 &pp, const Gri
     far_dense(L, p, pp, 2 * kRings + 1, rel, sorted, sorted_xy);
 }
 
-// ring r of the coarse grid (r0 == r1) or the whole square of rings r0 .. r1 row by row: unfinished points (ranks -> point indices)
+// The unfinished points in the coarse cells at Chebyshev distance (ra, rb] from the point's cell (ra = -1: the whole square
+// of radius rb): full rows above and below, the two side stretches of the rows in between; runs go through the run list
+// 64 at a time.
 template <int CAP, int NT, class RelFn>
-__device__ void far_coarse_rings(FarLds<CAP, NT> &L, int p, const P2 &pp, int r0, int r1, const Grid &g1,
-                                 const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt,
-                                 const P2 *__restrict__ sorted1_xy, RelFn rel)
+__device__ void far_coarse_annulus(FarLds<CAP, NT> &L, int p, const P2 &pp, int ra, int rb, const Grid &g1,
+                                   const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt,
+                                   const P2 *__restrict__ sorted1_xy, RelFn rel)
 {
     const int t = threadIdx.x, bx = g1.bx(pp.x), by = g1.by(pp.y);
-    int nruns;
-    __syncthreads();
-    if (r0 != r1 || r0 == 0) {                      // full rows of the square
-        nruns = 2 * r1 + 1;
-        if (t < nruns) far_set_run(L, t, g1, b1start, by - r1 + t, bx - r1, bx + r1);
-    } else {                                        // the ring alone: top and bottom rows, then the two end cells of the rows between
-        const int r = r0, total = 2 + 2 * (2 * r - 1);
-        for (int b0 = 0; b0 < total; b0 += 64) {    // (a wide ring has more runs than the run list holds)
-            const int cnt = min(64, total - b0);
-            __syncthreads();
-            if (t < cnt) {
-                const int i = b0 + t;
-                if (i == 0) far_set_run(L, t, g1, b1start, by - r, bx - r, bx + r);
-                else if (i == 1) far_set_run(L, t, g1, b1start, by + r, bx - r, bx + r);
-                else {
-                    const int m = i - 2, row = by - r + 1 + (m >> 1), col = (m & 1) ? bx + r : bx - r;
-                    far_set_run(L, t, g1, b1start, row, col, (col < 0 || col > g1.gx - 1) ? col - 1 : col);
-                }
+    const int nt = rb - ra, nm = ra >= 0 ? 2 * ra + 1 : 0, total = 2 * nt + 2 * nm;
+    for (int b0 = 0; b0 < total; b0 += 64) {
+        const int cnt = min(64, total - b0);
+        __syncthreads();
+        if (t < cnt) {
+            const int i = b0 + t;
+            if (i < nt) far_set_run(L, t, g1, b1start, by - rb + i, bx - rb, bx + rb);
+            else if (i < 2 * nt) far_set_run(L, t, g1, b1start, by + ra + 1 + (i - nt), bx - rb, bx + rb);
+            else {
+                const int m = i - 2 * nt, row = by - ra + (m >> 1);
+                if (m & 1) far_set_run(L, t, g1, b1start, row, bx + ra + 1, bx + rb);
+                else       far_set_run(L, t, g1, b1start, row, bx - rb, bx - ra - 1);
             }
-            far_dense(L, p, pp, cnt, rel, sorted1_pt, sorted1_xy);
         }
-        return;
+        far_dense(L, p, pp, cnt, rel, sorted1_pt, sorted1_xy);
     }
-    far_dense(L, p, pp, nruns, rel, sorted1_pt, sorted1_xy);
 }
 
 // the sites the per-thread pass left in the point's neighbour slots: one chunk, applied before anything else
@@ -793,17 +829,21 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     const int cbx = g1.bx(pp.x), cby = g1.by(pp.y);
     const int rgrid = max(max(cbx, g1.gx - 1 - cbx), max(cby, g1.gy - 1 - cby));
     bool done = false;
-    for (int r = 0; r <= rmax && !done; ++r) {
-        far_coarse_rings(L, p, pp, r, r, g1, b1start, sorted1_pt, sorted1_xy, rel);
+    for (int ra = -1; ra < rmax && !done;) {
+        // ring by ring while the cell is small; then annuli that grow by half their radius (one pass over their rows
+        // instead of one per ring: the rim of a large hole needs a hundred rings)
+        const int rb = ra < kMidRings ? ra + 1 : min(ra + max(ra / 2, 1), rmax);
+        far_coarse_annulus(L, p, pp, ra, rb, g1, b1start, sorted1_pt, sorted1_xy, rel);
         double r2 = 0.0;
         const int n = L.n;
         for (int k = t; k < n; k += 64) r2 = fmax(r2, L.vx[k] * L.vx[k] + L.vy[k] * L.vy[k]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             r2 = fmax(r2, __hiloint2double(__shfl_xor(__double2hiint(r2), off), __shfl_xor(__double2loint(r2), off)));
-        const double cover = (double)r * g1.s;
-        done = cover * cover >= 4.0 * r2 || r >= rgrid;
+        const double cover = (double)rb * g1.s;
+        done = cover * cover >= 4.0 * r2 || rb >= rgrid;
         if (L.status) break;
+        ra = rb;
     }
     __syncthreads();
     if (!done || L.status) { if (t == 0) far_deg[rank] = kDegLeft; return; }
@@ -841,10 +881,18 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     far_refresh(L);
     far_seeds(L, p, pp, nbr, pos, rel);
     far_near_rows(L, p, pp, g, bstart, sorted, sorted_xy, rel);
-    far_coarse_rings(L, p, pp, 0, kMidRings, g1, b1start, sorted1_pt, sorted1_xy, rel);
-    for (unsigned base = 0; base < n_left; base += 256) {
-        const bool in = base + t < n_left;
-        far_chunk(L, p, pp, in ? (int)left_pt[base + t] : -1, in ? left_xy[base + t] : pp, rel);
+    far_coarse_annulus(L, p, pp, -1, kMidRings, g1, b1start, sorted1_pt, sorted1_xy, rel);
+    // every other left-over point, 4 x 256 per step
+    for (unsigned base = 0; base < n_left; base += 1024) {
+        int cand[4];
+        P2  q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned j = base + 256 * k + t;
+            cand[k] = j < n_left ? (int)left_pt[j] : -1;
+            q[k] = j < n_left ? left_xy[j] : pp;
+        }
+        far_chunks<4>(L, p, pp, cand, q, rel);
     }
     __syncthreads();
     if (CAP < kFarCap && L.status) return;               // overflow of the small capacity: far_deg stays kDegLeft for the next pass
@@ -932,7 +980,12 @@ __device__ __forceinline__ void thread_raster(unsigned id, unsigned self, const 
 __global__ __launch_bounds__(256)
 void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
 {
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the field, so that the neighbour
+    // rows a point looks up (the stars of the sites above and below it) are in ITS L2
+    const unsigned nb = gridDim.x, per = (nb + 7) / 8;
+    const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (blk >= nb) return;
+    const size_t p = (size_t)blk * 256 + threadIdx.x;
     if (p >= (size_t)H * W) return;
     const unsigned d = ws.deg[p];
     if (d == 0 || d > kSlots) return;
@@ -940,16 +993,17 @@ void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int
     for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, (unsigned)p, pos, H, W, ws, far_base);
 }
 
+// one WAVE per unfinished point (their stars run to hundreds of triangles: a thread per point would crawl)
 __global__ __launch_bounds__(256)
 void dl_raster_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
 {
-    const unsigned rank = blockIdx.x * 256 + threadIdx.x;
+    const unsigned rank = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rank >= ws.head->n_far) return;
     const unsigned d = ws.far_deg[rank];
     if (d == kDegLeft) return;
     const PosFn pos(flow, sign, W);
     const unsigned self = ws.far_idx[rank];
-    for (unsigned k = 0; k < d; ++k) thread_raster(far_base + rank * kFarK + k, self, pos, H, W, ws, far_base);
+    for (unsigned k = threadIdx.x & 63; k < d; k += 64) thread_raster(far_base + rank * kFarK + k, self, pos, H, W, ws, far_base);
 }
 
 // one wave per large triangle: 64 nodes of the bounding box per step
@@ -1222,7 +1276,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        (const unsigned *)ws.sorted, (const unsigned *)nullptr, ws.sorted_xy, (unsigned *)nullptr);
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
     unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
-    hipLaunchKernelGGL(dl_star_fan_kernel, dim3((unsigned)((n + kFanBlock - 1) / kFanBlock)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
+    hipLaunchKernelGGL(dl_star_fan_kernel, dim3((unsigned)(((n + kFanBlock - 1) / kFanBlock + 7) / 8 * 8)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                        ws.deg, ws.nbr);
     // what the fans did not settle, in index order, for the clip pass
@@ -1295,9 +1349,9 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
             OFL_HIP(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(dl_raster_small_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+    hipLaunchKernelGGL(dl_raster_small_kernel, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     if (h.n_far)
-        hipLaunchKernelGGL(dl_raster_far_kernel, dim3((h.n_far + 255) / 256), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+        hipLaunchKernelGGL(dl_raster_far_kernel, dim3((h.n_far + 3) / 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     far_base_out = (unsigned)far_base;
     OFL_HIP(hipGetLastError());

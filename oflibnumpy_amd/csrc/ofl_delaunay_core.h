@@ -247,9 +247,12 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
 // The star of site p from the sites within `rings` bucket rings.  Returns 1 when the cell is final (every site within
 // twice the farthest cell vertex has been applied: sites in unvisited buckets are at least r * s away), 0 when it is
 // not (unbounded cells, rims of large holes: the far pass finishes those), -1 when the polygon overflowed.
+// A cell that is still unbounded (an edge on the initial box) after `open_rings` rings is given up at once: hull points
+// and rims of holes do not close within the ring search, and the cooperative passes pick them up with the sites found
+// so far as seeds.
 template <class PolyX, class PosFn>
 DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
-                    PosFn pos, int rings, const P2 *sorted_xy = nullptr)
+                    PosFn pos, int rings, const P2 *sorted_xy = nullptr, int open_rings = 1 << 30)
 {
     poly_init(P);
     const int bx = g.bx(pp.x), by = g.by(pp.y);
@@ -258,6 +261,11 @@ DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned
         if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy) < 0) return -1;
         const double cover = (double)r * g.s;
         if (cover * cover >= reach2) return 1;
+        if (r >= open_rings) {
+            bool open = false;
+            for (int k = 0; k < P.n; ++k) open = open || P.T(k) < 0;
+            if (open) return 0;
+        }
     }
     return 0;
 }
@@ -289,8 +297,8 @@ DL_HD int slot_offset(int s, int W)
 constexpr double kFanEps  = 1e-13;       // relative margin of the float64 three-term in-circle sum (its rounding error is ~1e-15)
 constexpr float  kFanEpsF = 2e-5f;       // ... and of its float32 version (inputs rounded to float32: ~1e-6)
 
-template <class PosFn>
-DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, const Grid &g, const unsigned *bstart,
+template <class PosFn, class SlotPosFn>
+DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const Grid &g, const unsigned *bstart,
                    const unsigned *sorted, const P2 *sorted_xy, int max_span,
                    P2 *nrel, int nstride,                     // scratch: relative positions of the eight slots
                    unsigned *nbr_out)                         // the star, counter-clockwise (4 .. 8 sites)
@@ -300,7 +308,7 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, const Grid &g, const u
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-    for (int s = 0; s < 8; ++s) Q[s] = pos(p + off[s]);
+    for (int s = 0; s < 8; ++s) Q[s] = npos(s);             // position of grid-neighbour slot s (= pos(p + off[s]))
     // diagonals: cell 0 (a = p, b = E, c = SE, d = S), cell 1 (a = W, b = p, c = S, d = SW),
     //            cell 2 (a = NW, b = N, c = p, d = W), cell 3 (a = N, b = NE, c = E, d = p)
     auto ac = [](const P2 &A, const P2 &B, const P2 &C, const P2 &D) {
@@ -343,6 +351,10 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, const Grid &g, const u
         if (valid) {
             adj |= 1ull << (8 * ((k & 1) ? d : c2) + k);
             adj |= (k & 1) ? (1ull << (8 * e + k)) : (diag ? (1ull << (8 * d + k)) : (1ull << (8 * e + k)));
+            // ... and the FOURTH corner of the triangle's own cell: which diagonal splits the cell has been decided above,
+            // once and identically for all four of its corners (for a similarity every cell is co-circular to rounding:
+            // re-deciding it from this site's point of view could only disagree with the other three)
+            adj |= (k & 1) ? (1ull << (8 * c2 + k)) : (diag ? (1ull << (8 * e + k)) : (1ull << (8 * d + k)));
             Mmax = fmaxf(Mmax, (float)fmax(mo, fmax(mu, mw)));
             if (!(ok_ > 0.0)) ok = false;                        // counter-clockwise triangles only
             if (A.y < 0.0 && B.y >= 0.0) ++winds;

@@ -101,7 +101,7 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
             if (intact) {
                 P2 nrel[8];
                 unsigned nb8[8];
-                const int m = star_fan(p, W, pos(p), pos, g, bstart.data(), sorted.data(), (const P2 *)nullptr, 6, nrel, 1, nb8);
+                const int m = star_fan(p, W, pos(p), pos, [&](int sl) { return pos(p + slot_offset(sl, W)); }, g, bstart.data(), sorted.data(), (const P2 *)nullptr, 6, nrel, 1, nb8);
                 if (m > 0) {
                     for (int k = 0; k < m; ++k) tag[k] = (int)nb8[k];
                     Poly Q{ vx.data(), vy.data(), tag.data(), 1, 64, m };

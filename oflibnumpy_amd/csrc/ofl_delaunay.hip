@@ -35,6 +35,8 @@ constexpr int      kRings    = 6;        // bucket rings of the per-thread star 
 constexpr int      kOpenRings = 2;       // ... of which a cell still unbounded after this many is handed on at once
 constexpr int      kNearCap  = 12;       // polygon capacity of the per-thread pass (float32 cell in LDS)
 constexpr int      kSlots    = 16;       // neighbour slots per point
+constexpr int      kNear2Rings = 6;      // coarse rings of the second per-thread pass ...
+constexpr int      kNear2Open = 3;       // ... which gives up a cell that is still unbounded after this many
 constexpr int      kMidCap   = 256;      // polygon capacity of the wave pass (unfinished points against the coarse grid of unfinished points)
 constexpr int      kMidRings = 8;        // rings of that coarse grid every unfinished point is given ...
 constexpr int      kMidRingsMax = 160;   // ... and the rings a BOUNDED cell may go on for (rims of large holes) before it is left to the workgroup pass
@@ -378,21 +380,57 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, int H, int W,
         if (base + threadIdx.x >= n_todo) return;
         const size_t p = todo[base + threadIdx.x];
         PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
-        const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings);
+        int rings_done;
+        const int rc = star_near(P, (int)p, pos((int)p), g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings, &rings_done);
         bool ok = rc == 1;
         for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
         if (!ok) {
-            // unfinished: the sites that bound the cell so far seed the cooperative passes (slot 0 will hold the point's
-            // rank, slot 1 the number of seeds) -- applied first, they spare those passes most of their clips
+            // unfinished: the sites that bound the cell so far seed the later passes (slot 0 will hold the point's rank,
+            // slot 1 the number of seeds, slot 14 the last fine ring that was applied completely) -- applied first, they
+            // spare those passes most of their clips
             deg[p] = kDegFar;
             unsigned c = 0;
             for (int k = 0; k < P.n; ++k) if (P.T(k) >= 0) nbr[p * kSlots + 2 + c++] = (unsigned)P.T(k);
             nbr[p * kSlots + 1] = c;
+            nbr[p * kSlots + 14] = (unsigned)rings_done;
             continue;
         }
         deg[p] = (unsigned char)P.n;
         for (int k = 0; k < P.n; ++k) nbr[p * kSlots + k] = (unsigned)P.T(k);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ stars, second per-thread pass
+// One thread per unfinished point that is not on the image border (those are hull points more often than not): the cell
+// is rebuilt from its seeds and finished against the coarse grid of unfinished points (ofl_dl::star_near2).  What closes
+// here -- the rims of tears at motion boundaries, of small holes -- becomes an ordinary small star; the rest stays
+// marked for the cooperative passes.
+__global__ __launch_bounds__(64)
+void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W, const DlHead *__restrict__ head,
+                          const unsigned *__restrict__ far_idx, const unsigned *__restrict__ bstart,
+                          const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                          const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt,
+                          const P2 *__restrict__ sorted1_xy, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr,
+                          unsigned *__restrict__ far_deg)
+{
+    __shared__ float s_vx[kSlots][64], s_vy[kSlots][64];
+    __shared__ int   s_tag[kSlots][64];
+    const unsigned rank = blockIdx.x * 64 + threadIdx.x;
+    if (rank >= head->n_far) return;
+    const int p = (int)far_idx[rank];
+    const int py = (int)((unsigned)p / (unsigned)W), px = p - py * W;
+    if (px == 0 || py == 0 || px == W - 1 || py == H - 1) return;
+    const Grid g = head->grid, g1 = head->grid1;
+    const PosFn pos(flow, sign, W);
+    unsigned *row = nbr + (size_t)p * kSlots;
+    const int ns = min((int)row[1], kSlots - 4);
+    PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kSlots, 0 };
+    const int rc = star_near2(P, p, pos(p), row + 2, ns, (int)row[14], kRings, g, bstart, sorted, sorted_xy,
+                              kNear2Rings, g1, b1start, sorted1_pt, sorted1_xy, pos, kNear2Open);
+    if (rc != 1) return;
+    for (int k = 0; k < P.n; ++k) row[k] = (unsigned)P.T(k);
+    deg[p] = (unsigned char)P.n;
+    far_deg[rank] = 0;                                     // not a cooperative-pass star: nothing in the pool
 }
 
 // compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx,
@@ -796,8 +834,8 @@ __global__ __launch_bounds__(64)
 void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
-                        const unsigned *__restrict__ far_idx, const unsigned *__restrict__ nbr, unsigned *__restrict__ far_deg,
-                        unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
+                        const unsigned *__restrict__ far_idx, const unsigned char *__restrict__ deg, const unsigned *__restrict__ nbr,
+                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
 {
     __shared__ FarLds<kMidCap, 64> L;
     __shared__ unsigned s_off;
@@ -805,6 +843,7 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     const unsigned rank = blockIdx.x;
     if (rank >= head->n_far) return;
     const int p = (int)far_idx[rank];
+    if (deg[p] != kDegFar) return;                         // finished by the second per-thread pass
     const Grid g = head->grid, g1 = head->grid1;
     const PosFn pos(flow, sign, W);
     const P2 pp = pos(p);
@@ -1318,9 +1357,12 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                            (const DlHead *)ws.head, 1, (const unsigned *)ws.b1start, ws.sorted1);
         hipLaunchKernelGGL(dl_list_xy_kernel<1>, dim3(std::min<unsigned>(rblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
                            (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, ws.sorted1_xy, ws.sorted1_pt);
+        hipLaunchKernelGGL(dl_star_near2_kernel, dim3((h.n_far + 63) / 64), dim3(64), 0, s, flow, sign_pp, H, W, (const DlHead *)ws.head,
+                           (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
+                           (const unsigned *)ws.b1start, (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, ws.deg, ws.nbr, ws.far_deg);
         hipLaunchKernelGGL(dl_star_mid_kernel, dim3(h.n_far), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
-                           (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
+                           (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned char *)ws.deg, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
                            (unsigned long long)ws.pool_cap);
         OFL_HIP(hipGetLastError());
         const unsigned lblk = (h.n_far + kScanChunk - 1) / kScanChunk;

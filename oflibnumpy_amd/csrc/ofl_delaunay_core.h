@@ -140,19 +140,27 @@ DL_HD P2 cut_point(int tag, const P2 &C, double h, RelFn rel, double ux, double 
     return r;
 }
 
-// Clips the polygon with the bisector of candidate `ctag` at relative position C.  Returns 0 (unchanged), 1 (clipped)
-// or -1 (the polygon would exceed its capacity; it is left unchanged).  Sequential; n <= 64.
+// Which vertices of the polygon does the bisector of candidate `ctag` at relative position C cut off?  (bit k = vertex k;
+// n <= 64.)  0 also when EVERY vertex would go: the site itself is inside every half-plane, so that is rounding only.
 template <class PolyX, class RelFn>
-DL_HD int poly_clip(PolyX &P, const P2 &C, int ctag, int ptag, RelFn rel)
+DL_HD unsigned long long poly_cutmask(const PolyX &P, const P2 &C, int ctag, int ptag, RelFn rel)
 {
     const double h = 0.5 * (C.x * C.x + C.y * C.y);
     const int n = P.n;
     unsigned long long cut = 0;
     for (int k = 0; k < n; ++k)
         if (vertex_cut(P, k, n, C, ctag, ptag, h, rel)) cut |= 1ull << k;
-    if (!cut) return 0;
     const unsigned long long full = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    if (cut == full) return 0;                       // the site itself is inside every half-plane: rounding only
+    return cut == full ? 0ull : cut;
+}
+
+// Removes the vertices of a non-empty `cut` mask (poly_cutmask) and closes the polygon with the candidate's edge.
+// Returns 1, or -1 when the polygon would exceed its capacity (it is left unchanged).
+template <class PolyX, class RelFn>
+DL_HD int poly_apply(PolyX &P, const P2 &C, int ctag, RelFn rel, unsigned long long cut)
+{
+    const double h = 0.5 * (C.x * C.x + C.y * C.y);
+    const int n = P.n;
     int a = -1;
     for (int k = 0; k < n; ++k)
         if (((cut >> k) & 1ull) && !((cut >> (k == 0 ? n - 1 : k - 1)) & 1ull)) { a = k; break; }
@@ -178,6 +186,15 @@ DL_HD int poly_clip(PolyX &P, const P2 &C, int ctag, int ptag, RelFn rel)
     }
     P.n = n2;
     return 1;
+}
+
+// Clips the polygon with the bisector of candidate `ctag` at relative position C.  Returns 0 (unchanged), 1 (clipped)
+// or -1 (the polygon would exceed its capacity; it is left unchanged).  Sequential; n <= 64.
+template <class PolyX, class RelFn>
+DL_HD int poly_clip(PolyX &P, const P2 &C, int ctag, int ptag, RelFn rel)
+{
+    const unsigned long long cut = poly_cutmask(P, C, ctag, ptag, rel);
+    return cut ? poly_apply(P, C, ctag, rel, cut) : 0;
 }
 
 // squared distance of the farthest cell vertex from the site
@@ -252,13 +269,16 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
 // so far as seeds.
 template <class PolyX, class PosFn>
 DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
-                    PosFn pos, int rings, const P2 *sorted_xy = nullptr, int open_rings = 1 << 30)
+                    PosFn pos, int rings, const P2 *sorted_xy = nullptr, int open_rings = 1 << 30,
+                    int *rings_done = nullptr)               // receives the last ring that was applied completely (-1: none)
 {
     poly_init(P);
     const int bx = g.bx(pp.x), by = g.by(pp.y);
     double reach2 = 4.0 * poly_rmax2(P);
+    if (rings_done) *rings_done = -1;
     for (int r = 0; r <= rings; ++r) {
         if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy) < 0) return -1;
+        if (rings_done) *rings_done = r;
         const double cover = (double)r * g.s;
         if (cover * cover >= reach2) return 1;
         if (r >= open_rings) {
@@ -446,6 +466,54 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const 
 #endif
     for (int s = 0; s < 8; ++s) if (present[s]) nbr_out[n++] = (unsigned)(p + off[s]);
     return n;
+}
+
+// Second per-thread attempt at a star the ring search left unfinished (rims of tears and small holes: cells tens of
+// bucket widths across, far too few vertices to be worth a workgroup).  The sites that bounded the cell when the ring
+// search stopped (`seeds`) rebuild it; the fine rings the search did not reach are applied; then rings of the COARSE
+// grid, which holds only the unfinished sites -- a Delaunay neighbour beyond the fine rings is itself unfinished (a
+// finished site has all its neighbours within its own ring search, and a fan-verified one within kFanSpan buckets).
+// Returns 1 when the cell is final and bounded, 0 when it is not within `rings1` coarse rings (or still unbounded), -1
+// on polygon overflow.
+template <class PolyX, class PosFn>
+DL_HD int star_near2(PolyX &P, int p, const P2 &pp, const unsigned *seeds, int nseeds, int rings_done, int rings,
+                     const Grid &g, const unsigned *bstart, const unsigned *sorted, const P2 *sorted_xy,
+                     int rings1, const Grid &g1, const unsigned *b1start, const unsigned *sorted1, const P2 *sorted1_xy,
+                     PosFn pos, int open_rings1 = 1 << 30)
+{
+    auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
+    poly_init(P);
+    for (int i = 0; i < nseeds; ++i) {
+        const int c = (int)seeds[i];
+        if (poly_clip(P, rel(c), c, p, rel) < 0) return -1;
+    }
+    double reach2 = 4.0 * poly_rmax2(P);
+    // the coarse rings first: they are sparse, and a cell they cannot close (the rim of a large hole) is given up before
+    // the dense fine rings are touched; the order in which half-planes are applied does not change their intersection
+    {
+        const int bx = g1.bx(pp.x), by = g1.by(pp.y);
+        const int a = bx > g1.gx - 1 - bx ? bx : g1.gx - 1 - bx, b = by > g1.gy - 1 - by ? by : g1.gy - 1 - by;
+        const int rgrid = a > b ? a : b;                  // beyond this ring the coarse grid is exhausted
+        bool done = false;
+        for (int r = 0; r <= rings1 && !done; ++r) {
+            if (apply_ring(P, p, pp, bx, by, r, g1, b1start, sorted1, pos, reach2, sorted1_xy) < 0) return -1;
+            const double cover = (double)r * g1.s;
+            done = cover * cover >= reach2 || r >= rgrid;
+            if (!done && r >= open_rings1) {              // still unbounded this far out: a large hole, not a tear
+                bool open = false;
+                for (int k = 0; k < P.n; ++k) open = open || P.T(k) < 0;
+                if (open) return 0;
+            }
+        }
+        if (!done) return 0;
+    }
+    {
+        const int bx = g.bx(pp.x), by = g.by(pp.y);
+        for (int r = rings_done + 1; r <= rings; ++r)
+            if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy) < 0) return -1;
+    }
+    for (int k = 0; k < P.n; ++k) if (P.T(k) < 0) return 0;
+    return 1;
 }
 
 // Rotation of a triangle's vertex indices that puts the smallest first without changing the cyclic order: every copy

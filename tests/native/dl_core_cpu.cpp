@@ -89,7 +89,9 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
         }
     };
     std::vector<float> fx(64), fy(64);
-    int fans = 0;
+    std::vector<std::vector<unsigned>> seed_of(n);
+    std::vector<int> rd_of(n, -1);
+    int fans = 0, near2 = 0;
     const int H = W > 0 ? n / W : 0;
     for (int p = 0; p < n; ++p) {
         if (!is_kept(p)) continue;
@@ -114,7 +116,8 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
         // near_cap < 0: the float32 cell of the GPU's per-thread pass
         if (near_cap < 0) {
             PolyT<float> P{ fx.data(), fy.data(), tag.data(), 1, -near_cap, 0 };
-            const int rc = star_near(P, p, pos(p), g, bstart.data(), sorted.data(), pos, rings);
+            int rdone = -1;
+            const int rc = star_near(P, p, pos(p), g, bstart.data(), sorted.data(), pos, rings, (const P2 *)nullptr, 2, &rdone);
             bool ok = rc == 1;
             for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
             if (ok) {
@@ -123,6 +126,8 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
                 continue;
             }
             if (rc < 0) ++overflow;
+            for (int k = 0; k < P.n; ++k) if (P.T(k) >= 0) seed_of[p].push_back((unsigned)P.T(k));
+            rd_of[p] = rdone;
             far.push_back(p);
             continue;
         }
@@ -132,7 +137,31 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
         if (rc < 0) ++overflow;
         far.push_back(p);
     }
+    // the GPU's second per-thread pass: coarse grid (8 fine buckets per cell) of the unfinished sites
+    std::vector<char> finished(n, 0);
+    if (near_cap < 0 && !far.empty()) {
+        Grid g1 = g;
+        g1.s = g.s * 8; g1.inv_s = 1.0 / g1.s; g1.gx = (g.gx + 7) / 8; g1.gy = (g.gy + 7) / 8;
+        const size_t nb1 = (size_t)g1.gx * g1.gy;
+        std::vector<unsigned> b1(nb1 + 1, 0), s1(far.size()), c1(nb1, 0);
+        auto bucket1 = [&](int i) { return (size_t)g1.by(pts[2 * i + 1]) * g1.gx + g1.bx(pts[2 * i]); };
+        for (int i : far) ++b1[bucket1(i) + 1];
+        for (size_t b = 0; b < nb1; ++b) b1[b + 1] += b1[b];
+        for (int i : far) { const size_t b = bucket1(i); s1[b1[b] + c1[b]++] = (unsigned)i; }
+        for (int p : far) {
+            if (W > 0) { const int x = p % W, y = p / W; if (x == 0 || y == 0 || x == W - 1 || y == H - 1) continue; }
+            PolyT<float> P{ fx.data(), fy.data(), tag.data(), 1, 16, 0 };
+            const int rc = star_near2(P, p, pos(p), seed_of[p].data(), (int)seed_of[p].size(), rd_of[p], rings, g, bstart.data(),
+                                      sorted.data(), (const P2 *)nullptr, 6, g1, b1.data(), s1.data(), (const P2 *)nullptr, pos);
+            if (rc != 1) continue;
+            Poly Q{ vx.data(), vy.data(), tag.data(), 1, 64, P.n };
+            emit(p, Q);
+            finished[p] = 1;
+            ++near2;
+        }
+    }
     for (int p : far) {
+        if (finished[p]) continue;
         Poly P{ vx.data(), vy.data(), tag.data(), 1, 4096, 0 };
         poly_init(P);
         const P2 pp = pos(p);
@@ -161,7 +190,7 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
         emit(p, P);
     }
     *n_tri = nt;
-    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy; info[4] = maxdeg; info[5] = fans;
+    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy; info[4] = maxdeg; info[5] = fans; info[6] = near2;
     return 0;
 }
 

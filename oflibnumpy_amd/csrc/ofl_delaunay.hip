@@ -72,6 +72,7 @@ struct DlWs {
     unsigned *sorted;      // [N] point indices bucket by bucket
     unsigned char *deg;    // [N] 0 .. 16, kDegTodo, kDegFar
     unsigned *todo_idx;    // [N] points for the clip pass, ascending
+    unsigned char *dup;    // [N] 1 = an exact duplicate of a site with a smaller index (not a site of the triangulation)
     unsigned *nbr;         // [N][kSlots]   (doubles as the bucket cursors while sorting)
     unsigned *far_idx;     // [N]
     unsigned *far_deg;     // [N]
@@ -326,6 +327,27 @@ void dl_list_xy_kernel(const float *__restrict__ flow, int sign, int W, const Dl
     }
 }
 
+// Exact duplicates (folded integer-valued fields: BASELINE config 5 puts several sites on most lattice nodes): Qhull keeps
+// ONE vertex per location and which one is its own business, so only the smallest index of a location stays a site here.
+// The others are flagged, and their entries in the bucket list are blanked (index 0xFFFFFFFF: every consumer skips
+// negative candidates) -- a field with five sheets builds a fifth of the stars.
+__global__ __launch_bounds__(256)
+void dl_dedupe_kernel(const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted,
+                      const P2 *__restrict__ sorted_xy, unsigned char *__restrict__ dup)
+{
+    const size_t nb = (size_t)head->grid.gx * head->grid.gy;
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
+        const unsigned lo = bstart[b], hi = bstart[b + 1];
+        if (hi - lo < 2 || hi - lo > 256) continue;
+        for (unsigned j = lo + 1; j < hi; ++j) {
+            const P2 q = sorted_xy[j];
+            bool same = false;
+            for (unsigned i = lo; i < j && !same; ++i) same = sorted[i] != 0xFFFFFFFFu && sorted_xy[i].x == q.x && sorted_xy[i].y == q.y;
+            if (same) { dup[sorted[j]] = 1; sorted[j] = 0xFFFFFFFFu; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ stars, mesh-fan pass
 // One thread per point: a point whose eight grid neighbours are kept proposes the star of the cell-wise mesh and verifies
 // it against the sites under its circumcircles (ofl_dl::star_fan).  Verified stars are final; everything else is marked
@@ -333,19 +355,23 @@ void dl_list_xy_kernel(const float *__restrict__ flow, int sign, int W, const Dl
 __global__ __launch_bounds__(kFanBlock)
 void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
                         const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
-                        const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                        const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy, const unsigned char *__restrict__ dup,
                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
     __shared__ P2 s_rel[8][kFanBlock];
     const unsigned per = gridDim.x >> 3;                        // (grid padded to a multiple of 8) one contiguous eighth per XCD
     const size_t p = (size_t)((blockIdx.x & 7u) * per + (blockIdx.x >> 3)) * kFanBlock + threadIdx.x;
     if (p >= (size_t)H * W) return;
-    if (!kept_pt(pmask, p)) { deg[p] = 0; return; }
+    if (!kept_pt(pmask, p) || dup[p]) { deg[p] = 0; return; }
     const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
     bool intact = x >= 1 && y >= 1 && x <= W - 2 && y <= H - 2;
     if (intact && pmask) {
         const uint8_t *m = pmask + p;
         intact = m[-W - 1] && m[-W] && m[-W + 1] && m[-1] && m[1] && m[W - 1] && m[W] && m[W + 1];
+    }
+    if (intact) {
+        const unsigned char *m = dup + p;
+        intact = !(m[-W - 1] | m[-W] | m[-W + 1] | m[-1] | m[1] | m[W - 1] | m[W] | m[W + 1]);
     }
     int n = 0;
     if (intact) {
@@ -1226,6 +1252,7 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.sorted = (unsigned *)p;              p += align_up(n * 4, 256);
     ws.deg = (unsigned char *)p;            p += align_up(n, 256);
     ws.todo_idx = (unsigned *)p;            p += align_up(n * 4, 256);
+    ws.dup = (unsigned char *)p;            p += align_up(n, 256);
     ws.nbr = (unsigned *)p;                 p += align_up(std::max(n * kSlots, ws.bcap) * 4, 256);
     ws.far_idx = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_deg = (unsigned *)p;             p += align_up(n * 4, 256);
@@ -1313,11 +1340,14 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        (const DlHead *)ws.head, 0, (const unsigned *)ws.bstart, ws.sorted);
     hipLaunchKernelGGL(dl_list_xy_kernel<0>, dim3(std::min<unsigned>(nblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
                        (const unsigned *)ws.sorted, (const unsigned *)nullptr, ws.sorted_xy, (unsigned *)nullptr);
+    OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
+    hipLaunchKernelGGL(dl_dedupe_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
+                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy, ws.dup);
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
     unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
     hipLaunchKernelGGL(dl_star_fan_kernel, dim3((unsigned)(((n + kFanBlock - 1) / kFanBlock + 7) / 8 * 8)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
-                       ws.deg, ws.nbr);
+                       (const unsigned char *)ws.dup, ws.deg, ws.nbr);
     // what the fans did not settle, in index order, for the clip pass
     hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));

@@ -405,7 +405,7 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const 
             const int qi = (int)sorted[j];
             const P2 C = { qa.x - pp.x, qa.y - pp.y };
             const float cxf = (float)C.x, cyf = (float)C.y, c2f = cxf * cxf + cyf * cyf;
-            if (qi == p || (C.x == 0.0 && C.y == 0.0)) continue;                  // the site itself, or a duplicate of it
+            if (qi < 0 || qi == p || (C.x == 0.0 && C.y == 0.0)) continue;        // a blanked entry, the site itself, or a duplicate of it
             const float marg = kFanEpsF * (c2f + fabsf(cxf) + fabsf(cyf)) * Mmax;
             unsigned need = 0;
 #ifdef __HIPCC__

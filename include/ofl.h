@@ -69,8 +69,12 @@ enum {
 /* flags OR-ed into the `valid_rule` argument of the scatter entries */
 enum {
     OFL_SCATTER_ROUND  = 0x100,  /* out = rint(result): np.round of integer-typed targets, utils.py:256-257 */
-    OFL_SCATTER_NEGATE = 0x200   /* out = -result: the values are -vals (Flow.invert s->s = self.apply(-self), flow_class.py:746,
+    OFL_SCATTER_NEGATE = 0x200,  /* out = -result: the values are -vals (Flow.invert s->s = self.apply(-self), flow_class.py:746,
                                     without materialising -self; negation commutes exactly with the interpolation) */
+    OFL_SCATTER_UNCERTIFIED = 0x400  /* the caller KNOWS the mesh cannot be certified (a certificate from ofl_scatter_certify_dev
+                                    that says so, or a point mask with zeros): the entry skips its own certificate pass and
+                                    read-back and takes the Delaunay path at once.  Never changes a result -- that path is the
+                                    general one -- only saves the pass */
 };
 
 /* bits written by the zero-flow statistics (ofl_flow_stats_dev, and the fused compose kernel) */

@@ -16,7 +16,7 @@ U8, I16, U16, F32, F64 = 0, 1, 2, 3, 4
 QUANT_OPENCV, QUANT_EXACT = 0, 1
 ARITH_NATIVE, ARITH_FLOAT_RNE = 0, 1
 RULE_EQ1, RULE_GE_HALF, RULE_GT_HALF = 0, 1, 2
-SCATTER_ROUND, SCATTER_NEGATE = 0x100, 0x200
+SCATTER_ROUND, SCATTER_NEGATE, SCATTER_UNCERTIFIED = 0x100, 0x200, 0x400
 STAT_NONZERO_MASKED, STAT_NONZERO_TH_MASKED, STAT_NONZERO, STAT_NONZERO_TH, STAT_NONFINITE, STAT_MASK_HAS_ZERO = 1, 2, 4, 8, 16, 32
 
 

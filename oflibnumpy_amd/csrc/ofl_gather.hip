@@ -10,6 +10,7 @@
 // Numerics follow oracle/ofl_oracle.c operation for operation (contraction disabled) so that the
 // float results and the validity masks are bit-identical to the CPU restatement.
 #include "ofl_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #pragma clang fp contract(off)
@@ -980,13 +981,13 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
                                           const Tap &tp, const int (&wi)[4], bool fixed_u8, int arith, int rule,
                                           bool want_valid, T (&res)[CT], bool &ok)
 {
-    bool   in[4];
-    size_t off[4];
+    bool     in[4];
+    uint32_t off[4];          // 32-bit offsets (the paired kernel takes images below 4 GiB): scalar base + 32-bit lane offset, no 64-bit address math
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int yy = tp.iy + (k >> 1), xx = tp.ix + (k & 1);
         in[k]  = INSIDE ? true : ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W);
-        off[k] = in[k] ? (size_t)yy * W + xx : 0;
+        off[k] = in[k] ? __umul24((uint32_t)yy, (uint32_t)W) + (uint32_t)xx : 0u;      // 24-bit multiplies are full rate, 32-bit ones a quarter
     }
     // the mask taps are requested BEFORE the image taps (their latency hides behind the image loads); inside the
     // image the two taps of a row are one 2-byte load (unaligned addresses are fine for global loads on gfx950)
@@ -1009,8 +1010,19 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
     constexpr bool kRun = INSIDE && (sizeof(T) <= 2 || (sizeof(T) == 4 && CT <= 2));     // float: 1 or 2 channels = 8 / 16 bytes per row
     uint32_t run[2][4] = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
     if constexpr (kRun) {
+        constexpr int kRB = 2 * CT * (int)sizeof(T);
+        // 6- and 12-byte runs are read as ONE 8- / 16-byte load (two or four bytes too many) wherever that stays inside the
+        // image -- everywhere but the last pixels of the last row
+        const uint32_t total = (uint32_t)H * (uint32_t)W * (uint32_t)(CT * sizeof(T));
 #pragma unroll
-        for (int r = 0; r < 2; ++r) load_run<2 * CT * (int)sizeof(T)>(reinterpret_cast<const uint8_t *>(src + off[2 * r] * CT), run[r]);
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t at = off[2 * r] * (uint32_t)(CT * sizeof(T));
+            const uint8_t *pr = reinterpret_cast<const uint8_t *>(src) + at;
+            if constexpr (kRB == 6 || kRB == 12) {
+                if (at + kRB + kRB / 3 <= total) load_run<kRB + kRB / 3>(pr, run[r]);
+                else                             load_run<kRB>(pr, run[r]);
+            } else load_run<kRB>(pr, run[r]);
+        }
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -1020,13 +1032,13 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
             v[2] = (A)run_elem<T>(run[1], c); v[3] = (A)run_elem<T>(run[1], CT + c);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = in[k] ? (A)src[off[k] * CT + c] : (A)0;
+            for (int k = 0; k < 4; ++k) v[k] = in[k] ? (A)(src + off[k] * (uint32_t)CT)[c] : (A)0;      // (one zero-extended base per tap: the channel loads still merge)
         }
         if constexpr (sizeof(T) == 8) {
             res[c] = (T)blend4d(v[0], v[1], v[2], v[3], tp);
         } else {
             if (fixed_u8) {
-                const int acc = (int)v[0] * wi[0] + (int)v[1] * wi[1] + (int)v[2] * wi[2] + (int)v[3] * wi[3];
+                const int acc = __mul24((int)v[0], wi[0]) + __mul24((int)v[1], wi[1]) + __mul24((int)v[2], wi[2]) + __mul24((int)v[3], wi[3]);
                 res[c] = (T)min(max((acc + (1 << 14)) >> 15, 0), 255);
             } else {
                 res[c] = finish<T>(blend4((float)v[0], (float)v[1], (float)v[2], (float)v[3], tp), arith);
@@ -1036,7 +1048,7 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
     ok = false;
     if (want_valid) {
         if (rule == OFL_RULE_GE_HALF) {
-            const int acc = m[0] * wi[0] + m[1] * wi[1] + m[2] * wi[2] + m[3] * wi[3];
+            const int acc = __mul24(m[0], wi[0]) + __mul24(m[1], wi[1]) + __mul24(m[2], wi[2]) + __mul24(m[3], wi[3]);
             ok = ((acc + (1 << 14)) >> 15) == 1;
         } else {
             const float sm = blend4((float)m[0], (float)m[1], (float)m[2], (float)m[3], tp);
@@ -1061,8 +1073,8 @@ __device__ __forceinline__ void gather2_core(const T *__restrict__ src, const ui
         const float px = map_coord(gx[j], fu[j], sign), py = map_coord(y, fv[j], sign);
         tp[j] = (quant == OFL_QUANT_OPENCV) ? make_tap<OFL_QUANT_OPENCV>(px, py) : make_tap<OFL_QUANT_EXACT>(px, py);
         if (quant == OFL_QUANT_OPENCV) {
-            wi[j][0] = (32 - tp[j].ay) * (32 - tp[j].ax) * 32; wi[j][1] = (32 - tp[j].ay) * tp[j].ax * 32;
-            wi[j][2] = tp[j].ay * (32 - tp[j].ax) * 32;        wi[j][3] = tp[j].ay * tp[j].ax * 32;
+            wi[j][0] = __mul24(32 - tp[j].ay, 32 - tp[j].ax) * 32; wi[j][1] = __mul24(32 - tp[j].ay, tp[j].ax) * 32;
+            wi[j][2] = __mul24(tp[j].ay, 32 - tp[j].ax) * 32;      wi[j][3] = __mul24(tp[j].ay, tp[j].ax) * 32;
         } else {
             wi[j][0] = __float2int_rn(tp[j].w0 * 32768.0f); wi[j][1] = __float2int_rn(tp[j].w1 * 32768.0f);
             wi[j][2] = __float2int_rn(tp[j].w2 * 32768.0f); wi[j][3] = __float2int_rn(tp[j].w3 * 32768.0f);
@@ -1129,24 +1141,24 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
         fu[2 * g] = fv[2 * g] = fu[2 * g + 1] = fv[2 * g + 1] = 0.0f;
         if (fmask && valid) {
             if (aligned && inf[2 * g] && inf[2 * g + 1]) {
-                fmw[g] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(fmask + (size_t)fy * fW + fx));
+                fmw[g] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(fmask + __umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)fx));
             } else {
-                if (inf[2 * g]) fmw[g] |= fmask[(size_t)fy * fW + fx];
-                if (inf[2 * g + 1]) fmw[g] |= (uint32_t)fmask[(size_t)fy * fW + fx + 1] << 8;
+                if (inf[2 * g]) fmw[g] |= fmask[__umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)fx];
+                if (inf[2 * g + 1]) fmw[g] |= (uint32_t)fmask[__umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)fx + 1] << 8;
             }
         }
         if (aligned && inf[2 * g] && inf[2 * g + 1]) {
 #if OFL_G2_NT_FLOW
-            const v4f f = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(flow + ((size_t)fy * fW + fx) * 2));
+            const v4f f = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(flow + (__umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)fx) * 2));
 #else
-            const float4 f = *reinterpret_cast<const float4 *>(flow + ((size_t)fy * fW + fx) * 2);
+            const float4 f = *reinterpret_cast<const float4 *>(flow + (__umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)fx) * 2);
 #endif
             fu[2 * g] = f.x; fv[2 * g] = f.y; fu[2 * g + 1] = f.z; fv[2 * g + 1] = f.w;
         } else {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 if (inf[2 * g + e]) {
-                    const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)fy * fW + fx + e) * 2);
+                    const float2 f = *reinterpret_cast<const float2 *>(flow + (__umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)fx + e) * 2);
                     fu[2 * g + e] = f.x; fv[2 * g + e] = f.y;
                 }
         }
@@ -1217,20 +1229,58 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
     }
 
     uint32_t vword[2] = { 0u, 0u };
+    // 8- and 16-bit results leave as DWORDS as well: the two pixels of a lane are 2 .. 16 bytes; 2- and 6-byte pairs are
+    // joined with the neighbouring lane's (four consecutive pixels = 4 / 12 bytes, dword-aligned when W is a multiple of 4).
+    // Element-wise byte stores made this kernel instruction-bound: RGB uint8 cost 12 stores per lane, now 3 per lane PAIR.
+    constexpr int kPB = 2 * CT * (int)sizeof(T);          // bytes of a pixel pair
+    constexpr bool kPack = sizeof(T) <= 2;
+    const bool quad4 = (W & 3) == 0;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        if (!act[g]) continue;
-        const size_t o = (size_t)yl * W + xg[g];
-        T *d = dst + o * CT;
+        const uint32_t o = __umul24((uint32_t)yl, (uint32_t)W) + (uint32_t)xg[g];
+        if constexpr (kPack) {
+            uint32_t pw[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+            for (int i = 0; i < 2 * CT; ++i) {
+                const uint32_t v = (uint32_t)(typename std::make_unsigned<T>::type)res[2 * g + i / CT][i % CT];
+                if constexpr (sizeof(T) == 1) pw[i >> 2] |= v << (8 * (i & 3));
+                else                          pw[i >> 1] |= v << (16 * (i & 1));
+            }
+            uint8_t *d8 = reinterpret_cast<uint8_t *>(dst) + o * (uint32_t)(CT * sizeof(T));
+            if constexpr (kPB == 2 || kPB == 6) {
+                const uint32_t q0 = (uint32_t)__shfl_xor((int)pw[0], 1), q1 = (uint32_t)__shfl_xor((int)pw[1], 1);
+                if (quad4) {
+                    if (act[g] && (lx & 1) == 0) {
+                        if constexpr (kPB == 2) {
+                            *reinterpret_cast<uint32_t *>(d8) = pw[0] | (q0 << 16);
+                        } else {
+                            uint32_t *d32 = reinterpret_cast<uint32_t *>(d8);
+                            d32[0] = pw[0]; d32[1] = pw[1] | (q0 << 16); d32[2] = (q0 >> 16) | (q1 << 16);
+                        }
+                    }
+                } else if (act[g]) {
+                    if constexpr (kPB == 2) *reinterpret_cast<uint16_t *>(d8) = (uint16_t)pw[0];
+                    else { *reinterpret_cast<uint16_t *>(d8) = (uint16_t)pw[0]; *reinterpret_cast<uint16_t *>(d8 + 2) = (uint16_t)(pw[0] >> 16);
+                           *reinterpret_cast<uint16_t *>(d8 + 4) = (uint16_t)pw[1]; }
+                }
+            } else if (act[g]) {
+                if constexpr (kPB == 4)       *reinterpret_cast<uint32_t *>(d8) = pw[0];
+                else if constexpr (kPB == 8)  *reinterpret_cast<uint2 *>(d8) = make_uint2(pw[0], pw[1]);
+                else if constexpr (kPB == 12) { uint32_t *d32 = reinterpret_cast<uint32_t *>(d8); d32[0] = pw[0]; d32[1] = pw[1]; d32[2] = pw[2]; }
+                else                          *reinterpret_cast<uint4 *>(d8) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            }
+        } else if (act[g]) {
+            T *d = dst + o * (uint32_t)CT;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
 #if OFL_G2_NT_DST
-            for (int c = 0; c < CT; ++c) __builtin_nontemporal_store(res[2 * g + e][c], &d[e * CT + c]);
+                for (int c = 0; c < CT; ++c) __builtin_nontemporal_store(res[2 * g + e][c], &d[e * CT + c]);
 #else
-            for (int c = 0; c < CT; ++c) d[e * CT + c] = res[2 * g + e][c];
+                for (int c = 0; c < CT; ++c) d[e * CT + c] = res[2 * g + e][c];
 #endif
-        if (want_valid) {
+        }
+        if (act[g] && want_valid) {
             uint32_t m = (ok[2 * g] ? 1u : 0u) | (ok[2 * g + 1] ? 0x100u : 0u);
             if (fmask) m &= ((fmw[g] & 0xffu) ? 1u : 0u) | ((fmw[g] & 0xff00u) ? 0x100u : 0u);
             vword[g] = m;
@@ -1244,7 +1294,7 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
         for (int g = 0; g < 2; ++g) {
             const uint32_t other = (uint32_t)__shfl_xor((int)vword[g], 1);
             if (!act[g]) continue;
-            const size_t o = (size_t)yl * W + xg[g];
+            const uint32_t o = __umul24((uint32_t)yl, (uint32_t)W) + (uint32_t)xg[g];
             if (quad) {
                 if ((lx & 1) == 0) __builtin_nontemporal_store(vword[g] | (other << 16), reinterpret_cast<uint32_t *>(valid + o));
             } else {
@@ -1259,7 +1309,8 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
                     int pad_left, int sign, const uint8_t *smask, const uint8_t *fmask, void *dst,
                     uint8_t *valid, int quant, int arith, int rule, int row0, int rows, hipStream_t s)
 {
-    if (W % 2 == 0 && C >= 1 && C <= 4) {
+    // (the paired kernel addresses with 32-bit offsets: images, flows and results below 4 GiB)
+    if (W % 2 == 0 && C >= 1 && C <= 4 && (unsigned long long)H * W * C * sizeof(T) < (1ull << 32) && (unsigned long long)fH * fW * 8 < (1ull << 32)) {
         const int tiles_x = (W + 127) / 128, tiles_y = (rows + 7) / 8;
         const int nblocks = tiles_x * tiles_y;
         static const int swz = getenv("OFL_G2_SWZ") ? atoi(getenv("OFL_G2_SWZ")) : 0;          // tuning knob: 1 = XCD swizzle

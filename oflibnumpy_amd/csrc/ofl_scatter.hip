@@ -34,7 +34,7 @@ int check_common(const char *who, const float *flow, int &sign, int point_precis
     if (C == 0 && !valid) return fail(OFL_E_INVALID, "%s: nothing to compute", who);
     if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "%s: sign must be +1 or -1", who);
     if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "%s: bad point_precision", who);
-    if ((valid_rule & ~(3 | OFL_SCATTER_ROUND | OFL_SCATTER_NEGATE)) || (valid_rule & 3) == 3) return fail(OFL_E_INVALID, "%s: bad valid_rule", who);
+    if ((valid_rule & ~(3 | OFL_SCATTER_ROUND | OFL_SCATTER_NEGATE | OFL_SCATTER_UNCERTIFIED)) || (valid_rule & 3) == 3) return fail(OFL_E_INVALID, "%s: bad valid_rule", who);
     if (workspace_bytes < kMinWorkspace) return fail(OFL_E_INVALID, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, kMinWorkspace);
     if (point_precision == 1) sign *= 2;          // the point precision rides in bit 1 of the sign's magnitude
     return OFL_OK;
@@ -50,11 +50,13 @@ int scatter_grid_impl(const char *who, const float *flow, int sign, int point_pr
     OFL_TRY(check_common(who, flow, sign, point_precision, C, vals, out, valid, valid_rule, H, W, workspace, workspace_bytes));
     if (row0 < 0 || rows <= 0 || row0 + rows > H)
         return fail(OFL_E_INVALID, "%s: rows [%d, %d) outside the %d-row grid", who, row0, row0 + rows, H);
-    ofl_mesh_cert cert;
-    OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));       // a point mask without zeros drops nothing
-    if (cert.certified) {
-        if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
-        return walk_launch<VT>(flow, sign, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule, &cert, nullptr, s);
+    if (!(valid_rule & OFL_SCATTER_UNCERTIFIED)) {
+        ofl_mesh_cert cert;
+        OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));       // a point mask without zeros drops nothing
+        if (cert.certified) {
+            if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
+            return walk_launch<VT>(flow, sign, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule, &cert, nullptr, s);
+        }
     }
     return exact_scatter<VT>(flow, sign, pmask, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule,
                              workspace, workspace_bytes, info_host, s);
@@ -67,11 +69,13 @@ int scatter_query_impl(const char *who, const float *flow, int sign, int point_p
                        uint64_t *info_host, hipStream_t s)
 {
     OFL_TRY(check_common(who, flow, sign, point_precision, C, vals, out, valid, valid_rule, H, W, workspace, workspace_bytes));
-    ofl_mesh_cert cert;
-    OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));
-    if (cert.certified) {
-        if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
-        return walk_query_launch(flow, sign, vals, C, vmask, H, W, query, n, sparse, out, valid, valid_rule, &cert, s);
+    if (!(valid_rule & OFL_SCATTER_UNCERTIFIED)) {
+        ofl_mesh_cert cert;
+        OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));
+        if (cert.certified) {
+            if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
+            return walk_query_launch(flow, sign, vals, C, vmask, H, W, query, n, sparse, out, valid, valid_rule, &cert, s);
+        }
     }
     return exact_query(flow, sign, pmask, vals, C, vmask, H, W, query, n, sparse, out, valid, valid_rule,
                        workspace, workspace_bytes, info_host, s);

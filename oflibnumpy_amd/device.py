@@ -481,7 +481,7 @@ class DeviceFlow:
         valid = DeviceBuffer(self.n_px)
         pm = self._point_mask(consider_mask)
         scatter_linear(self.vecs, +1, pm, image.buf, C, vmask, h, w, None, out.buf, valid, 0,
-                       cert=self.mesh_cert(+1) if pm is None else None)
+                       cert=self.mesh_cert(+1) if pm is None else None, drops_points=pm is not None)
         return out, valid
 
     def resize(self, scale):
@@ -526,7 +526,7 @@ class DeviceFlow:
             _mask_and(target.mask, self.mask, vmask, self.n_px)  # mask channel, flow_class.py:643
         pm = self._point_mask(consider_mask)
         scatter_linear(self.vecs, sign, pm, target.vecs, 2, vmask, h, w, None, out.vecs, out.mask,
-                       nat.SCATTER_NEGATE if negate else 0, cert=self.mesh_cert(sign) if pm is None else None)
+                       nat.SCATTER_NEGATE if negate else 0, cert=self.mesh_cert(sign) if pm is None else None, drops_points=pm is not None)
         return out
 
     def switch_ref(self):
@@ -639,7 +639,7 @@ class DeviceFlow:
         valid = DeviceBuffer(self.n_px)
         pm = self._point_mask(consider_mask)
         scatter_linear(self.vecs, sign, pm, None, 0, self.mask, h, w, None, None, valid, 0,
-                       cert=self.mesh_cert(sign) if pm is None else None)
+                       cert=self.mesh_cert(sign) if pm is None else None, drops_points=pm is not None)
         return valid
 
 
@@ -709,16 +709,20 @@ def _workspace(h, w, C):
 
 
 def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, valid_rule, point_precision=0,
-                   stream=None, cert=None):
+                   stream=None, cert=None, drops_points=False):
     """K3: scattered -> regular-grid linear interpolation.  Replaces utils.py:237-258 (and, with `query`,
     flow_class.py:1398-1410).  Raises ValueError("No points given") like qhull when nothing is kept.
     cert: a MeshCert of this very (flow, sign, point_precision) without point mask; when it certifies the mesh the
-    asynchronous one-kernel entry is taken (no workspace, no read-back)."""
+    asynchronous one-kernel entry is taken (no workspace, no read-back).  drops_points: pmask is KNOWN to hold zeros
+    (the flow's statistics say so); like a certificate that says "not certified" this spares the entry its own certificate
+    pass (OFL_SCATTER_UNCERTIFIED)."""
     ptr = lambda b: b.ptr if b is not None else None
     if cert is not None and cert.certified and pmask is None and query is None:
         nat.check(_lib().ofl_scatter_certified_dev(flow.ptr, sign, point_precision, ptr(vals), C, ptr(vmask), h, w, 0, h,
                                                    ptr(out), ptr(valid), valid_rule, ctypes.byref(cert), None, stream))
         return (h * w, 0, 0)
+    if (cert is not None and not cert.certified and pmask is None) or (drops_points and pmask is not None):
+        valid_rule |= nat.SCATTER_UNCERTIFIED          # the certificate pass has been run for this field: not again per call
     ws = _workspace(h, w, C)
     info = (ctypes.c_uint64 * 3)()
     nat.check(_lib().ofl_scatter_linear_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One operation in a loop for profiling: python tools/bench_invert.py [--op invert|switch|speckle|hole|stripes] [--iters N]"""
+"""One operation in a loop for profiling: python tools/bench_invert.py [--op invert|switch|speckle|hole|stripes|object|config5] [--iters N]"""
 import argparse
 import os
 import sys
@@ -33,6 +33,15 @@ def main():
         yy, xx = np.mgrid[:h, :w].astype(np.float32)
         v = np.zeros((h, w, 2), np.float32)
         v[..., 0] = (np.floor(xx / 64) % 2) * 20.0
+        d = dev.DeviceFlow.from_host(v, 's')
+    elif args.op == "config5":
+        flo = of.load_sintel(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sintel.flo"))
+        big = np.tile(flo, (h // flo.shape[0], w // flo.shape[1], 1))
+        h, w = big.shape[:2]
+        d = dev.DeviceFlow.from_host(big, 's')
+    elif args.op == "object":
+        v = np.zeros((h, w, 2), np.float32)
+        v[h // 4:h // 4 * 3, w // 4:w // 4 * 3] = [30.0, -12.0]
         d = dev.DeviceFlow.from_host(v, 's')
     else:
         raise SystemExit("unknown op")

@@ -179,6 +179,18 @@ __device__ __forceinline__ D2 warp_pt(int x, int y, float u, float v)
     return p;
 }
 
+// 1 / d for a positive, ordinary d (a triangle's doubled area) to a few ulp: hardware estimate + two Newton steps -- five
+// instructions where the IEEE division sequence takes about thirty-five (the kernel is bound by float64 instructions;
+// the coordinates feed float32 results and a `== 1` that holds for any c0 = 1 - c1 - c2)
+__device__ __forceinline__ double rcp_newton(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double r = fma(-d, x, 1.0);
+    x = fma(x, r, x);
+    r = fma(-d, x, 1.0);
+    return fma(x, r, x);
+}
+
 // Tests the two triangles of source cell (cx, cy) for the position (qx, qy) with SciPy's inclusion rule (division-free
 // edge functions; the certificate guarantees convex, positively oriented cells, so the Delaunay diagonal is one
 // in-circle sign).  On a miss the affine map of the less-missed triangle turns the position into a new estimate
@@ -222,7 +234,7 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
             else { t = 0; tri_corners(diag, 0, i0, i1, i2); }
         }
     }
-    const double inv = 1.0 / det;
+    const double inv = rcp_newton(det);
     const double c1 = w1 * inv, c2 = w2 * inv, c0 = 1.0 - c1 - c2;
     const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
     const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);

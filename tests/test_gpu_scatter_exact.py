@@ -254,6 +254,51 @@ def test_exact_path_bands_and_determinism(gpu, golden2):
             np.testing.assert_array_equal(np.concatenate(vparts), fullv, err_msg=tag)
 
 
+def test_both_paths_agree_at_full_size(gpu):
+    """A generic affine field at 1080p through BOTH paths: the certificate + walk kernel, and -- with
+    OFL_SCATTER_UNCERTIFIED, which makes the entry skip its certificate pass -- the Delaunay path (mesh fans for the
+    interior, the clip and cooperative passes for the border).  The triangulation is unique here (no co-circular
+    cells), so masks must be identical and values equal within the float32 tolerance; a hole and a 20-px tear are then
+    cut into the same field and the Delaunay path must reproduce the walk result wherever the cut cannot reach."""
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    nat = of.native
+    h, w = 1080, 1920
+    vecs = affine_field((h, w), -0.07, 0.11, -0.065, 0.04, 30.0, -12.0)
+    cert = certify(of, vecs)
+    assert cert.certified
+    rng = np.random.default_rng(5)
+    vals = rng.random((h, w, 2), dtype=np.float32)
+    vm = (rng.random((h, w)) > 0.05).astype(np.uint8)
+    fb, vb, mb = dev.DeviceBuffer.from_host(vecs), dev.DeviceBuffer.from_host(vals), dev.DeviceBuffer.from_host(vm)
+    out, valid = dev.DeviceBuffer(h * w * 8), dev.DeviceBuffer(h * w)
+    info = dev.scatter_linear(fb, +1, None, vb, 2, mb, h, w, None, out, valid, 0)
+    assert info[1] == 0                                                    # certified: nothing unfinished
+    walk, walkv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8)
+    info = dev.scatter_linear(fb, +1, None, vb, 2, mb, h, w, None, out, valid, nat.SCATTER_UNCERTIFIED)
+    assert info[0] == h * w and 0 < info[1] < 4 * (h + w)                  # the Delaunay path ran: border points unfinished
+    exact, exactv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8)
+    np.testing.assert_array_equal(exactv, walkv)
+    np.testing.assert_allclose(exact, walk, rtol=RTOL, atol=ATOL)
+    # dropped points: away from them the triangulation is the same
+    pm = np.ones((h, w), np.uint8)
+    pm[300:420, 500:800] = 0
+    pm[:, 1200:1202] = 0
+    info = dev.scatter_linear(fb, +1, dev.DeviceBuffer.from_host(pm), vb, 2, mb, h, w, None, out, valid, 0)
+    assert info[0] == int(pm.sum())
+    cut, cutv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8)
+    yy, xx = np.mgrid[:h, :w]
+    px, py = xx + vecs[..., 0], yy + vecs[..., 1]                           # where the sources land
+    far = np.ones((h, w), bool)
+    for ys, xs in ((slice(298, 423), slice(498, 803)), (slice(0, h), slice(1198, 1205))):
+        x0, x1, y0, y1 = px[ys, xs].min() - 3, px[ys, xs].max() + 3, py[ys, xs].min() - 3, py[ys, xs].max() + 3
+        far &= ~((xx >= x0) & (xx <= x1) & (yy >= y0) & (yy <= y1))
+    assert far.mean() > 0.8
+    np.testing.assert_array_equal(cutv[far], walkv[far])
+    np.testing.assert_allclose(cut[far], walk[far], rtol=RTOL, atol=ATOL)
+    assert (cutv[~far] == 1).mean() > 0.5                                  # the hole and the tear are triangulated across
+
+
 def test_exact_path_random_fields_against_scipy(gpu, oracle):
     """Seeded sweep on ragged shapes: smooth non-affine fields, folds, random point masks with holes, both signs, random
     image values -- the full result (values and validity of a random value mask) equals SciPy's outside non-unique

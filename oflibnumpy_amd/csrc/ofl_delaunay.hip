@@ -364,17 +364,17 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
     if (p >= (size_t)H * W) return;
     if (!kept_pt(pmask, p) || dup[p]) { deg[p] = 0; return; }
     const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
-    bool intact = x >= 1 && y >= 1 && x <= W - 2 && y <= H - 2;
-    if (intact && pmask) {
-        const uint8_t *m = pmask + p;
-        intact = m[-W - 1] && m[-W] && m[-W + 1] && m[-1] && m[1] && m[W - 1] && m[W] && m[W + 1];
-    }
-    if (intact) {
-        const unsigned char *m = dup + p;
-        intact = !(m[-W - 1] | m[-W] | m[-W + 1] | m[-1] | m[1] | m[W - 1] | m[W] | m[W + 1]);
+    // which of the eight grid neighbours exist: inside the grid, kept by the point mask, not a dropped duplicate
+    unsigned kept8 = 0;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        const int dx = (int)((0x901Au >> (2 * sl)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * sl)) & 3u) - 1;
+        const bool in = (unsigned)(x + dx) < (unsigned)W && (unsigned)(y + dy) < (unsigned)H;
+        const size_t q = in ? (size_t)((long long)p + dx + (long long)dy * W) : p;
+        if (in && kept_pt(pmask, q) && !dup[q]) kept8 |= 1u << sl;
     }
     int n = 0;
-    if (intact) {
+    {
         const Grid g = head->grid;
         const PosFn pos(flow, sign, W);
         auto npos = [&](int sl) {                               // slot -> grid offset at compile time (the loops over slots are unrolled)
@@ -383,7 +383,7 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
             return P2{ q.x, q.y };
         };
         const D2 c = point_of(flow, sign, W, x, y);
-        n = star_fan((int)p, W, P2{ c.x, c.y }, pos, npos, g, bstart, sorted, sorted_xy, kFanSpan, &s_rel[0][threadIdx.x], kFanBlock,
+        n = star_fan((int)p, W, P2{ c.x, c.y }, kept8, pos, npos, g, bstart, sorted, sorted_xy, kFanSpan, &s_rel[0][threadIdx.x], kFanBlock,
                      nbr + p * kSlots);
     }
     deg[p] = n > 0 ? (unsigned char)n : kDegTodo;

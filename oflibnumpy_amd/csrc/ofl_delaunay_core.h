@@ -317,40 +317,61 @@ DL_HD int slot_offset(int s, int W)
 constexpr double kFanEps  = 1e-13;       // relative margin of the float64 three-term in-circle sum (its rounding error is ~1e-15)
 constexpr float  kFanEpsF = 2e-5f;       // ... and of its float32 version (inputs rounded to float32: ~1e-6)
 
+// first set bit of an 8-bit ring read cyclically from position `from`: the next present slot at or after `from`
+DL_HD int ring_next(unsigned mask8, int from)
+{
+    const unsigned r = ((mask8 | (mask8 << 8)) >> from) & 0xFFu;      // bit i = slot (from + i) & 7
+    return (from + __builtin_ctz(r | 0x100u)) & 7;
+}
+
+// kept8: bit s = grid-neighbour slot s exists (inside the grid, kept by the point mask, not a dropped duplicate).  With
+// all eight the proposal is the cell-wise mesh as described above; with some missing, the kept neighbours in their
+// cyclic order (a diagonal neighbour of an incomplete cell is simply taken) -- a guess that the verification either
+// confirms or sends to the clip path, so speckled point masks still settle most of their stars here.
 template <class PosFn, class SlotPosFn>
-DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const Grid &g, const unsigned *bstart,
+DL_HD int star_fan(int p, int W, const P2 &pp, unsigned kept8, PosFn pos, SlotPosFn npos, const Grid &g, const unsigned *bstart,
                    const unsigned *sorted, const P2 *sorted_xy, int max_span,
                    P2 *nrel, int nstride,                     // scratch: relative positions of the eight slots
-                   unsigned *nbr_out)                         // the star, counter-clockwise (4 .. 8 sites)
+                   unsigned *nbr_out)                         // the star, counter-clockwise (3 .. 8 sites)
 {
     const int off[8] = { 1, W + 1, W, W - 1, -1, -W - 1, -W, -W + 1 };
     P2 Q[8];
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-    for (int s = 0; s < 8; ++s) Q[s] = npos(s);             // position of grid-neighbour slot s (= pos(p + off[s]))
+    for (int s = 0; s < 8; ++s) Q[s] = ((kept8 >> s) & 1u) ? npos(s) : pp;   // position of grid-neighbour slot s (= pos(p + off[s]))
     // diagonals: cell 0 (a = p, b = E, c = SE, d = S), cell 1 (a = W, b = p, c = S, d = SW),
     //            cell 2 (a = NW, b = N, c = p, d = W), cell 3 (a = N, b = NE, c = E, d = p)
     auto ac = [](const P2 &A, const P2 &B, const P2 &C, const P2 &D) {
         return incircle_origin(P2{ B.x - A.x, B.y - A.y }, P2{ D.x - A.x, D.y - A.y }, P2{ C.x - A.x, C.y - A.y }) >= 0.0;
     };
-    bool present[8];
-    present[0] = present[2] = present[4] = present[6] = true;
-    present[1] = ac(pp, Q[0], Q[1], Q[2]);
-    present[3] = !ac(Q[4], pp, Q[2], Q[3]);
-    present[5] = ac(Q[5], Q[6], pp, Q[4]);
-    present[7] = !ac(Q[6], Q[7], Q[0], pp);
+    bool whole[4];                                               // cell c has all its corners
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; ++c) whole[c] = ((kept8 >> (2 * c)) & (kept8 >> (2 * c + 1)) & (kept8 >> ((2 * c + 2) & 7)) & 1u) != 0;
+    unsigned pmask8 = kept8 & 0x55u;                             // present slots: the kept axis neighbours ...
+    if (((kept8 >> 1) & 1u) && (!whole[0] || ac(pp, Q[0], Q[1], Q[2]))) pmask8 |= 2u;         // ... and the diagonal ones a whole
+    if (((kept8 >> 3) & 1u) && (!whole[1] || !ac(Q[4], pp, Q[2], Q[3]))) pmask8 |= 8u;        //     cell's diagonal leads to
+    if (((kept8 >> 5) & 1u) && (!whole[2] || ac(Q[5], Q[6], pp, Q[4]))) pmask8 |= 32u;        //     (any kept one of a broken cell)
+    if (((kept8 >> 7) & 1u) && (!whole[3] || !ac(Q[6], Q[7], Q[0], pp))) pmask8 |= 128u;
+    int npresent = 0;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+    for (int s = 0; s < 8; ++s) npresent += (pmask8 >> s) & 1u;
+    if (npresent < 3) return 0;
     P2 N[8];
 #ifdef __HIPCC__
 #pragma unroll
 #endif
     for (int s = 0; s < 8; ++s) { N[s] = P2{ Q[s].x - pp.x, Q[s].y - pp.y }; nrel[s * nstride] = N[s]; }
-    // triangles: slot 2c = (N[2c], N[2c+1] or N[2c+2]), slot 2c + 1 = (N[2c+1], N[2c+2]) when the diagonal is present.
+    // triangle k (for a present slot k) = (N[k], N[next present slot]).
     // In-circle sum of a site C against triangle (0, A, B): |C|^2 o + C.x u + C.y w, negative inside; kept in float32
     // for the first look at every (site, triangle) pair.
     float o[8], u[8], w[8];
     float Mmax = 0.0f;
-    unsigned long long adj = 0ull;                               // byte s: the triangles that have slot s as a corner (its sites lie ON their circles)
+    unsigned long long adj = 0ull;                               // byte s: the triangles whose circle slot s is known to lie ON (or to be settled against)
     bool ok = true;
     int winds = 0;
     float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
@@ -358,25 +379,26 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const 
 #pragma unroll
 #endif
     for (int k = 0; k < 8; ++k) {
-        const int c2 = k & ~1, d = c2 + 1, e = (c2 + 2) & 7;
-        const bool diag = present[d];
-        const bool valid = (k & 1) ? diag : true;
-        const P2 A = (k & 1) ? N[d] : N[c2];
-        const P2 B = (k & 1) ? N[e] : (diag ? N[d] : N[e]);
+        const bool valid = (pmask8 >> k) & 1u;
+        const int nk = ring_next(pmask8, (k + 1) & 7);
+        const P2 A = N[k], B = nrel[nk * nstride];
         const double a2 = A.x * A.x + A.y * A.y, b2 = B.x * B.x + B.y * B.y;
         const double ok_ = A.x * B.y - A.y * B.x;
         const double uk = A.y * b2 - a2 * B.y, wk = a2 * B.x - A.x * b2;
         const double mo = fabs(A.x * B.y) + fabs(A.y * B.x), mu = fabs(A.y) * b2 + a2 * fabs(B.y), mw = a2 * fabs(B.x) + fabs(A.x) * b2;
         o[k] = valid ? (float)ok_ : 0.0f; u[k] = valid ? (float)uk : 0.0f; w[k] = valid ? (float)wk : 0.0f;
         if (valid) {
-            adj |= 1ull << (8 * ((k & 1) ? d : c2) + k);
-            adj |= (k & 1) ? (1ull << (8 * e + k)) : (diag ? (1ull << (8 * d + k)) : (1ull << (8 * e + k)));
-            // ... and the FOURTH corner of the triangle's own cell: which diagonal splits the cell has been decided above,
-            // once and identically for all four of its corners (for a similarity every cell is co-circular to rounding:
-            // re-deciding it from this site's point of view could only disagree with the other three)
-            adj |= (k & 1) ? (1ull << (8 * c2 + k)) : (diag ? (1ull << (8 * e + k)) : (1ull << (8 * d + k)));
+            adj |= (1ull << (8 * k + k)) | (1ull << (8 * nk + k));      // its own two sites
+            // ... and the FOURTH corner of a whole cell the triangle lies in: which diagonal splits that cell has been
+            // decided above, once and identically for all four of its corners (for a similarity every cell is co-circular
+            // to rounding: re-deciding it from this site's point of view could only disagree with the other three)
+            const int c = k >> 1;
+            if (whole[c]) {
+                if (!(k & 1)) adj |= 1ull << (8 * (nk == k + 1 ? ((k + 2) & 7) : k + 1) + k);
+                else          adj |= 1ull << (8 * (k - 1) + k);
+            }
             Mmax = fmaxf(Mmax, (float)fmax(mo, fmax(mu, mw)));
-            if (!(ok_ > 0.0)) ok = false;                        // counter-clockwise triangles only
+            if (!(ok_ > 0.0)) ok = false;                        // counter-clockwise triangles of less than a half turn only
             if (A.y < 0.0 && B.y >= 0.0) ++winds;
             // bounding box of the circumcircle, float32 with a safety margin (wide circles leave the fan path anyway)
             const float inv = 0.5f / (float)ok_;
@@ -393,11 +415,6 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const 
     const int cb0 = g.bx(pp.x + (double)bx0), cb1 = g.bx(pp.x + (double)bx1);
     const int rb0 = g.by(pp.y + (double)by0), rb1 = g.by(pp.y + (double)by1);
     if (cb1 - cb0 >= max_span || rb1 - rb0 >= max_span) return 0;
-    unsigned pmask8 = 0x55u;                                     // present slots as bits
-    if (present[1]) pmask8 |= 2u;
-    if (present[3]) pmask8 |= 8u;
-    if (present[5]) pmask8 |= 32u;
-    if (present[7]) pmask8 |= 128u;
     for (int row = rb0; row <= rb1; ++row) {
         const unsigned lo = bstart[(size_t)row * g.gx + cb0], hi = bstart[(size_t)row * g.gx + cb1 + 1];
         for (unsigned j = lo; j < hi; ++j) {
@@ -430,11 +447,8 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const 
 #pragma unroll 1
 #endif
             for (int k = 0; k < 8; ++k) {
-                if (!((need >> k) & 1u)) continue;
-                const int kc = k & ~1, d = kc + 1, e = (kc + 2) & 7;
-                const bool diag = (pmask8 >> d) & 1u;
-                if ((k & 1) && !diag) continue;                  // unused slot
-                const int sa = (k & 1) ? d : kc, sb = (k & 1) ? e : (diag ? d : e);
+                if (!((need >> k) & 1u) || !((pmask8 >> k) & 1u)) continue;
+                const int sa = k, sb = ring_next(pmask8, (k + 1) & 7);
                 const int pa = p + slot_offset(sa, W), pb = p + slot_offset(sb, W);
                 if (qi == pa || qi == pb) continue;              // the triangle's own sites lie ON its circle
                 const P2 A = nrel[sa * nstride], B = nrel[sb * nstride];
@@ -453,7 +467,7 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const 
 #ifdef __HIPCC__
 #pragma unroll 1
 #endif
-                        for (int s = 0; s < 8; ++s) { const P2 T = nrel[s * nstride]; member = member || (T.x == C.x && T.y == C.y); }
+                        for (int s = 0; s < 8; ++s) { const P2 T = nrel[s * nstride]; member = member || (((kept8 >> s) & 1u) && T.x == C.x && T.y == C.y); }
                     }
                     if (!member && (p < qi ? p : qi) < (pa < pb ? pa : pb)) return 0;
                 }
@@ -464,7 +478,7 @@ DL_HD int star_fan(int p, int W, const P2 &pp, PosFn pos, SlotPosFn npos, const 
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-    for (int s = 0; s < 8; ++s) if (present[s]) nbr_out[n++] = (unsigned)(p + off[s]);
+    for (int s = 0; s < 8; ++s) if ((pmask8 >> s) & 1u) nbr_out[n++] = (unsigned)(p + off[s]);
     return n;
 }
 

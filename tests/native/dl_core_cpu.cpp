@@ -97,13 +97,16 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
         if (!is_kept(p)) continue;
         if (W > 0) {
             const int x = p % W, y = p / W;
-            bool intact = x >= 1 && y >= 1 && x <= W - 2 && y <= H - 2;
-            for (int dy = -1; intact && dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) intact = intact && is_kept(p + dy * W + dx);
-            if (intact) {
+            unsigned kept8 = 0;
+            for (int sl = 0; sl < 8; ++sl) {
+                const int dx = (int)((0x901Au >> (2 * sl)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * sl)) & 3u) - 1;
+                if (x + dx >= 0 && x + dx < W && y + dy >= 0 && y + dy < H && is_kept(p + dy * W + dx)) kept8 |= 1u << sl;
+            }
+            {
                 P2 nrel[8];
                 unsigned nb8[8];
-                const int m = star_fan(p, W, pos(p), pos, [&](int sl) { return pos(p + slot_offset(sl, W)); }, g, bstart.data(), sorted.data(), (const P2 *)nullptr, 6, nrel, 1, nb8);
+                const int m = star_fan(p, W, pos(p), kept8, pos, [&](int sl) { return pos(p + slot_offset(sl, W)); }, g, bstart.data(),
+                                       sorted.data(), (const P2 *)nullptr, 6, nrel, 1, nb8);
                 if (m > 0) {
                     for (int k = 0; k < m; ++k) tag[k] = (int)nb8[k];
                     Poly Q{ vx.data(), vy.data(), tag.data(), 1, 64, m };

@@ -36,6 +36,7 @@ constexpr int      kOpenRings = 2;       // ... of which a cell still unbounded 
 constexpr int      kNearCap  = 12;       // polygon capacity of the per-thread pass (float32 cell in LDS)
 constexpr int      kSlots    = 16;       // neighbour slots per point
 constexpr int      kNear2Rings = 6;      // coarse rings of the second per-thread pass ...
+constexpr unsigned kNear2MinPoints = 32768;   // unfinished points below which the second per-thread pass is skipped
 constexpr int      kNear2Open = 3;       // ... which gives up a cell that is still unbounded after this many
 constexpr int      kMidCap   = 256;      // polygon capacity of the wave pass (unfinished points against the coarse grid of unfinished points)
 constexpr int      kMidRings = 8;        // rings of that coarse grid every unfinished point is given ...
@@ -1387,6 +1388,10 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                            (const DlHead *)ws.head, 1, (const unsigned *)ws.b1start, ws.sorted1);
         hipLaunchKernelGGL(dl_list_xy_kernel<1>, dim3(std::min<unsigned>(rblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
                            (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, ws.sorted1_xy, ws.sorted1_pt);
+        // (a per-thread pass needs tens of thousands of points to fill the chip; below that its few waves crawl through
+        // their serial clips and the wave-per-point pass is the faster one)
+        const char *n2 = getenv("OFL_DL_NEAR2_MIN");               // test knob: 0 runs the pass on the smallest field
+        if (h.n_far >= (n2 ? (unsigned)atoi(n2) : kNear2MinPoints))
         hipLaunchKernelGGL(dl_star_near2_kernel, dim3((h.n_far + 63) / 64), dim3(64), 0, s, flow, sign_pp, H, W, (const DlHead *)ws.head,
                            (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                            (const unsigned *)ws.b1start, (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, ws.deg, ws.nbr, ws.far_deg);

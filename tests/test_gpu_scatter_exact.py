@@ -37,6 +37,15 @@ def wobble(shape, ax=0.5, ay=0.4):
     return np.stack([ax * np.sin(xx / 9) * np.cos(yy / 7), ay * np.cos(xx / 8) * np.sin(yy / 6)], -1).astype(np.float32)
 
 
+@pytest.fixture(params=["default", "near2"])
+def near2_always(request, monkeypatch):
+    """The second per-thread star pass only runs for fields with tens of thousands of unfinished points; "near2" makes it
+    run on the small fixtures as well (OFL_DL_NEAR2_MIN=0), so both routes through the star passes are compared."""
+    if request.param == "near2":
+        monkeypatch.setenv("OFL_DL_NEAR2_MIN", "0")
+    return request.param
+
+
 def test_certificates(gpu):
     """What the certify pass reports for the field families of the reference's tests and of BASELINE.json."""
     of = gpu
@@ -200,7 +209,7 @@ EXACT_TAGS = ["affine_generic", "affine_generic_hole", "block_generic", "curved"
 
 
 @pytest.mark.parametrize("tag", EXACT_TAGS)
-def test_exact_path_matches_reference_outputs(gpu, golden2, tag):
+def test_exact_path_matches_reference_outputs(gpu, golden2, tag, near2_always):
     """Outputs of the REAL reference (tests/golden/make_golden.py::main_delaunay) for fields whose cell-wise mesh is
     not the Delaunay triangulation: folds (incl. BASELINE config 5 as loaded, 4 x 4 tiles), holes with random image
     values, curved borders, sheared cells, speckled point masks.  Masks bit-exact everywhere; values within 1e-4
@@ -223,7 +232,7 @@ def test_exact_path_matches_reference_outputs(gpu, golden2, tag):
         assert amb.mean() < 0.12, (tag, amb.mean())           # the comparison above is not vacuous
 
 
-def test_exact_path_bands_and_determinism(gpu, golden2):
+def test_exact_path_bands_and_determinism(gpu, golden2, near2_always):
     """Row bands of the exact path concatenate to the full result bit for bit, and repeated calls give the same bits
     (bucket order, far-point order and triangle ids are functions of the input only)."""
     of = gpu
@@ -299,7 +308,7 @@ def test_both_paths_agree_at_full_size(gpu):
     assert (cutv[~far] == 1).mean() > 0.5                                  # the hole and the tear are triangulated across
 
 
-def test_exact_path_random_fields_against_scipy(gpu, oracle):
+def test_exact_path_random_fields_against_scipy(gpu, oracle, near2_always):
     """Seeded sweep on ragged shapes: smooth non-affine fields, folds, random point masks with holes, both signs, random
     image values -- the full result (values and validity of a random value mask) equals SciPy's outside non-unique
     simplices."""

@@ -87,6 +87,7 @@ struct DlWs {
     unsigned *sorted1_pt;  // [N] point indices in `sorted1` order
     P2       *left_xy;     // [N] positions of the left-over points, in left_idx order
     unsigned *left_pt;     // [N] their point indices
+    double   *left_box;    // [N / 256 + 1][4] bounding boxes (x0, y0, x1, y1) of 256 consecutive left-over points
     int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
     unsigned *big;         // [big_cap] triangle ids with a large bounding box
     uint32_t *owner;       // [H][W] (biased by the first row of the band)
@@ -328,6 +329,32 @@ void dl_list_xy_kernel(const float *__restrict__ flow, int sign, int W, const Dl
     }
 }
 
+// bounding box of every 256 consecutive left-over points (one workgroup each): the sweeps of the workgroup pass skip the
+// chunks whose box cannot hold a cutting site
+__global__ __launch_bounds__(256)
+void dl_left_box_kernel(const DlHead *__restrict__ head, const P2 *__restrict__ left_xy, double *__restrict__ box)
+{
+    __shared__ double s_b[4][4];
+    const unsigned j = blockIdx.x * 256 + threadIdx.x, n = head->n_left;
+    double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+    if (j < n) { const P2 q = left_xy[j]; x0 = x1 = q.x; y0 = y1 = q.y; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fmin(x0, __hiloint2double(__shfl_xor(__double2hiint(x0), off), __shfl_xor(__double2loint(x0), off)));
+        y0 = fmin(y0, __hiloint2double(__shfl_xor(__double2hiint(y0), off), __shfl_xor(__double2loint(y0), off)));
+        x1 = fmax(x1, __hiloint2double(__shfl_xor(__double2hiint(x1), off), __shfl_xor(__double2loint(x1), off)));
+        y1 = fmax(y1, __hiloint2double(__shfl_xor(__double2hiint(y1), off), __shfl_xor(__double2loint(y1), off)));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_b[0][w] = x0; s_b[1][w] = y0; s_b[2][w] = x1; s_b[3][w] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { x0 = fmin(x0, s_b[0][k]); y0 = fmin(y0, s_b[1][k]); x1 = fmax(x1, s_b[2][k]); y1 = fmax(y1, s_b[3][k]); }
+        double *b = box + (size_t)blockIdx.x * 4;
+        b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1;
+    }
+}
+
 // Exact duplicates (folded integer-valued fields: BASELINE config 5 puts several sites on most lattice nodes): Qhull keeps
 // ONE vertex per location and which one is its own business, so only the smallest index of a location stays a site here.
 // The others are flagged, and their entries in the bucket list are blanked (index 0xFFFFFFFF: every consumer skips
@@ -522,6 +549,7 @@ struct FarLds {
     int    tag[CAP];
     unsigned char cut[CAP];
     int    cidx[NT];
+    unsigned clist[NT];        // chunk numbers the sweep of the workgroup pass keeps (of a group of NT chunks)
     double ccx[NT], ccy[NT];
     unsigned long long hit[NT / 64];
     double wmax[NT / 64], wfar[NT / 64];
@@ -922,8 +950,8 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
                         const unsigned *__restrict__ far_idx, const unsigned *__restrict__ left_idx,
-                        const unsigned *__restrict__ left_pt, const P2 *__restrict__ left_xy, const unsigned *__restrict__ nbr,
-                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
+                        const unsigned *__restrict__ left_pt, const P2 *__restrict__ left_xy, const double *__restrict__ left_box,
+                        const unsigned *__restrict__ nbr, unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
                         unsigned long long pool_cap)
 {
     __shared__ FarLds<CAP, 256> L;
@@ -948,17 +976,60 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     far_seeds(L, p, pp, nbr, pos, rel);
     far_near_rows(L, p, pp, g, bstart, sorted, sorted_xy, rel);
     far_coarse_annulus(L, p, pp, -1, kMidRings, g1, b1start, sorted1_pt, sorted1_xy, rel);
-    // every other left-over point, 4 x 256 per step
-    for (unsigned base = 0; base < n_left; base += 1024) {
-        int cand[4];
-        P2  q[4];
+    // Every other left-over point, 4 x 256 per step -- but only the chunks of 256 whose bounding box could hold a site
+    // that cuts the cell AS IT STANDS NOW (later the cell only shrinks: its reach falls, its far vertices stay inside the
+    // present cone and below the present largest distance, so what cannot cut now cannot cut later).  The test is
+    // far_test's, applied to a box: nearer than the reach of the near vertices, or not excluded by the far cone.
+    const unsigned n_chunks = (n_left + 255) / 256;
+    for (unsigned cbase = 0; cbase < n_chunks; cbase += 256) {
+        __syncthreads();
+        bool keep = false;
+        const unsigned ck = cbase + t;
+        if (ck < n_chunks) {
+            const double *b = left_box + (size_t)ck * 4;
+            const double x0 = b[0] - pp.x, y0 = b[1] - pp.y, x1 = b[2] - pp.x, y1 = b[3] - pp.y;
+            const double dx = fmax(fmax(x0, -x1), 0.0), dy = fmax(fmax(y0, -y1), 0.0), dmin2 = dx * dx + dy * dy;
+            if (dmin2 < L.reach2) keep = true;
+            else if (L.nfar != 0) {
+                keep = true;
+                if (L.cone) {
+                    double mmax = 0.0, amax = 0.0;
+                    bool right0 = true, left1 = true;            // every corner strictly outside one side of the cone?
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned j = base + 256 * k + t;
-            cand[k] = j < n_left ? (int)left_pt[j] : -1;
-            q[k] = j < n_left ? left_xy[j] : pp;
+                    for (int k = 0; k < 4; ++k) {
+                        const double cx = (k & 1) ? x1 : x0, cy = (k & 2) ? y1 : y0;
+                        mmax = fmax(mmax, fmax(L.c0x * cx + L.c0y * cy, L.c1x * cx + L.c1y * cy));
+                        amax = fmax(amax, fabs(cx) + fabs(cy));
+                        right0 = right0 && (L.c0x * cy - L.c0y * cx < 0.0);
+                        left1 = left1 && (cx * L.c1y - cy * L.c1x < 0.0);
+                    }
+                    if ((right0 || left1) && mmax + 1e-9 * amax < dmin2 * L.kcone) keep = false;
+                }
+            }
         }
-        far_chunks<4>(L, p, pp, cand, q, rel);
+        // ordered compaction of the kept chunk numbers of this group
+        const unsigned long long bal = __ballot(keep);
+        if ((t & 63) == 0) L.hit[t >> 6] = bal;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+        for (int w = 0; w < 4; ++w) { const unsigned c = (unsigned)__popcll(L.hit[w]); if (w < (t >> 6)) before += c; total += c; }
+        if (keep) L.clist[before + (unsigned)__popcll(bal & ((1ull << (t & 63)) - 1ull))] = ck;
+        __syncthreads();
+        for (unsigned k0 = 0; k0 < total; k0 += 4) {
+            int cand[4];
+            P2  q[4];
+            unsigned cks[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cks[k] = k0 + k < total ? L.clist[k0 + k] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned j = cks[k] * 256u + t;
+                const bool in = cks[k] != 0xFFFFFFFFu && j < n_left;
+                cand[k] = in ? (int)left_pt[j] : -1;
+                q[k] = in ? left_xy[j] : pp;
+            }
+            far_chunks<4>(L, p, pp, cand, q, rel);
+        }
     }
     __syncthreads();
     if (CAP < kFarCap && L.status) return;               // overflow of the small capacity: far_deg stays kDegLeft for the next pass
@@ -1267,6 +1338,7 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.sorted1_pt = (unsigned *)p;          p += align_up(n * 4, 256);
     ws.left_xy = (P2 *)p;                   p += align_up(n * 16, 256);
     ws.left_pt = (unsigned *)p;             p += align_up(n * 4, 256);
+    ws.left_box = (double *)p;              p += align_up((n / 256 + 1) * 32, 256);
     ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
     ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
@@ -1413,15 +1485,16 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         if (h.n_left) {
             hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(std::min<unsigned>((h.n_left + 255) / 256, 65535u)), dim3(256), 0, s, flow, sign_pp, W,
                                (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
+            hipLaunchKernelGGL(dl_left_box_kernel, dim3((h.n_left + 255) / 256), dim3(256), 0, s, (const DlHead *)ws.head, (const P2 *)ws.left_xy, ws.left_box);
             hipLaunchKernelGGL(dl_star_far_kernel<512>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
                                (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                                (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
-                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const unsigned *)ws.nbr,
+                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
                                ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
             hipLaunchKernelGGL(dl_star_far_kernel<kFarCap>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
                                (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                                (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
-                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const unsigned *)ws.nbr,
+                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
                                ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
             OFL_HIP(hipGetLastError());
         }

@@ -198,8 +198,8 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  * Source point i sits at (x, y) + sign*flow[i] -- evaluated in float64 (point_precision 0, utils.py:242)
  * or rounded to float32 first (point_precision 1, flow_class.py:1398-1400) -- and carries
  * vals[i][0..C) (float32) plus, optionally, a mask value vmask[i]; points with pmask[i] == 0 are
- * dropped (pmask NULL = keep all, utils.py:249-251).  The warped grid cells are split into triangles
- * along their Delaunay diagonal and scan-converted:
+ * dropped (pmask NULL = keep all, utils.py:249-251).  The result is linear on the Delaunay triangulation of the kept
+ * points (what griddata builds with Qhull):
  *     out[H][W][C]  piecewise-linear interpolation (float64 barycentric, stored as float32),
  *                   0 where no triangle covers the node;
  *     valid[H][W]   valid_rule 0: float32(interpolated vmask) == 1   (flow_class.py:668)
@@ -211,13 +211,16 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  *                   (vmask NULL = all ones, i.e. valid == "covered by a triangle").
  * query == NULL evaluates at the regular grid nodes; otherwise query [H][W][2] holds absolute (x, y)
  * positions (mode 2 't').  C may be 0 (validity only).  `workspace` (device) must hold
- * ofl_scatter_workspace_bytes() bytes.  info_host (host uint64[3] or NULL): [0] kept points; on the exact path
- * [1] points whose Delaunay star was not final within the per-thread ring search and [2] those left for the
- * workgroup pass (hull points, rims of very large holes); on the owner-map path (query positions) [1] number of
- * large triangles, [2] their bounding-box nodes.  OFL_E_NOPOINTS when no point is kept (qhull's "No points given").
+ * ofl_scatter_workspace_bytes() bytes.  info_host (host uint64[3] or NULL): [0] kept points (exact duplicates of a
+ * site included, although only the smallest index of a location is a site of the triangulation); on the Delaunay path
+ * [1] points whose star neither the mesh-fan pass nor the per-thread ring search could finish and [2] those of them left
+ * for the workgroup pass (hull points, fan apexes of border pockets); 0 / 0 on the certified path.
+ * OFL_E_NOPOINTS when no point is kept (qhull's "No points given").
  * Grid nodes take one of two paths: a field whose cell-wise mesh is certified to BE the Delaunay triangulation
  * (ofl_scatter_certify_dev) is resolved by one kernel; every other field -- folds, dropped points, curved borders,
  * sheared cells -- gets a real Delaunay triangulation of the kept points on the GPU.
+ * valid_rule | OFL_SCATTER_UNCERTIFIED skips the entry's own certificate pass (and its read-back) for callers that know
+ * the answer is "not certified"; the result is the same either way.
  */
 int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                            const float *vals, int C, const uint8_t *vmask, int H, int W,

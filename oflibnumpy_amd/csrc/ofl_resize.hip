@@ -127,7 +127,8 @@ __device__ __forceinline__ float2 pick6(int i, const float2 (&v)[6])
     return r;
 }
 
-__global__ __launch_bounds__(256)
+template <bool X2>      // X2: scale_x == 0.5 (the x2 up-scaling of pyramids): the tap columns of the four pixels sit at FIXED
+__global__ __launch_bounds__(256)      // places of the run -- (0,1) (1,2) (1,2) (2,3) -- away from the left and right borders
 void resize_flow4_kernel(const float2 *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W, int Ho, int Wo,
                          double scale_y, double scale_x, float mul_u, float mul_v,
                          float2 *__restrict__ out, uint8_t *__restrict__ mout)
@@ -164,9 +165,30 @@ void resize_flow4_kernel(const float2 *__restrict__ src, const uint8_t *__restri
             }
         }
     }
-    if (!act) return;
     float2 p[4];
     uint32_t mo = 0;
+    // x2: the picks by index (a third of this kernel's instructions, and it is instruction-bound) are spared wherever the
+    // whole wave has the regular pattern; the arithmetic per pixel is the same
+    bool regular = false;
+    if constexpr (X2)
+        regular = __all(!act || (cx[0].s0 == base && cx[0].s1 == base + 1 && cx[1].s0 == base + 1 && cx[1].s1 == base + 2 &&
+                                 cx[2].s0 == base + 1 && cx[2].s1 == base + 2 && cx[3].s0 == base + 2 && cx[3].s1 == base + 3));
+    if (!act) return;
+    if (X2 && regular) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            constexpr int kk[4] = { 0, 1, 1, 2 };
+            const int k0 = kk[j];
+            const float2 a = r0[k0], b = r0[k0 + 1], c = r1[k0], d = r1[k0 + 1];
+            p[j] = make_float2(resize_blend(a.x, b.x, c.x, d.x, cx[j], cy) * mul_u, resize_blend(a.y, b.y, c.y, d.y, cx[j], cy) * mul_v);
+            if (mask) {
+                const float q00 = (float)(((m0 >> (8 * k0)) & 0xffu) != 0), q01 = (float)(((m0 >> (8 * k0 + 8)) & 0xffu) != 0);
+                const float q10 = (float)(((m1 >> (8 * k0)) & 0xffu) != 0), q11 = (float)(((m1 >> (8 * k0 + 8)) & 0xffu) != 0);
+                const float v = resize_blend(q00, q01, q10, q11, cx[j], cy);
+                mo |= (v > 0.5f ? 1u : 0u) << (8 * j);
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k0 = cx[j].s0 - base, k1 = cx[j].s1 - base;
@@ -179,6 +201,7 @@ void resize_flow4_kernel(const float2 *__restrict__ src, const uint8_t *__restri
             const float v = resize_blend(q00, q01, q10, q11, cx[j], cy);
             mo |= (v > 0.5f ? 1u : 0u) << (8 * j);
         }
+    }
     }
     const size_t o = (size_t)dy * Wo + dx;
 #if OFL_RS_NT
@@ -210,9 +233,14 @@ int ofl_resize_flow_dev(const float *vecs, const uint8_t *mask, int H, int W, in
     if (gy > 65535u) return fail(OFL_E_INVALID, "ofl_resize_flow: output too tall");
     static const bool no4 = getenv("OFL_RS_NO4") != nullptr;         // development knob (A/B)
     if (!no4 && scale_x <= 1.0 && (Wo & 3) == 0 && W >= 6) {
-        hipLaunchKernelGGL(resize_flow4_kernel, dim3((unsigned)((Wo + 255) / 256), gy), dim3(64, 4), 0, stream_of(stream),
-                           reinterpret_cast<const float2 *>(vecs), mask, H, W, Ho, Wo, scale_y, scale_x, mul_u, mul_v,
-                           reinterpret_cast<float2 *>(out), mout);
+        if (scale_x == 0.5)
+            hipLaunchKernelGGL(resize_flow4_kernel<true>, dim3((unsigned)((Wo + 255) / 256), gy), dim3(64, 4), 0, stream_of(stream),
+                               reinterpret_cast<const float2 *>(vecs), mask, H, W, Ho, Wo, scale_y, scale_x, mul_u, mul_v,
+                               reinterpret_cast<float2 *>(out), mout);
+        else
+            hipLaunchKernelGGL(resize_flow4_kernel<false>, dim3((unsigned)((Wo + 255) / 256), gy), dim3(64, 4), 0, stream_of(stream),
+                               reinterpret_cast<const float2 *>(vecs), mask, H, W, Ho, Wo, scale_y, scale_x, mul_u, mul_v,
+                               reinterpret_cast<float2 *>(out), mout);
         OFL_HIP(hipGetLastError());
         return OFL_OK;
     }

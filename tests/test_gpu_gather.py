@@ -592,7 +592,7 @@ def test_resize_matches_oracle(gpu, oracle):
     sizes, speckled masks; plus the reference's own mask known answer (tests/test_flow_class.py:380-389)."""
     of, O = gpu, oracle
     rng = np.random.default_rng(21)
-    for shape in ((20, 10), (37, 53), (64, 129), (1, 7), (9, 1)):
+    for shape in ((20, 10), (37, 53), (64, 129), (1, 7), (9, 1), (33, 300), (12, 128)):
         vecs = (rng.standard_normal(shape + (2,)) * 5).astype(np.float32)
         mask = rng.random(shape) > 0.3
         f = of.Flow(vecs, 's', mask)

@@ -308,6 +308,36 @@ def test_both_paths_agree_at_full_size(gpu):
     assert (cutv[~far] == 1).mean() > 0.5                                  # the hole and the tear are triangulated across
 
 
+def test_exact_path_medium_field_against_scipy(gpu, oracle, near2_always):
+    """One field large enough (240 x 320) for every star pass to see real work -- a smooth non-affine warp with a 15-px
+    tear along a slanted line (folds on one side, a gap on the other), a 40 x 60 hole and 3 % speckle in the point mask,
+    random image values and a speckled value mask: the whole result equals SciPy's outside non-unique simplices."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev
+    rng = np.random.default_rng(99)
+    h, w = 240, 320
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    vecs = np.stack([2.5 * np.sin(xx / 23 + yy / 31) + 0.11 * yy + 0.04 * xx,
+                     2.0 * np.cos(xx / 19) * np.sin(yy / 27) - 0.06 * xx + 0.03 * yy], -1).astype(np.float32)
+    vecs[(xx + 0.4 * yy) > 210] += np.float32([15.0, -6.0])                 # the tear
+    pm = rng.random((h, w)) > 0.03
+    pm[90:130, 60:120] = False
+    vals = rng.random((h, w, 2), dtype=np.float32)
+    vm = rng.random((h, w)) > 0.1
+    f, dv, dm, dpm = (dev.DeviceBuffer.from_host(a) for a in (vecs, vals, vm.astype(np.uint8), pm.astype(np.uint8)))
+    out, valid = dev.DeviceBuffer(h * w * 8), dev.DeviceBuffer(h * w)
+    info = dev.scatter_linear(f, +1, dpm, dv, 2, dm, h, w, None, out, valid, 0)
+    assert info[0] == int(pm.sum()) and info[1] > 500                       # rims of the tear and the hole, the border
+    got, gv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+    want = O.scatter_griddata(vecs, np.concatenate([vals, vm[..., None].astype(np.float32)], -1), pm)
+    pts = np.stack([(xx + vecs[..., 0].astype(np.float64)).ravel(), (yy + vecs[..., 1].astype(np.float64)).ravel()], 1)[pm.ravel()]
+    amb, inside = nonunique_nodes(pts, (h, w))
+    assert amb.mean() < 0.02
+    np.testing.assert_array_equal(gv[~amb], (want[..., -1] == 1)[~amb])
+    bad = ~np.isclose(got, want[..., :2], rtol=RTOL, atol=ATOL).all(-1)
+    assert not (bad & ~amb).any(), (int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:4].tolist())
+
+
 def test_exact_path_random_fields_against_scipy(gpu, oracle, near2_always):
     """Seeded sweep on ragged shapes: smooth non-affine fields, folds, random point masks with holes, both signs, random
     image values -- the full result (values and validity of a random value mask) equals SciPy's outside non-unique

@@ -5,12 +5,17 @@
 // folded meshes (motion boundaries, the tiled Sintel field of BASELINE config 5 as loaded), dropped points (holes and
 // speckle of the point mask), curved mesh borders (pockets between the mesh and its convex hull), sheared cells.
 //
-//   bin      the kept points are counting-sorted into a bucket grid over their bounding box (~1 point per bucket)
-//   stars    one thread per point builds its Voronoi cell / Delaunay star from the buckets around it
-//            (ofl_delaunay_core.h: half-plane clipping, in-circle decisions, security radius); cells that are not
-//            final within kRings bucket rings -- hull points, rims of large holes, fan apexes of border pockets --
-//            are finished by one WORKGROUP per point against the near buckets plus all other unfinished points
-//            (every Delaunay neighbour of an unfinished point beyond the ring search is itself unfinished)
+//   bin      the kept points are counting-sorted into a bucket grid over their bounding box (~1 point per bucket); exact
+//            duplicates of a site are dropped (the smallest index of a location stays)
+//   stars    four passes, cheapest first (ofl_delaunay_core.h holds the geometry, shared with the CPU test build):
+//            mesh fans   one thread per point VERIFIES the star the warped grid proposes (empty circumcircles against the
+//                        sites of the buckets under them) -- the interior of every smooth piece of the field;
+//            clip        one thread per remaining point builds its Voronoi cell by half-plane clipping in growing bucket
+//                        rings (in-circle decisions, security radius);
+//            rims        cells that are not final within the rings -- rims of tears and holes -- against a coarse grid of
+//                        the unfinished points only: per thread when there are tens of thousands, one wave per point else;
+//            hull        what is still left (unbounded cells) by one workgroup per point against all other left-over
+//                        points (every Delaunay neighbour of an unfinished point beyond the ring search is itself unfinished)
 //   raster   every star's triangles (p, n_k, n_k+1) are scan-converted with SciPy's inclusion rule; atomicMin keeps
 //            the smallest triangle id per node -- each triangle is emitted by all three of its sites, so stars that
 //            disagree on an exactly co-circular cell (where Qhull itself is arbitrary) still tile the hull

@@ -215,7 +215,9 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  * site included, although only the smallest index of a location is a site of the triangulation); on the Delaunay path
  * [1] points whose star neither the mesh-fan pass nor the per-thread ring search could finish and [2] those of them left
  * for the workgroup pass (hull points, fan apexes of border pockets); 0 / 0 on the certified path.
- * OFL_E_NOPOINTS when no point is kept (qhull's "No points given").
+ * OFL_E_NOPOINTS when no point is kept (qhull's "No points given") -- on the Delaunay path this and the capacity errors are
+ * known only after the fact and reported to callers that pass info_host (one read-back at the end of the call); with
+ * info_host == NULL that path only enqueues work and a field without kept points gives an all-invalid result.
  * Grid nodes take one of two paths: a field whose cell-wise mesh is certified to BE the Delaunay triangulation
  * (ofl_scatter_certify_dev) is resolved by one kernel; every other field -- folds, dropped points, curved borders,
  * sheared cells -- gets a real Delaunay triangulation of the kept points on the GPU.

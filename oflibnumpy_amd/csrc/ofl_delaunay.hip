@@ -62,7 +62,7 @@ constexpr int      kScanChunk = 2048;    // elements per block of the scan kerne
 struct DlHead {                           // device header of the exact path (256 bytes)
     unsigned long long kx0, kx1, ky0, ky1;   // ordered keys of the bounding box while it is reduced
     Grid     grid, grid1;                    // fine buckets (all kept points), coarse buckets (unfinished points)
-    unsigned kept, n_far, n_left, pool_used, err;    // err bit 0: far polygon overflow, bit 1: pool overflow, bit 2: big list overflow
+    unsigned kept, n_far, n_left, pool_used, err;    // err bit 0: far polygon overflow, bit 1: pool overflow, bit 2: big list overflow, bit 3: triangle-id space
     unsigned long long big_n;
     unsigned n_todo;                                 // points the mesh-fan pass left to the clip pass
     unsigned pad0;
@@ -230,11 +230,11 @@ __global__ __launch_bounds__(256)
 void dl_count1_kernel(const float *__restrict__ flow, int sign, int W, const DlHead *__restrict__ head,
                       const unsigned *__restrict__ far_idx, unsigned *__restrict__ bcount)
 {
-    const unsigned r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= head->n_far) return;
     const Grid g = head->grid1;
-    const P2 p = PosFn(flow, sign, W)((int)far_idx[r]);
-    atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
+    for (unsigned r = blockIdx.x * 256 + threadIdx.x; r < head->n_far; r += gridDim.x * 256) {      // (sized on the device: no read-back of the count)
+        const P2 p = PosFn(flow, sign, W)((int)far_idx[r]);
+        atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -242,12 +242,12 @@ void dl_fill1_kernel(const float *__restrict__ flow, int sign, int W, const DlHe
                      const unsigned *__restrict__ far_idx, const unsigned *__restrict__ bstart,
                      unsigned *__restrict__ cursor, unsigned *__restrict__ sorted)
 {
-    const unsigned r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= head->n_far) return;
     const Grid g = head->grid1;
-    const P2 p = PosFn(flow, sign, W)((int)far_idx[r]);
-    const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
-    sorted[bstart[b] + atomicAdd(&cursor[b], 1u)] = r;
+    for (unsigned r = blockIdx.x * 256 + threadIdx.x; r < head->n_far; r += gridDim.x * 256) {
+        const P2 p = PosFn(flow, sign, W)((int)far_idx[r]);
+        const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
+        sorted[bstart[b] + atomicAdd(&cursor[b], 1u)] = r;
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -340,7 +340,10 @@ __global__ __launch_bounds__(256)
 void dl_left_box_kernel(const DlHead *__restrict__ head, const P2 *__restrict__ left_xy, double *__restrict__ box)
 {
     __shared__ double s_b[4][4];
-    const unsigned j = blockIdx.x * 256 + threadIdx.x, n = head->n_left;
+    const unsigned n = head->n_left;
+    for (unsigned chunk = blockIdx.x; chunk * 256u < n; chunk += gridDim.x) {
+    __syncthreads();
+    const unsigned j = chunk * 256 + threadIdx.x;
     double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
     if (j < n) { const P2 q = left_xy[j]; x0 = x1 = q.x; y0 = y1 = q.y; }
 #pragma unroll
@@ -355,8 +358,9 @@ void dl_left_box_kernel(const DlHead *__restrict__ head, const P2 *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; ++k) { x0 = fmin(x0, s_b[0][k]); y0 = fmin(y0, s_b[1][k]); x1 = fmax(x1, s_b[2][k]); y1 = fmax(y1, s_b[3][k]); }
-        double *b = box + (size_t)blockIdx.x * 4;
+        double *b = box + (size_t)chunk * 4;
         b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1;
+    }
     }
 }
 
@@ -470,15 +474,16 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
                           const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                           const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt,
                           const P2 *__restrict__ sorted1_xy, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr,
-                          unsigned *__restrict__ far_deg)
+                          unsigned *__restrict__ far_deg, unsigned min_points)
 {
     __shared__ float s_vx[kSlots][64], s_vy[kSlots][64];
     __shared__ int   s_tag[kSlots][64];
-    const unsigned rank = blockIdx.x * 64 + threadIdx.x;
-    if (rank >= head->n_far) return;
+    const unsigned n_far = head->n_far;
+    if (n_far < min_points) return;                        // (a per-thread pass needs tens of thousands of points to fill the chip)
+    for (unsigned rank = blockIdx.x * 64 + threadIdx.x; rank < n_far; rank += gridDim.x * 64) {
     const int p = (int)far_idx[rank];
     const int py = (int)((unsigned)p / (unsigned)W), px = p - py * W;
-    if (px == 0 || py == 0 || px == W - 1 || py == H - 1) return;
+    if (px == 0 || py == 0 || px == W - 1 || py == H - 1) continue;
     const Grid g = head->grid, g1 = head->grid1;
     const PosFn pos(flow, sign, W);
     unsigned *row = nbr + (size_t)p * kSlots;
@@ -486,10 +491,11 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
     PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kSlots, 0 };
     const int rc = star_near2(P, p, pos(p), row + 2, ns, (int)row[14], kRings, g, bstart, sorted, sorted_xy,
                               kNear2Rings, g1, b1start, sorted1_pt, sorted1_xy, pos, kNear2Open);
-    if (rc != 1) return;
+    if (rc != 1) continue;
     for (int k = 0; k < P.n; ++k) row[k] = (unsigned)P.T(k);
     deg[p] = (unsigned char)P.n;
     far_deg[rank] = 0;                                     // not a cooperative-pass star: nothing in the pool
+    }
 }
 
 // compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx,
@@ -534,7 +540,11 @@ void dl_flag_write_kernel(const void *__restrict__ src, DlHead *head, size_t n_f
             list[at++] = (unsigned)(base + k);
         }
     if (blockIdx.x == last_block && threadIdx.x == 0) {
-        const unsigned cnt = offs[blockIdx.x] + total;
+        unsigned cnt = offs[blockIdx.x] + total;
+        if (MODE == 0 && (unsigned long long)n_fixed * kSlots + (unsigned long long)cnt * kFarK >= 0xFFFFFFF0ull) {
+            atomicOr(&head->err, 8u);                      // the unfinished stars exceed the triangle-id space: none is built, the caller is told
+            cnt = 0;
+        }
         if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else head->n_todo = cnt;
     }
 }
@@ -890,18 +900,14 @@ __device__ void far_store(FarLds<CAP, NT> &L, unsigned rank, DlHead *head, unsig
     if (t == 0) { far_deg[rank] = (unsigned)n; far_off[rank] = off; }
 }
 
-__global__ __launch_bounds__(64)
-void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
+__device__ void mid_point(FarLds<kMidCap, 64> &L, unsigned &s_off, unsigned rank,
+                          const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
                         const unsigned *__restrict__ far_idx, const unsigned char *__restrict__ deg, const unsigned *__restrict__ nbr,
                         unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
 {
-    __shared__ FarLds<kMidCap, 64> L;
-    __shared__ unsigned s_off;
     const int t = threadIdx.x;
-    const unsigned rank = blockIdx.x;
-    if (rank >= head->n_far) return;
     const int p = (int)far_idx[rank];
     if (deg[p] != kDegFar) return;                         // finished by the second per-thread pass
     const Grid g = head->grid, g1 = head->grid1;
@@ -949,9 +955,27 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
 }
 
-template <int CAP>          // first with a small cell capacity (several workgroups per CU), then -- for the few fans that overflowed it -- the large one
-__global__ __launch_bounds__(256)
-void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
+// one wave per unfinished point; the grid is fixed and walks the ranks (their number stays on the device)
+__global__ __launch_bounds__(64)
+void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
+                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
+                        const unsigned *__restrict__ far_idx, const unsigned char *__restrict__ deg, const unsigned *__restrict__ nbr,
+                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
+{
+    __shared__ FarLds<kMidCap, 64> L;
+    __shared__ unsigned s_off;
+    const unsigned n_far = head->n_far;
+    for (unsigned rank = blockIdx.x; rank < n_far; rank += gridDim.x) {
+        __syncthreads();                                   // the previous point's cell has been stored by every thread
+        mid_point(L, s_off, rank, flow, sign, H, W, head, bstart, sorted, sorted_xy, b1start, sorted1_pt, sorted1_xy, far_idx, deg, nbr,
+                  far_deg, far_off, pool, pool_cap);
+    }
+}
+
+template <int CAP>
+__device__ void far_point(FarLds<CAP, 256> &L, unsigned &s_off, unsigned li, unsigned n_left,
+                          const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
                         const unsigned *__restrict__ far_idx, const unsigned *__restrict__ left_idx,
@@ -959,12 +983,8 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
                         const unsigned *__restrict__ nbr, unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
                         unsigned long long pool_cap)
 {
-    __shared__ FarLds<CAP, 256> L;
-    __shared__ unsigned s_off;
     const int t = threadIdx.x;
-    const unsigned n_left = head->n_left;
-    if (blockIdx.x >= n_left) return;
-    const unsigned rank = left_idx[blockIdx.x];
+    const unsigned rank = left_idx[li];
     if (far_deg[rank] != kDegLeft) return;               // finished by the pass with the smaller capacity
     const int p = (int)far_idx[rank];
     const Grid g = head->grid, g1 = head->grid1;
@@ -1039,6 +1059,26 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     __syncthreads();
     if (CAP < kFarCap && L.status) return;               // overflow of the small capacity: far_deg stays kDegLeft for the next pass
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
+}
+
+template <int CAP>          // first with a small cell capacity (several workgroups per CU), then -- for the few fans that overflowed it -- the large one
+__global__ __launch_bounds__(256)
+void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
+                        const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
+                        const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
+                        const unsigned *__restrict__ far_idx, const unsigned *__restrict__ left_idx,
+                        const unsigned *__restrict__ left_pt, const P2 *__restrict__ left_xy, const double *__restrict__ left_box,
+                        const unsigned *__restrict__ nbr, unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
+                        unsigned long long pool_cap)
+{
+    __shared__ FarLds<CAP, 256> L;
+    __shared__ unsigned s_off;
+    const unsigned n_left = head->n_left;
+    for (unsigned li = blockIdx.x; li < n_left; li += gridDim.x) {
+        __syncthreads();
+        far_point<CAP>(L, s_off, li, n_left, flow, sign, H, W, head, bstart, sorted, sorted_xy, b1start, sorted1_pt, sorted1_xy, far_idx,
+                       left_idx, left_pt, left_xy, left_box, nbr, far_deg, far_off, pool, pool_cap);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ raster
@@ -1139,13 +1179,14 @@ void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int
 __global__ __launch_bounds__(256)
 void dl_raster_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
 {
-    const unsigned rank = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rank >= ws.head->n_far) return;
-    const unsigned d = ws.far_deg[rank];
-    if (d == kDegLeft) return;
     const PosFn pos(flow, sign, W);
-    const unsigned self = ws.far_idx[rank];
-    for (unsigned k = threadIdx.x & 63; k < d; k += 64) thread_raster(far_base + rank * kFarK + k, self, pos, H, W, ws, far_base);
+    const unsigned n_far = ws.head->n_far;
+    for (unsigned rank = blockIdx.x * 4 + (threadIdx.x >> 6); rank < n_far; rank += gridDim.x * 4) {
+        const unsigned d = ws.far_deg[rank];
+        if (d == kDegLeft) continue;
+        const unsigned self = ws.far_idx[rank];
+        for (unsigned k = threadIdx.x & 63; k < d; k += 64) thread_raster(far_base + rank * kFarK + k, self, pos, H, W, ws, far_base);
+    }
 }
 
 // one wave per large triangle: 64 nodes of the bounding box per step
@@ -1388,7 +1429,7 @@ size_t exact_workspace_bytes(int H, int W)
 
 namespace {
 
-// Bins, stars and the owner map of rows [row0, row0 + rows); synchronises twice (counts of the star passes).
+// Bins, stars and the owner map of rows [row0, row0 + rows).  Asynchronous unless the caller asks for the counts.
 int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows,
                   void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s, DlWs &ws, unsigned &far_base_out)
 {
@@ -1441,19 +1482,14 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     hipLaunchKernelGGL(dl_flag_write_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, ws.head, n, (const unsigned *)fcnt,
                        ws.far_idx, fblk - 1, ws.nbr);
     OFL_HIP(hipGetLastError());
-    DlHead h;
-    OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
-    OFL_HIP(hipStreamSynchronize(s));
-    if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = 0; }
-    static const bool debug = getenv("OFL_DL_DEBUG") != nullptr;                 // development aid
-    if (debug) fprintf(stderr, "[ofl exact] kept %u, clip pass %u, unfinished %u\n", h.kept, h.n_todo, h.n_far);
-    if (h.kept == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
+    // From here on every launch is sized on the device: fixed grids walk the unfinished points, whose numbers stay in the
+    // header.  Nothing is read back unless the caller asks for the counts (info_host) -- then ONE read-back at the end,
+    // which also carries the errors that cannot be known earlier (no point kept, a capacity exceeded).
     const unsigned long long far_base = (unsigned long long)n * kSlots;
-    if (far_base + (unsigned long long)h.n_far * kFarK >= 0xFFFFFFF0ull)
-        return fail(OFL_E_INVALID, "ofl_scatter_linear: %u unfinished stars exceed the triangle-id space of the exact path", h.n_far);
-    if (h.n_far) {
-        // coarse grid of the unfinished points, wave pass, then the workgroup pass for what is still left
-        const unsigned rblk = (h.n_far + 255) / 256;
+    const unsigned walk = (unsigned)std::min<size_t>(n, 16384);          // workgroups that walk ranks
+    {
+        // coarse grid of the unfinished points, per-thread / wave pass, then the workgroup pass for what is still left
+        const unsigned rblk = std::min<unsigned>(nblk, 2048u);
         OFL_HIP(hipMemsetAsync(ws.b1start, 0, (ws.b1cap + 1) * 4, s));
         OFL_HIP(hipMemsetAsync(ws.b1cursor, 0, ws.b1cap * 4, s));
         hipLaunchKernelGGL(dl_count1_kernel, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
@@ -1463,60 +1499,55 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                            (const unsigned *)ws.far_idx, (const unsigned *)ws.b1start, ws.b1cursor, ws.sorted1);
         hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.b1cap + 255) / 256), 65535u)), dim3(256), 0, s,
                            (const DlHead *)ws.head, 1, (const unsigned *)ws.b1start, ws.sorted1);
-        hipLaunchKernelGGL(dl_list_xy_kernel<1>, dim3(std::min<unsigned>(rblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
+        hipLaunchKernelGGL(dl_list_xy_kernel<1>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
                            (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, ws.sorted1_xy, ws.sorted1_pt);
-        // (a per-thread pass needs tens of thousands of points to fill the chip; below that its few waves crawl through
-        // their serial clips and the wave-per-point pass is the faster one)
-        const char *n2 = getenv("OFL_DL_NEAR2_MIN");               // test knob: 0 runs the pass on the smallest field
-        if (h.n_far >= (n2 ? (unsigned)atoi(n2) : kNear2MinPoints))
-        hipLaunchKernelGGL(dl_star_near2_kernel, dim3((h.n_far + 63) / 64), dim3(64), 0, s, flow, sign_pp, H, W, (const DlHead *)ws.head,
-                           (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
-                           (const unsigned *)ws.b1start, (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, ws.deg, ws.nbr, ws.far_deg);
-        hipLaunchKernelGGL(dl_star_mid_kernel, dim3(h.n_far), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
+        const char *n2 = getenv("OFL_DL_NEAR2_MIN");               // test knob: 0 runs the per-thread pass on the smallest field
+        hipLaunchKernelGGL(dl_star_near2_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 8192u)), dim3(64), 0, s, flow, sign_pp, H, W,
+                           (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
+                           (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start, (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy,
+                           ws.deg, ws.nbr, ws.far_deg, n2 ? (unsigned)atoi(n2) : kNear2MinPoints);
+        hipLaunchKernelGGL(dl_star_mid_kernel, dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned char *)ws.deg, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
                            (unsigned long long)ws.pool_cap);
         OFL_HIP(hipGetLastError());
-        const unsigned lblk = (h.n_far + kScanChunk - 1) / kScanChunk;
         unsigned *lcnt = (unsigned *)ws.big;                             // the large-triangle list is empty until the raster passes
-        hipLaunchKernelGGL(dl_flag_count_kernel<1>, dim3(lblk), dim3(256), 0, s, (const void *)ws.far_deg, (const DlHead *)ws.head, (size_t)0, lcnt);
-        OFL_TRY(scan_exclusive(lcnt, lblk, ws.scan_tmp, s));
-        hipLaunchKernelGGL(dl_flag_write_kernel<1>, dim3(lblk), dim3(256), 0, s, (const void *)ws.far_deg, ws.head, (size_t)0,
-                           (const unsigned *)lcnt, ws.left_idx, lblk - 1, (unsigned *)nullptr);
+        hipLaunchKernelGGL(dl_flag_count_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, (const DlHead *)ws.head, (size_t)0, lcnt);
+        OFL_TRY(scan_exclusive(lcnt, fblk, ws.scan_tmp, s));
+        hipLaunchKernelGGL(dl_flag_write_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, ws.head, (size_t)0,
+                           (const unsigned *)lcnt, ws.left_idx, fblk - 1, (unsigned *)nullptr);
+        hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W,
+                           (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
+        hipLaunchKernelGGL(dl_left_box_kernel, dim3(rblk), dim3(256), 0, s, (const DlHead *)ws.head, (const P2 *)ws.left_xy, ws.left_box);
+        hipLaunchKernelGGL(dl_star_far_kernel<512>, dim3(walk), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+                           (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
+                           (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                           (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
+                           ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
+        hipLaunchKernelGGL(dl_star_far_kernel<kFarCap>, dim3(std::min<unsigned>(walk, 2048u)), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+                           (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
+                           (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
+                           (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
+                           ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
         OFL_HIP(hipGetLastError());
-        OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
-        OFL_HIP(hipStreamSynchronize(s));
-        if (info_host) info_host[2] = h.n_left;
-        if (h.n_left) {
-            hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(std::min<unsigned>((h.n_left + 255) / 256, 65535u)), dim3(256), 0, s, flow, sign_pp, W,
-                               (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
-            hipLaunchKernelGGL(dl_left_box_kernel, dim3((h.n_left + 255) / 256), dim3(256), 0, s, (const DlHead *)ws.head, (const P2 *)ws.left_xy, ws.left_box);
-            hipLaunchKernelGGL(dl_star_far_kernel<512>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
-                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
-                               (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
-                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
-                               ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
-            hipLaunchKernelGGL(dl_star_far_kernel<kFarCap>, dim3(h.n_left), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
-                               (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
-                               (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
-                               (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
-                               ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
-            OFL_HIP(hipGetLastError());
-        }
     }
     hipLaunchKernelGGL(dl_raster_small_kernel, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
-    if (h.n_far)
-        hipLaunchKernelGGL(dl_raster_far_kernel, dim3((h.n_far + 3) / 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+    hipLaunchKernelGGL(dl_raster_far_kernel, dim3(std::min<unsigned>(walk, 4096u)), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     far_base_out = (unsigned)far_base;
     OFL_HIP(hipGetLastError());
-    if (info_host) {
-        // callers that ask for the counts also learn whether a capacity of the star passes was exceeded (a fan of more
-        // than kFarCap neighbours, the neighbour pool, the large-triangle list): one more small read-back
+    static const bool debug = getenv("OFL_DL_DEBUG") != nullptr;                 // development aid
+    if (info_host || debug) {
+        DlHead h;
         OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
         OFL_HIP(hipStreamSynchronize(s));
+        if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = h.n_left; }
+        if (debug) fprintf(stderr, "[ofl exact] kept %u, clip pass %u, unfinished %u, left over %u\n", h.kept, h.n_todo, h.n_far, h.n_left);
+        if (!info_host) return OFL_OK;
+        if (h.kept == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
         if (h.err) return fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
-                                              "neighbours, 2 = neighbour pool, 4 = large-triangle list)", h.err, kFarCap);
+                                              "neighbours, 2 = neighbour pool, 4 = large-triangle list, 8 = unfinished stars beyond the "
+                                              "triangle-id space)", h.err, kFarCap);
     }
     return OFL_OK;
 }

@@ -308,6 +308,37 @@ def test_both_paths_agree_at_full_size(gpu):
     assert (cutv[~far] == 1).mean() > 0.5                                  # the hole and the tear are triangulated across
 
 
+def test_delaunay_path_without_counts(gpu, golden2):
+    """info_host == NULL: the Delaunay path sizes every launch on the device and reads nothing back (the entry only
+    enqueues); the result is bit-identical to the call that asks for the counts.  What can only be known after the
+    fact -- no point kept at all -- is reported to callers that ask, and is an all-invalid result for those that do not."""
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    nat, lib = of.native, of.native.load()
+    vecs, mask, img, _ = fixture_case(golden2, "block_generic")
+    h, w = vecs.shape[:2]
+    f, vals = dev.DeviceBuffer.from_host(vecs), dev.DeviceBuffer.from_host(img)
+    ws = dev._workspace(h, w, 3)
+    outs = []
+    for with_info in (True, False):
+        out, valid = dev.DeviceBuffer(h * w * 12), dev.DeviceBuffer(h * w)
+        info = (ctypes.c_uint64 * 3)()
+        nat.check(lib.ofl_scatter_linear_dev(f.ptr, 1, 0, None, vals.ptr, 3, None, h, w, None, out.ptr, valid.ptr, 0, ws.ptr, ws.nbytes,
+                                             info if with_info else None, None))
+        outs.append((out.to_host((h, w, 3), np.float32), valid.to_host((h, w), np.uint8)))
+        assert (info[0] == h * w and info[1] > 0) if with_info else info[0] == 0
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    none = dev.DeviceBuffer.from_host(np.zeros((h, w), np.uint8))
+    out, valid = dev.DeviceBuffer(h * w * 12), dev.DeviceBuffer(h * w)
+    info = (ctypes.c_uint64 * 3)()
+    assert lib.ofl_scatter_linear_dev(f.ptr, 1, 0, none.ptr, vals.ptr, 3, None, h, w, None, out.ptr, valid.ptr, 0, ws.ptr, ws.nbytes,
+                                      info, None) == nat.E_NOPOINTS
+    nat.check(lib.ofl_scatter_linear_dev(f.ptr, 1, 0, none.ptr, vals.ptr, 3, None, h, w, None, out.ptr, valid.ptr,
+                                         nat.SCATTER_UNCERTIFIED, ws.ptr, ws.nbytes, None, None))
+    assert not valid.to_host((h, w), np.uint8).any() and not out.to_host((h, w, 3), np.float32).any()
+
+
 def test_exact_path_medium_field_against_scipy(gpu, oracle, near2_always):
     """One field large enough (240 x 320) for every star pass to see real work -- a smooth non-affine warp with a 15-px
     tear along a slanted line (folds on one side, a gap on the other), a 40 x 60 hole and 3 % speckle in the point mask,

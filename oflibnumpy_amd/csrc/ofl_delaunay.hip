@@ -1121,10 +1121,18 @@ __device__ __forceinline__ bool star_has(const DlWs &ws, unsigned s, unsigned a,
 {
     const unsigned d = ws.deg[s];
     if (d <= kSlots) {
-        const unsigned *nb = ws.nbr + (size_t)s * kSlots;
-        for (unsigned k = 0; k < d; ++k)
-            if (nb[k] == a) return nb[k + 1 == d ? 0 : k + 1] == b;
-        return false;
+        // the whole row in four 16-byte loads that are in flight together (a loop that stops at the match is a chain of
+        // dependent 4-byte loads: this look-up is most of the small-triangle raster's time)
+        const uint4 *row = reinterpret_cast<const uint4 *>(ws.nbr + (size_t)s * kSlots);
+        const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        const unsigned v[kSlots] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w };
+        bool has = false;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const unsigned nxt = (unsigned)(k + 1) < d ? v[(k + 1) & (kSlots - 1)] : v[0];      // (k + 1 == d == 16 wraps to v[0] either way)
+            has = has || ((unsigned)k < d && v[k] == a && nxt == b);
+        }
+        return has;
     }
     if (d != kDegFar) return false;
     const unsigned rank = ws.nbr[(size_t)s * kSlots], fd = ws.far_deg[rank];

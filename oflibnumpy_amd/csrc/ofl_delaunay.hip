@@ -1062,7 +1062,7 @@ __device__ void far_point(FarLds<CAP, 256> &L, unsigned &s_off, unsigned li, uns
 }
 
 template <int CAP>          // first with a small cell capacity (several workgroups per CU), then -- for the few fans that overflowed it -- the large one
-__global__ __launch_bounds__(256, 4)     // (room for four workgroups per CU: the sweep waits on votes and loads)
+__global__ __launch_bounds__(256, CAP <= 512 ? 4 : 1)     // (small cells: room for four workgroups per CU -- the sweep waits on votes and loads)
 void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,

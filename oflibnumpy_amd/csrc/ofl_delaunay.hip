@@ -448,13 +448,12 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, int H, int W,
         bool ok = rc == 1;
         for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
         if (!ok) {
-            // unfinished: the sites that bound the cell so far seed the later passes (slot 0 will hold the point's rank,
-            // slot 1 the number of seeds, slot 14 the last fine ring that was applied completely) -- applied first, they
-            // spare those passes most of their clips
+            // unfinished: the edges of the cell so far -- their sites in cyclic order, box sides (negative) included -- seed
+            // the later passes, which rebuild the cell from them in one step (slot 0 will hold the point's rank, slot 1 the
+            // number of seeds, slot 14 the last fine ring that was applied completely)
             deg[p] = kDegFar;
-            unsigned c = 0;
-            for (int k = 0; k < P.n; ++k) if (P.T(k) >= 0) nbr[p * kSlots + 2 + c++] = (unsigned)P.T(k);
-            nbr[p * kSlots + 1] = c;
+            for (int k = 0; k < P.n; ++k) nbr[p * kSlots + 2 + k] = (unsigned)P.T(k);
+            nbr[p * kSlots + 1] = (unsigned)P.n;
             nbr[p * kSlots + 14] = (unsigned)rings_done;
             continue;
         }
@@ -871,12 +870,34 @@ __device__ void far_coarse_annulus(FarLds<CAP, NT> &L, int p, const P2 &pp, int 
     }
 }
 
-// the sites the per-thread pass left in the point's neighbour slots: one chunk, applied before anything else
+// The cell the per-thread pass left in the point's neighbour slots (the sites of its edges in cyclic order, box sides
+// included): rebuilt in one step -- vertex k is where the lines of edges k - 1 and k meet, one lane each -- instead of one
+// cooperative clip per site (eight clips of a dozen barriers each were a third of the workgroup pass).  Should a vertex
+// not come out finite, the sites are applied as candidates the old way.
 template <int CAP, int NT, class RelFn>
 __device__ void far_seeds(FarLds<CAP, NT> &L, int p, const P2 &pp, const unsigned *__restrict__ nbr, const PosFn &pos, RelFn rel)
 {
     const unsigned *sd = nbr + (size_t)p * kSlots;
-    const int ns = min((int)sd[1], kSlots - 2), t = threadIdx.x;
+    const int ns = min((int)sd[1], kSlots - 4), t = threadIdx.x;
+    bool bad = ns < 3;
+    double vx = 0.0, vy = 0.0;
+    int tag = 0;
+    if (t < ns && !bad) {
+        double ax, ay, ah, bx, by, bh;
+        tag = (int)sd[2 + t];
+        edge_line((int)sd[2 + (t == 0 ? ns - 1 : t - 1)], rel, ax, ay, ah);
+        edge_line(tag, rel, bx, by, bh);
+        const double det = ax * by - bx * ay;
+        vx = (ah * by - bh * ay) / det; vy = (ax * bh - bx * ah) / det;
+        bad = det == 0.0 || !(isfinite(vx) && isfinite(vy)) || fabs(vx) > 4.0 * kBox || fabs(vy) > 4.0 * kBox;
+    }
+    if (!__syncthreads_or(bad)) {
+        if (t < ns) { L.vx[t] = vx; L.vy[t] = vy; L.tag[t] = tag; }
+        if (t == 0) L.n = ns;
+        __syncthreads();
+        far_refresh(L);
+        return;
+    }
     const int cand = t < ns ? (int)sd[2 + t] : -1;
     far_chunk(L, p, pp, cand, cand >= 0 ? pos(cand) : pp, rel);
 }

@@ -482,9 +482,33 @@ DL_HD int star_fan(int p, int W, const P2 &pp, unsigned kept8, PosFn pos, SlotPo
     return n;
 }
 
+// The polygon of a cell from the cyclic sequence of its edges' sites (box sides: -1 .. -4) -- what a pass that had to
+// leave the cell unfinished hands on: vertex k is where the lines of tags[k - 1] and tags[k] meet.  One step instead of one
+// clip per site.  Returns false (polygon untouched) when a vertex does not come out finite: the caller then clips the
+// sites one by one.
+template <class PolyX, class RelFn>
+DL_HD bool poly_from_tags(PolyX &P, const unsigned *tags, int n, RelFn rel)
+{
+    if (n < 3 || n > P.cap) return false;
+    double vx[16], vy[16];
+    if (n > 16) return false;
+    for (int k = 0; k < n; ++k) {
+        double ax, ay, ah, bx, by, bh;
+        edge_line((int)tags[k == 0 ? n - 1 : k - 1], rel, ax, ay, ah);
+        edge_line((int)tags[k], rel, bx, by, bh);
+        const double det = ax * by - bx * ay;
+        if (det == 0.0) return false;
+        vx[k] = (ah * by - bh * ay) / det; vy[k] = (ax * bh - bx * ah) / det;
+        if (!(isfinite(vx[k]) && isfinite(vy[k])) || fabs(vx[k]) > 4.0 * kBox || fabs(vy[k]) > 4.0 * kBox) return false;
+    }
+    for (int k = 0; k < n; ++k) { P.X(k) = vx[k]; P.Y(k) = vy[k]; P.T(k) = (int)tags[k]; }
+    P.n = n;
+    return true;
+}
+
 // Second per-thread attempt at a star the ring search left unfinished (rims of tears and small holes: cells tens of
-// bucket widths across, far too few vertices to be worth a workgroup).  The sites that bounded the cell when the ring
-// search stopped (`seeds`) rebuild it; the fine rings the search did not reach are applied; then rings of the COARSE
+// bucket widths across, far too few vertices to be worth a workgroup).  The edges the cell had when the ring search
+// stopped (`seeds`: their sites in cyclic order, box sides included) rebuild it; the fine rings the search did not reach are applied; then rings of the COARSE
 // grid, which holds only the unfinished sites -- a Delaunay neighbour beyond the fine rings is itself unfinished (a
 // finished site has all its neighbours within its own ring search, and a fan-verified one within kFanSpan buckets).
 // Returns 1 when the cell is final and bounded, 0 when it is not within `rings1` coarse rings (or still unbounded), -1
@@ -496,10 +520,12 @@ DL_HD int star_near2(PolyX &P, int p, const P2 &pp, const unsigned *seeds, int n
                      PosFn pos, int open_rings1 = 1 << 30)
 {
     auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
-    poly_init(P);
-    for (int i = 0; i < nseeds; ++i) {
-        const int c = (int)seeds[i];
-        if (poly_clip(P, rel(c), c, p, rel) < 0) return -1;
+    if (!poly_from_tags(P, seeds, nseeds, rel)) {
+        poly_init(P);
+        for (int i = 0; i < nseeds; ++i) {
+            const int c = (int)seeds[i];
+            if (c >= 0 && poly_clip(P, rel(c), c, p, rel) < 0) return -1;
+        }
     }
     double reach2 = 4.0 * poly_rmax2(P);
     // the coarse rings first: they are sparse, and a cell they cannot close (the rim of a large hole) is given up before

@@ -129,7 +129,7 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
                 continue;
             }
             if (rc < 0) ++overflow;
-            for (int k = 0; k < P.n; ++k) if (P.T(k) >= 0) seed_of[p].push_back((unsigned)P.T(k));
+            for (int k = 0; k < P.n; ++k) seed_of[p].push_back((unsigned)P.T(k));      // every edge, box sides included: the cell is rebuilt from them
             rd_of[p] = rdone;
             far.push_back(p);
             continue;

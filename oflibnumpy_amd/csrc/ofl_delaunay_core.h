@@ -90,6 +90,16 @@ DL_HD bool vertex_cut(const PolyX &P, int k, int n, const P2 &C, int ctag, int p
 {
     const int ta = P.T(k == 0 ? n - 1 : k - 1), tb = P.T(k);
     if (ctag == ta || ctag == tb) return false;       // the candidate already carries an edge at this vertex
+    if (sizeof(P.X(0)) == 4) {
+        // float32 cells (the per-thread passes, which are bound by exactly these instructions): the first look in float32
+        // as well -- the stored vertex is only good to 6e-8 anyway, and the margin below covers the rounding of three more
+        // float32 operations many times over; what it cannot decide goes through the float64 test and the predicate as before
+        const float cx = (float)C.x, cy = (float)C.y, hf = (float)h;
+        const float txf = (float)P.X(k) * cx, tyf = (float)P.Y(k) * cy, df = txf + tyf - hf;
+        const float mf = 8e-6f * (fabsf(txf) + fabsf(tyf) + hf);
+        if (df > mf) return true;
+        if (df < -mf) return false;
+    }
     const double tx = (double)P.X(k) * C.x, ty = (double)P.Y(k) * C.y;
     const double d = tx + ty - h;
     const double m = PolyX::decide * (fabs(tx) + fabs(ty) + h);

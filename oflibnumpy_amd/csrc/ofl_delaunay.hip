@@ -92,7 +92,7 @@ struct DlWs {
     unsigned *sorted1_pt;  // [N] point indices in `sorted1` order
     P2       *left_xy;     // [N] positions of the left-over points, in left_idx order
     unsigned *left_pt;     // [N] their point indices
-    double   *left_box;    // [N / 256 + 1][4] bounding boxes (x0, y0, x1, y1) of 256 consecutive left-over points
+    double   *left_box;    // [N / 256 + 1][2][8] oriented boxes of the two image halves of 256 consecutive left-over points
     int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
     unsigned *big;         // [big_cap] triangle ids with a large bounding box
     uint32_t *owner;       // [H][W] (biased by the first row of the band)
@@ -215,7 +215,9 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
         }
         g.ox = x0; g.oy = y0; g.s = s; g.inv_s = 1.0 / s;
         g.gx = (int)(floor(bw / s) + 1.0); g.gy = (int)(floor(bh / s) + 1.0);
-        const double t = 8.0 * (bw + bh) + 8.0 * s;
+        // beyond the data from any site in it (float32 flows of hundreds of pixels leave a straight border 1e-5 px rough:
+        // its sliver triangles have circumcentres 1e4 px out, which must count as far for the reach of the near ones to mean anything)
+        const double t = 1.5 * (bw + bh) + 8.0 * s;
         head->far_t2 = t * t;
     } else head->far_t2 = 1.0;
     head->grid = g;
@@ -334,33 +336,59 @@ void dl_list_xy_kernel(const float *__restrict__ flow, int sign, int W, const Dl
     }
 }
 
-// bounding box of every 256 consecutive left-over points (one workgroup each): the sweeps of the workgroup pass skip the
-// chunks whose box cannot hold a cutting site
+// Bounds of every 256 consecutive left-over points (one workgroup each): the sweeps of the workgroup pass skip the chunks
+// that cannot hold a cutting site.  Left-over points are mostly image-border points in index order -- the top row, then the
+// left and right columns in turns, then the bottom row -- so a chunk is split by image half (x < W / 2 or not) and each
+// half gets an ORIENTED box along the line from its first to its last point: a piece of one border side is a thin sliver
+// whatever the rotation of the field (an axis-aligned box of a slanted side holds the whole hull).
+// box[chunk][half] = { ox, oy, ax, ay, t0, t1, s0, s1 }: origin, unit axis, ranges along the axis and along (-ay, ax);
+// t0 > t1: the half is empty.
 __global__ __launch_bounds__(256)
-void dl_left_box_kernel(const DlHead *__restrict__ head, const P2 *__restrict__ left_xy, double *__restrict__ box)
+void dl_left_box_kernel(const DlHead *__restrict__ head, int W, const unsigned *__restrict__ left_pt,
+                        const P2 *__restrict__ left_xy, double *__restrict__ box)
 {
-    __shared__ double s_b[4][4];
+    __shared__ unsigned s_first[2], s_last[2];
+    __shared__ unsigned long long s_k[2][4];               // ordered keys of t0 (min), t1 (max), s0 (min), s1 (max)
     const unsigned n = head->n_left;
+    const int t = threadIdx.x;
     for (unsigned chunk = blockIdx.x; chunk * 256u < n; chunk += gridDim.x) {
-    __syncthreads();
-    const unsigned j = chunk * 256 + threadIdx.x;
-    double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
-    if (j < n) { const P2 q = left_xy[j]; x0 = x1 = q.x; y0 = y1 = q.y; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        x0 = fmin(x0, __hiloint2double(__shfl_xor(__double2hiint(x0), off), __shfl_xor(__double2loint(x0), off)));
-        y0 = fmin(y0, __hiloint2double(__shfl_xor(__double2hiint(y0), off), __shfl_xor(__double2loint(y0), off)));
-        x1 = fmax(x1, __hiloint2double(__shfl_xor(__double2hiint(x1), off), __shfl_xor(__double2loint(x1), off)));
-        y1 = fmax(y1, __hiloint2double(__shfl_xor(__double2hiint(y1), off), __shfl_xor(__double2loint(y1), off)));
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_b[0][w] = x0; s_b[1][w] = y0; s_b[2][w] = x1; s_b[3][w] = y1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) { x0 = fmin(x0, s_b[0][k]); y0 = fmin(y0, s_b[1][k]); x1 = fmax(x1, s_b[2][k]); y1 = fmax(y1, s_b[3][k]); }
-        double *b = box + (size_t)chunk * 4;
-        b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1;
-    }
+        __syncthreads();
+        if (t < 2) { s_first[t] = 0xFFFFFFFFu; s_last[t] = 0u; s_k[t][0] = ~0ull; s_k[t][1] = 0ull; s_k[t][2] = ~0ull; s_k[t][3] = 0ull; }
+        __syncthreads();
+        const unsigned j = chunk * 256 + t;
+        const bool in = j < n;
+        P2 q{ 0.0, 0.0 };
+        int half = 0;
+        if (in) {
+            q = left_xy[j];
+            half = (int)(left_pt[j] % (unsigned)W) * 2 >= W ? 1 : 0;
+            atomicMin(&s_first[half], j);
+            atomicMax(&s_last[half], j);
+        }
+        __syncthreads();
+        double ax = 1.0, ay = 0.0, ox = 0.0, oy = 0.0;
+        if (in) {
+            const P2 o = left_xy[s_first[half]], e = left_xy[s_last[half]];
+            const double dx = e.x - o.x, dy = e.y - o.y, len = sqrt(dx * dx + dy * dy);
+            ox = o.x; oy = o.y;
+            if (len > 0.0 && isfinite(len)) { ax = dx / len; ay = dy / len; }
+            const double rx = q.x - ox, ry = q.y - oy, tt = rx * ax + ry * ay, ss = ry * ax - rx * ay;
+            atomicMin(&s_k[half][0], okey(tt)); atomicMax(&s_k[half][1], okey(tt));
+            atomicMin(&s_k[half][2], okey(ss)); atomicMax(&s_k[half][3], okey(ss));
+        }
+        __syncthreads();
+        if (t < 2) {
+            double *b = box + ((size_t)chunk * 2 + t) * 8;
+            if (s_first[t] == 0xFFFFFFFFu) { b[4] = 1.0; b[5] = 0.0; }          // empty half
+            else {
+                const P2 o = left_xy[s_first[t]], e = left_xy[s_last[t]];
+                const double dx = e.x - o.x, dy = e.y - o.y, len = sqrt(dx * dx + dy * dy);
+                double axx = 1.0, ayy = 0.0;
+                if (len > 0.0 && isfinite(len)) { axx = dx / len; ayy = dy / len; }       // (the same expressions as above: the same axis)
+                b[0] = o.x; b[1] = o.y; b[2] = axx; b[3] = ayy;
+                b[4] = okey_inv(s_k[t][0]); b[5] = okey_inv(s_k[t][1]); b[6] = okey_inv(s_k[t][2]); b[7] = okey_inv(s_k[t][3]);
+            }
+        }
     }
 }
 
@@ -1032,25 +1060,30 @@ __device__ void far_point(FarLds<CAP, 256> &L, unsigned &s_off, unsigned li, uns
         bool keep = false;
         const unsigned ck = cbase + t;
         if (ck < n_chunks) {
-            const double *b = left_box + (size_t)ck * 4;
-            const double x0 = b[0] - pp.x, y0 = b[1] - pp.y, x1 = b[2] - pp.x, y1 = b[3] - pp.y;
-            const double dx = fmax(fmax(x0, -x1), 0.0), dy = fmax(fmax(y0, -y1), 0.0), dmin2 = dx * dx + dy * dy;
-            if (dmin2 < L.reach2) keep = true;
-            else if (L.nfar != 0) {
-                keep = true;
-                if (L.cone) {
-                    double mmax = 0.0, amax = 0.0;
-                    bool right0 = true, left1 = true;            // every corner strictly outside one side of the cone?
+#pragma unroll 1
+            for (int half = 0; half < 2 && !keep; ++half) {
+                const double *b = left_box + ((size_t)ck * 2 + half) * 8;
+                const double ax = b[2], ay = b[3], t0 = b[4], t1 = b[5], s0 = b[6], s1 = b[7];
+                if (!(t0 <= t1)) continue;                       // empty half
+                const double rx = b[0] - pp.x, ry = b[1] - pp.y;              // the box origin seen from the site
+                const double tp = -(rx * ax + ry * ay), sp = -(ry * ax - rx * ay);        // the site in the box frame
+                const double dt = fmax(fmax(t0 - tp, tp - t1), 0.0), ds = fmax(fmax(s0 - sp, sp - s1), 0.0), dmin2 = dt * dt + ds * ds;
+                if (dmin2 < L.reach2) { keep = true; break; }
+                if (L.nfar == 0) continue;
+                if (!L.cone) { keep = true; break; }
+                double mmax = 0.0, amax = 0.0;
+                bool right0 = true, left1 = true;                // every corner strictly outside one side of the cone?
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const double cx = (k & 1) ? x1 : x0, cy = (k & 2) ? y1 : y0;
-                        mmax = fmax(mmax, fmax(L.c0x * cx + L.c0y * cy, L.c1x * cx + L.c1y * cy));
-                        amax = fmax(amax, fabs(cx) + fabs(cy));
-                        right0 = right0 && (L.c0x * cy - L.c0y * cx < 0.0);
-                        left1 = left1 && (cx * L.c1y - cy * L.c1x < 0.0);
-                    }
-                    if ((right0 || left1) && mmax + 1e-9 * amax < dmin2 * L.kcone) keep = false;
+                for (int k = 0; k < 4; ++k) {
+                    const double tt = (k & 1) ? t1 : t0, ss = (k & 2) ? s1 : s0;
+                    const double cx = rx + tt * ax - ss * ay, cy = ry + tt * ay + ss * ax;
+                    mmax = fmax(mmax, fmax(L.c0x * cx + L.c0y * cy, L.c1x * cx + L.c1y * cy));
+                    amax = fmax(amax, fabs(cx) + fabs(cy));
+                    right0 = right0 && (L.c0x * cy - L.c0y * cx < 0.0);
+                    left1 = left1 && (cx * L.c1y - cy * L.c1x < 0.0);
                 }
+                // (the corners are rounded: a margin of 1e-9 of their size on the dot products, as on the sites themselves)
+                if (!((right0 || left1) && mmax + 2e-9 * amax < dmin2 * L.kcone)) keep = true;
             }
         }
         // ordered compaction of the kept chunk numbers of this group
@@ -1413,7 +1446,7 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.sorted1_pt = (unsigned *)p;          p += align_up(n * 4, 256);
     ws.left_xy = (P2 *)p;                   p += align_up(n * 16, 256);
     ws.left_pt = (unsigned *)p;             p += align_up(n * 4, 256);
-    ws.left_box = (double *)p;              p += align_up((n / 256 + 1) * 32, 256);
+    ws.left_box = (double *)p;              p += align_up((n / 256 + 1) * 128, 256);
     ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
     ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
@@ -1547,7 +1580,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                            (const unsigned *)lcnt, ws.left_idx, fblk - 1, (unsigned *)nullptr);
         hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
-        hipLaunchKernelGGL(dl_left_box_kernel, dim3(rblk), dim3(256), 0, s, (const DlHead *)ws.head, (const P2 *)ws.left_xy, ws.left_box);
+        hipLaunchKernelGGL(dl_left_box_kernel, dim3(rblk), dim3(256), 0, s, (const DlHead *)ws.head, W, (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, ws.left_box);
         hipLaunchKernelGGL(dl_star_far_kernel<512>, dim3(walk), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,

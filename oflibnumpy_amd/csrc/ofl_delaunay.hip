@@ -83,6 +83,7 @@ struct DlWs {
     unsigned *far_idx;     // [N]
     unsigned *far_deg;     // [N]
     unsigned *far_off;     // [N]
+    unsigned char *far_wide; // [N] 1 = finished by the wave pass BEYOND the coarse rings the workgroup pass searches: stays a candidate of its sweeps
     unsigned *left_idx;    // [N] ranks of the points the wave pass could not finish
     unsigned *b1start;     // [b1cap + 1] coarse buckets of the unfinished points
     unsigned *b1cursor;    // [b1cap]
@@ -137,6 +138,9 @@ struct PosFn {
 };
 
 __device__ __forceinline__ bool kept_pt(const uint8_t *pmask, size_t i) { return !pmask || pmask[i] != 0; }
+// a point with a NaN / Inf position cannot be a site (the reference's Flow refuses such vectors; behind the bare C ABI they
+// are dropped like masked-out points instead of sending bucket indices out of range)
+__device__ __forceinline__ bool finite_pt(double x, double y) { return isfinite(x) && isfinite(y); }
 
 // exclusive scan of one value per thread over a 256-thread block; `total` = block sum (valid in all threads)
 __device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned &total)
@@ -169,6 +173,7 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
         for (int y = blockIdx.y * 8 + (threadIdx.x >> 5); y < H; y += gridDim.y * 8) {
             if (!kept_pt(pmask, (size_t)y * W + x)) continue;
             const D2 p = point_of(flow, sign, W, x, y);
+            if (!finite_pt(p.x, p.y)) continue;
             x0 = fmin(x0, p.x); x1 = fmax(x1, p.x); y0 = fmin(y0, p.y); y1 = fmax(y1, p.y);
             ++cnt;
         }
@@ -197,13 +202,21 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     }
 }
 
-__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale)
+__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale, int H, int W)
 {
     Grid g;
     g.ox = 0.0; g.oy = 0.0; g.s = 1.0; g.inv_s = 1.0; g.gx = 1; g.gy = 1;
     const unsigned n = head->kept;
     if (n > 0) {
-        const double x0 = okey_inv(head->kx0), x1 = okey_inv(head->kx1), y0 = okey_inv(head->ky0), y1 = okey_inv(head->ky1);
+        double x0 = okey_inv(head->kx0), x1 = okey_inv(head->kx1), y0 = okey_inv(head->ky0), y1 = okey_inv(head->ky1);
+        // The grid covers at most the image and a margin of W + H around it: a handful of garbage vectors (1e9 marks
+        // "unknown" in some flow files) must not blow the buckets up to thousands of sites each.  Sites beyond it fall
+        // into the border buckets (Grid::bx / by clamp) -- seen from any site inside, such a site is at least as far away
+        // as its bucket, which is all the ring searches rely on; the outliers themselves never close within the rings and
+        // end in the passes that run until the candidates are exhausted.
+        const double m = (double)W + (double)H;
+        x0 = fmax(x0, fmin(-m, x1 - 1.0)); x1 = fmin(x1, fmax((double)W + m, x0 + 1.0));
+        y0 = fmax(y0, fmin(-m, y1 - 1.0)); y1 = fmin(y1, fmax((double)H + m, y0 + 1.0));
         const double bw = x1 - x0, bh = y1 - y0;
         double s = bucket_scale * sqrt(fmax(bw * bh, 1e-300) / (double)n);             // ~bucket_scale^2 points per bucket
         s = fmax(s, (bw + bh) / (double)n);
@@ -254,12 +267,13 @@ void dl_fill1_kernel(const float *__restrict__ flow, int sign, int W, const DlHe
 
 __global__ __launch_bounds__(256)
 void dl_count_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
-                     const DlHead *__restrict__ head, unsigned *__restrict__ bcount)
+                     const DlHead *__restrict__ head, unsigned *__restrict__ bcount, unsigned char *__restrict__ dup)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)H * W || !kept_pt(pmask, i)) return;
     const Grid g = head->grid;
     const P2 p = PosFn(flow, sign, W)((int)i);
+    if (!finite_pt(p.x, p.y)) { dup[i] = 1; return; }      // not a site (flagged like a dropped duplicate)
     atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
 }
 
@@ -292,10 +306,10 @@ void dl_scan_apply_kernel(unsigned *__restrict__ data, size_t n, const unsigned 
 __global__ __launch_bounds__(256)
 void dl_fill_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
                     const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ cursor,
-                    unsigned *__restrict__ sorted)
+                    unsigned *__restrict__ sorted, const unsigned char *__restrict__ dup)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)H * W || !kept_pt(pmask, i)) return;
+    if (i >= (size_t)H * W || !kept_pt(pmask, i) || dup[i]) return;
     const Grid g = head->grid;
     const P2 p = PosFn(flow, sign, W)((int)i);
     const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
@@ -501,7 +515,7 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
                           const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                           const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt,
                           const P2 *__restrict__ sorted1_xy, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr,
-                          unsigned *__restrict__ far_deg, unsigned min_points)
+                          unsigned *__restrict__ far_deg, unsigned char *__restrict__ far_wide, unsigned min_points)
 {
     __shared__ float s_vx[kSlots][64], s_vy[kSlots][64];
     __shared__ int   s_tag[kSlots][64];
@@ -522,27 +536,31 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
     for (int k = 0; k < P.n; ++k) row[k] = (unsigned)P.T(k);
     deg[p] = (unsigned char)P.n;
     far_deg[rank] = 0;                                     // not a cooperative-pass star: nothing in the pool
+    far_wide[rank] = 0;                                    // (its reach is within the coarse rings every later pass searches)
     }
 }
 
 // compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx,
 // MODE 2 = points with deg == kDegTodo -> todo_idx
+// MODE 1 also lists the ranks the wave pass finished beyond kMidRings coarse rings (aux = far_wide): they are not computed
+// again, but the workgroup pass searches the coarse grid only that far around a point, and a neighbour whose own cell
+// reaches farther would otherwise be missing from its candidates.
 template <int MODE>
-__device__ __forceinline__ bool flagged(const void *src, size_t i)
+__device__ __forceinline__ bool flagged(const void *src, const unsigned char *aux, size_t i)
 {
     return MODE == 0 ? ((const unsigned char *)src)[i] == kDegFar
-         : MODE == 2 ? ((const unsigned char *)src)[i] == kDegTodo : ((const unsigned *)src)[i] == kDegLeft;
+         : MODE == 2 ? ((const unsigned char *)src)[i] == kDegTodo : (((const unsigned *)src)[i] == kDegLeft || aux[i] != 0);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256)
-void dl_flag_count_kernel(const void *__restrict__ src, const DlHead *__restrict__ head, size_t n_fixed, unsigned *__restrict__ cnt)
+void dl_flag_count_kernel(const void *__restrict__ src, const unsigned char *__restrict__ aux, const DlHead *__restrict__ head, size_t n_fixed, unsigned *__restrict__ cnt)
 {
     const size_t n = MODE != 1 ? n_fixed : head->n_far;
     const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, base + k)) ++v;
+    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, aux, base + k)) ++v;
     unsigned total;
     (void)block_exscan(v, total);
     if (threadIdx.x == 0) cnt[blockIdx.x] = total;
@@ -550,19 +568,19 @@ void dl_flag_count_kernel(const void *__restrict__ src, const DlHead *__restrict
 
 template <int MODE>
 __global__ __launch_bounds__(256)
-void dl_flag_write_kernel(const void *__restrict__ src, DlHead *head, size_t n_fixed, const unsigned *__restrict__ offs,
+void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__restrict__ aux, DlHead *head, size_t n_fixed, const unsigned *__restrict__ offs,
                           unsigned *__restrict__ list, unsigned last_block, unsigned *__restrict__ rank_of)
 {
     const size_t n = MODE != 1 ? n_fixed : head->n_far;
     const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, base + k)) ++v;
+    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, aux, base + k)) ++v;
     unsigned total;
     unsigned at = block_exscan(v, total) + offs[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-        if (base + k < n && flagged<MODE>(src, base + k)) {
+        if (base + k < n && flagged<MODE>(src, aux, base + k)) {
             if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
             list[at++] = (unsigned)(base + k);
         }
@@ -954,7 +972,8 @@ __device__ void mid_point(FarLds<kMidCap, 64> &L, unsigned &s_off, unsigned rank
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
                         const unsigned *__restrict__ far_idx, const unsigned char *__restrict__ deg, const unsigned *__restrict__ nbr,
-                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
+                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap,
+                        unsigned char *__restrict__ far_wide)
 {
     const int t = threadIdx.x;
     const int p = (int)far_idx[rank];
@@ -983,7 +1002,8 @@ __device__ void mid_point(FarLds<kMidCap, 64> &L, unsigned &s_off, unsigned rank
     const int cbx = g1.bx(pp.x), cby = g1.by(pp.y);
     const int rgrid = max(max(cbx, g1.gx - 1 - cbx), max(cby, g1.gy - 1 - cby));
     bool done = false;
-    for (int ra = -1; ra < rmax && !done;) {
+    int ra = -1;                                           // the last ring applied
+    for (; ra < rmax && !done;) {
         // ring by ring while the cell is small; then annuli that grow by half their radius (one pass over their rows
         // instead of one per ring: the rim of a large hole needs a hundred rings)
         const int rb = ra < kMidRings ? ra + 1 : min(ra + max(ra / 2, 1), rmax);
@@ -1000,6 +1020,7 @@ __device__ void mid_point(FarLds<kMidCap, 64> &L, unsigned &s_off, unsigned rank
         ra = rb;
     }
     __syncthreads();
+    if (t == 0) far_wide[rank] = (done && !L.status && ra > kMidRings) ? 1 : 0;
     if (!done || L.status) { if (t == 0) far_deg[rank] = kDegLeft; return; }
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
 }
@@ -1010,7 +1031,8 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
                         const unsigned *__restrict__ far_idx, const unsigned char *__restrict__ deg, const unsigned *__restrict__ nbr,
-                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap)
+                        unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool, unsigned long long pool_cap,
+                        unsigned char *__restrict__ far_wide)
 {
     __shared__ FarLds<kMidCap, 64> L;
     __shared__ unsigned s_off;
@@ -1018,7 +1040,7 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     for (unsigned rank = blockIdx.x; rank < n_far; rank += gridDim.x) {
         __syncthreads();                                   // the previous point's cell has been stored by every thread
         mid_point(L, s_off, rank, flow, sign, H, W, head, bstart, sorted, sorted_xy, b1start, sorted1_pt, sorted1_xy, far_idx, deg, nbr,
-                  far_deg, far_off, pool, pool_cap);
+                  far_deg, far_off, pool, pool_cap, far_wide);
     }
 }
 
@@ -1437,6 +1459,7 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.far_idx = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_deg = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_off = (unsigned *)p;             p += align_up(n * 4, 256);
+    ws.far_wide = (unsigned char *)p;       p += align_up(n, 256);
     ws.left_idx = (unsigned *)p;            p += align_up(n * 4, 256);
     ws.b1start = (unsigned *)p;             p += align_up((ws.b1cap + 1) * 4, 256);
     ws.b1cursor = (unsigned *)p;            p += align_up(ws.b1cap * 4, 256);
@@ -1511,17 +1534,17 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     const unsigned nblk = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 1024 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
     static const double bucket_scale = getenv("OFL_DL_BUCKET") ? atof(getenv("OFL_DL_BUCKET")) : 1.0;      // development knob
-    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale);
-    hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart);
+    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W);
+    OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
+    hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup);
     OFL_HIP(hipGetLastError());
     OFL_TRY(scan_exclusive(ws.bstart, ws.bcap + 1, ws.scan_tmp, s));
     hipLaunchKernelGGL(dl_fill_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
-                       (const unsigned *)ws.bstart, ws.nbr, ws.sorted);
+                       (const unsigned *)ws.bstart, ws.nbr, ws.sorted, (const unsigned char *)ws.dup);
     hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
                        (const DlHead *)ws.head, 0, (const unsigned *)ws.bstart, ws.sorted);
     hipLaunchKernelGGL(dl_list_xy_kernel<0>, dim3(std::min<unsigned>(nblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
                        (const unsigned *)ws.sorted, (const unsigned *)nullptr, ws.sorted_xy, (unsigned *)nullptr);
-    OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
     hipLaunchKernelGGL(dl_dedupe_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
                        (const DlHead *)ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy, ws.dup);
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
@@ -1530,18 +1553,18 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                        (const unsigned char *)ws.dup, ws.deg, ws.nbr);
     // what the fans did not settle, in index order, for the clip pass
-    hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const DlHead *)ws.head, n, fcnt);
+    hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, ws.head, n, (const unsigned *)fcnt,
+    hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
                        ws.todo_idx, fblk - 1, (unsigned *)nullptr);
     hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.todo_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
                        (const P2 *)ws.sorted_xy, ws.deg, ws.nbr);
     OFL_HIP(hipGetLastError());
     // unfinished points in index order
-    hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const DlHead *)ws.head, n, fcnt);
+    hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_flag_write_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, ws.head, n, (const unsigned *)fcnt,
+    hipLaunchKernelGGL(dl_flag_write_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
                        ws.far_idx, fblk - 1, ws.nbr);
     OFL_HIP(hipGetLastError());
     // From here on every launch is sized on the device: fixed grids walk the unfinished points, whose numbers stay in the
@@ -1567,16 +1590,16 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         hipLaunchKernelGGL(dl_star_near2_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 8192u)), dim3(64), 0, s, flow, sign_pp, H, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
                            (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start, (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy,
-                           ws.deg, ws.nbr, ws.far_deg, n2 ? (unsigned)atoi(n2) : kNear2MinPoints);
+                           ws.deg, ws.nbr, ws.far_deg, ws.far_wide, n2 ? (unsigned)atoi(n2) : kNear2MinPoints);
         hipLaunchKernelGGL(dl_star_mid_kernel, dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned char *)ws.deg, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
-                           (unsigned long long)ws.pool_cap);
+                           (unsigned long long)ws.pool_cap, ws.far_wide);
         OFL_HIP(hipGetLastError());
         unsigned *lcnt = (unsigned *)ws.big;                             // the large-triangle list is empty until the raster passes
-        hipLaunchKernelGGL(dl_flag_count_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, (const DlHead *)ws.head, (size_t)0, lcnt);
+        hipLaunchKernelGGL(dl_flag_count_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, (const unsigned char *)ws.far_wide, (const DlHead *)ws.head, (size_t)0, lcnt);
         OFL_TRY(scan_exclusive(lcnt, fblk, ws.scan_tmp, s));
-        hipLaunchKernelGGL(dl_flag_write_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, ws.head, (size_t)0,
+        hipLaunchKernelGGL(dl_flag_write_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, (const unsigned char *)ws.far_wide, ws.head, (size_t)0,
                            (const unsigned *)lcnt, ws.left_idx, fblk - 1, (unsigned *)nullptr);
         hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);

@@ -308,6 +308,84 @@ def test_both_paths_agree_at_full_size(gpu):
     assert (cutv[~far] == 1).mean() > 0.5                                  # the hole and the tear are triangulated across
 
 
+def test_notch_open_to_the_border(gpu, oracle, near2_always):
+    """A 110 x 170 notch of dropped points that is OPEN to the image border: the two border points at its mouth are hull
+    points (workgroup pass), the rim points at its bottom close only after a dozen coarse rings (wave pass), and they are
+    Delaunay neighbours of each other across more than the coarse rings the workgroup pass searches -- the wave pass
+    leaves such wide-reaching stars in the candidate list of the sweeps.  Whole result against SciPy."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev
+    rng = np.random.default_rng(41)
+    h, w = 230, 330
+    vecs = affine_field((h, w), 0.06, 0.11, -0.07, 0.045, 4.0, -3.0)
+    pm = np.ones((h, w), bool)
+    pm[:110, 80:250] = False
+    pm[150:, 140:143] = False                                                # and a slit open to the bottom border
+    vals = rng.random((h, w, 2), dtype=np.float32)
+    vm = rng.random((h, w)) > 0.1
+    f, dv, dm, dpm = (dev.DeviceBuffer.from_host(a) for a in (vecs, vals, vm.astype(np.uint8), pm.astype(np.uint8)))
+    out, valid = dev.DeviceBuffer(h * w * 8), dev.DeviceBuffer(h * w)
+    dev.scatter_linear(f, +1, dpm, dv, 2, dm, h, w, None, out, valid, 0)
+    got, gv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+    want = O.scatter_griddata(vecs, np.concatenate([vals, vm[..., None].astype(np.float32)], -1), pm)
+    yy, xx = np.mgrid[:h, :w]
+    pts = np.stack([(xx + vecs[..., 0].astype(np.float64)).ravel(), (yy + vecs[..., 1].astype(np.float64)).ravel()], 1)[pm.ravel()]
+    amb, inside = nonunique_nodes(pts, (h, w))
+    assert amb.mean() < 0.01
+    np.testing.assert_array_equal(gv[~amb], (want[..., -1] == 1)[~amb])
+    bad = ~np.isclose(got, want[..., :2], rtol=RTOL, atol=ATOL).all(-1)
+    assert not (bad & ~amb).any(), (int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:4].tolist())
+    assert gv[20:90, 100:230].mean() > 0.5                                   # the notch is triangulated across (inside the hull)
+
+
+def test_garbage_vectors_do_not_hurt(gpu, golden2):
+    """Behind the bare C ABI nothing has validated the vectors (the reference's Flow refuses NaN / Inf): points with a
+    non-finite position are dropped like masked-out points -- the result is bit-identical to the call that masks them --
+    and a handful of 1e9 vectors ("unknown flow" in some files) neither blow the buckets up to thousands of sites (the
+    call stays fast) nor change the result away from the hull."""
+    import time
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    vecs, mask, img, _ = fixture_case(golden2, "curved")
+    h, w = vecs.shape[:2]
+    rng = np.random.default_rng(8)
+    bad = rng.random((h, w)) < 0.01
+    bad[0, 0] = bad[h // 2, w // 2] = True
+    v2 = vecs.copy()
+    v2[bad] = rng.choice(np.float32([np.nan, np.inf, -np.inf]), (int(bad.sum()), 2))
+    vals = dev.DeviceBuffer.from_host(img)
+    res = []
+    for fv, pm in ((v2, None), (vecs, ~bad)):
+        out, valid = dev.DeviceBuffer(h * w * 12), dev.DeviceBuffer(h * w)
+        info = dev.scatter_linear(dev.DeviceBuffer.from_host(fv), +1, None if pm is None else dev.DeviceBuffer.from_host(pm.astype(np.uint8)),
+                                  vals, 3, None, h, w, None, out, valid, 0)
+        assert info[0] == int((~bad).sum())
+        res.append((out.to_host((h, w, 3), np.float32), valid.to_host((h, w), np.uint8)))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    # outliers at 1080p: time and the interior
+    H, W = 1080, 1920
+    big = affine_field((H, W), 0.05, 0.02, -0.03, 0.04, 2.0, 1.0)
+    img2 = rng.random((H, W, 1), dtype=np.float32)
+    fb, vb = dev.DeviceBuffer.from_host(big), dev.DeviceBuffer.from_host(img2)
+    out, valid = dev.DeviceBuffer(H * W * 4), dev.DeviceBuffer(H * W)
+    dev.scatter_linear(fb, +1, None, vb, 1, None, H, W, None, out, valid, of.native.SCATTER_UNCERTIFIED)
+    clean = out.to_host((H, W, 1), np.float32)
+    wild = big.copy()
+    for (y, x) in ((5, 7), (500, 900), (1079, 1919), (700, 3)):
+        wild[y, x] = [1e9, -3e8]
+    t0 = time.perf_counter()
+    dev.scatter_linear(dev.DeviceBuffer.from_host(wild), +1, None, vb, 1, None, H, W, None, out, valid, 0)
+    got = out.to_host((H, W, 1), np.float32)
+    assert time.perf_counter() - t0 < 2.0
+    far = np.ones((H, W), bool)
+    far[:40] = far[-40:] = False
+    far[:, :40] = far[:, -40:] = False
+    far[480:520, 880:920] = False
+    np.testing.assert_allclose(got[far], clean[far], rtol=RTOL, atol=ATOL)
+    assert valid.to_host((H, W), np.uint8)[far].all()
+
+
 def test_delaunay_path_without_counts(gpu, golden2):
     """info_host == NULL: the Delaunay path sizes every launch on the device and reads nothing back (the entry only
     enqueues); the result is bit-identical to the call that asks for the counts.  What can only be known after the

@@ -198,7 +198,8 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  * Source point i sits at (x, y) + sign*flow[i] -- evaluated in float64 (point_precision 0, utils.py:242)
  * or rounded to float32 first (point_precision 1, flow_class.py:1398-1400) -- and carries
  * vals[i][0..C) (float32) plus, optionally, a mask value vmask[i]; points with pmask[i] == 0 are
- * dropped (pmask NULL = keep all, utils.py:249-251).  The result is linear on the Delaunay triangulation of the kept
+ * dropped (pmask NULL = keep all, utils.py:249-251), and so are points whose position is not finite (the reference's Flow
+ * refuses NaN / Inf vectors before it gets here).  The result is linear on the Delaunay triangulation of the kept
  * points (what griddata builds with Qhull):
  *     out[H][W][C]  piecewise-linear interpolation (float64 barycentric, stored as float32),
  *                   0 where no triangle covers the node;

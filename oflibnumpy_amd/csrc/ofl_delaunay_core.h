@@ -262,11 +262,21 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
         }
         return 0;
     };
-    if (r == 0) return run(by, bx, bx);
-    if (run(by - r, bx - r, bx + r) < 0 || run(by + r, bx - r, bx + r) < 0) return -1;
-    for (int row = by - r + 1; row <= by + r - 1; ++row) {
-        if (bx - r >= 0 && run(row, bx - r, bx - r) < 0) return -1;
-        if (bx + r <= g.gx - 1 && run(row, bx + r, bx + r) < 0) return -1;
+    // the ring as a sequence of runs -- top row, bottom row, then the two end buckets of the rows between -- walked by ONE
+    // loop: four separate calls of `run` made four copies of the (four times unrolled) clip code, 250 KB per kernel
+    const int nseg = r == 0 ? 1 : 2 + 2 * (2 * r - 1);
+    for (int seg = 0; seg < nseg; ++seg) {
+        int row, x0, x1;
+        if (r == 0) { row = by; x0 = bx; x1 = bx; }
+        else if (seg == 0) { row = by - r; x0 = bx - r; x1 = bx + r; }
+        else if (seg == 1) { row = by + r; x0 = bx - r; x1 = bx + r; }
+        else {
+            const int m = seg - 2;
+            row = by - r + 1 + (m >> 1);
+            x0 = x1 = (m & 1) ? bx + r : bx - r;
+            if (x0 < 0 || x0 > g.gx - 1) continue;            // (a single bucket outside the grid must not be clamped onto the border one)
+        }
+        if (run(row, x0, x1) < 0) return -1;
     }
     return 0;
 }

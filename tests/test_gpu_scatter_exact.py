@@ -374,6 +374,9 @@ def test_garbage_vectors_do_not_hurt(gpu, golden2):
     wild = big.copy()
     for (y, x) in ((5, 7), (500, 900), (1079, 1919), (700, 3)):
         wild[y, x] = [1e9, -3e8]
+    for k in range(300):                                                     # and a spray of them in every direction: long slivers
+        ang = 2 * np.pi * k / 300                                            # from the hull to far away, each with the frame as its box
+        wild[3 + (k * 7) % (H - 6), 40 + (k * 131) % (W - 80)] = [4e5 * np.cos(ang), 4e5 * np.sin(ang)]
     t0 = time.perf_counter()
     dev.scatter_linear(dev.DeviceBuffer.from_host(wild), +1, None, vb, 1, None, H, W, None, out, valid, 0)
     got = out.to_host((H, W, 1), np.float32)
@@ -381,7 +384,11 @@ def test_garbage_vectors_do_not_hurt(gpu, golden2):
     far = np.ones((H, W), bool)
     far[:40] = far[-40:] = False
     far[:, :40] = far[:, -40:] = False
-    far[480:520, 880:920] = False
+    far[480:560, 880:960] = False
+    for k in range(300):                                                     # (where the displaced points USED to land)
+        y, x = 3 + (k * 7) % (H - 6), 40 + (k * 131) % (W - 80)
+        ly, lx = int(round(y + big[y, x, 1])), int(round(x + big[y, x, 0]))
+        far[max(ly - 3, 0):ly + 4, max(lx - 3, 0):lx + 4] = False
     np.testing.assert_allclose(got[far], clean[far], rtol=RTOL, atol=ATOL)
     assert valid.to_host((H, W), np.uint8)[far].all()
 

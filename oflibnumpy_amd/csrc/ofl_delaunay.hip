@@ -57,6 +57,10 @@ constexpr unsigned char kDegFar = 0xFF;
 constexpr unsigned char kDegTodo = 0xFE;  // not settled by the mesh-fan pass: the clip pass builds this star
 constexpr int      kFanSpan  = 6;        // buckets per axis a fan's circumcircles may span (wider: clip pass)
 constexpr int      kFanBlock = 128;
+constexpr unsigned kMaxBucket = 4096;     // sites one bucket may hold (coincident / collinear points in bulk: the point set is degenerate)
+constexpr unsigned kMaxFar   = 1u << 20;  // unfinished stars ...
+constexpr unsigned kMaxLeft  = 1u << 18;  // ... and stars for the workgroup pass (quadratic in their number) before the call gives up
+constexpr unsigned kErrDegenerate = 16u;  // err bit: one of the three limits above -- Qhull, too, refuses such input ("initial simplex is flat")
 constexpr int      kScanChunk = 2048;    // elements per block of the scan kernels (256 threads x 8)
 
 struct DlHead {                           // device header of the exact path (256 bytes)
@@ -411,12 +415,13 @@ void dl_left_box_kernel(const DlHead *__restrict__ head, int W, const unsigned *
 // The others are flagged, and their entries in the bucket list are blanked (index 0xFFFFFFFF: every consumer skips
 // negative candidates) -- a field with five sheets builds a fifth of the stars.
 __global__ __launch_bounds__(256)
-void dl_dedupe_kernel(const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted,
+void dl_dedupe_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted,
                       const P2 *__restrict__ sorted_xy, unsigned char *__restrict__ dup)
 {
     const size_t nb = (size_t)head->grid.gx * head->grid.gy;
     for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
         const unsigned lo = bstart[b], hi = bstart[b + 1];
+        if (hi - lo > kMaxBucket) atomicOr(&head->err, kErrDegenerate);
         if (hi - lo < 2 || hi - lo > 256) continue;
         for (unsigned j = lo + 1; j < hi; ++j) {
             const P2 q = sorted_xy[j];
@@ -442,6 +447,7 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
     const size_t p = (size_t)((blockIdx.x & 7u) * per + (blockIdx.x >> 3)) * kFanBlock + threadIdx.x;
     if (p >= (size_t)H * W) return;
     if (!kept_pt(pmask, p) || dup[p]) { deg[p] = 0; return; }
+    if (head->err & kErrDegenerate) { deg[p] = kDegTodo; return; }           // (the clip pass then sees n_todo = 0)
     const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
     // which of the eight grid neighbours exist: inside the grid, kept by the point mask, not a dropped duplicate
     unsigned kept8 = 0;
@@ -590,6 +596,8 @@ void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__r
             atomicOr(&head->err, 8u);                      // the unfinished stars exceed the triangle-id space: none is built, the caller is told
             cnt = 0;
         }
+        if ((MODE == 0 && cnt > kMaxFar) || (MODE == 1 && cnt > kMaxLeft)) { atomicOr(&head->err, kErrDegenerate); cnt = 0; }
+        if (head->err & kErrDegenerate) cnt = 0;           // a degenerate point set: no star pass runs (their loops are sized for ordinary buckets)
         if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else head->n_todo = cnt;
     }
 }
@@ -1570,7 +1578,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     hipLaunchKernelGGL(dl_list_xy_kernel<0>, dim3(std::min<unsigned>(nblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
                        (const unsigned *)ws.sorted, (const unsigned *)nullptr, ws.sorted_xy, (unsigned *)nullptr);
     hipLaunchKernelGGL(dl_dedupe_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
-                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy, ws.dup);
+                       ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy, ws.dup);
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
     unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
     hipLaunchKernelGGL(dl_star_fan_kernel, dim3((unsigned)(((n + kFanBlock - 1) / kFanBlock + 7) / 8 * 8)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
@@ -1656,7 +1664,8 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         if (h.kept == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
         if (h.err) return fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
                                               "neighbours, 2 = neighbour pool, 4 = large-triangle list, 8 = unfinished stars beyond the "
-                                              "triangle-id space)", h.err, kFarCap);
+                                              "triangle-id space, 16 = degenerate point set: thousands of coincident points or hundreds of "
+                                              "thousands of unbounded cells)", h.err, kFarCap);
     }
     return OFL_OK;
 }

@@ -393,6 +393,35 @@ def test_garbage_vectors_do_not_hurt(gpu, golden2):
     assert valid.to_host((H, W), np.uint8)[far].all()
 
 
+def test_degenerate_point_sets_are_refused_not_endured(gpu):
+    """Qhull refuses a flat point set ("initial simplex is flat"); here the star passes are sized for ordinary buckets and
+    a few ten thousand unbounded cells, so a field that maps a million points onto one spot, or onto one line, is reported
+    (OFL_E_INVALID, flag 16) instead of being ground through -- quickly, and with an all-invalid result."""
+    import time
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    nat, lib = of.native, of.native.load()
+    h, w = 1080, 1920
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    ws = dev._workspace(h, w, 1)
+    vals = dev.DeviceBuffer.from_host(np.ones((h, w, 1), np.float32))
+    for name, vecs in (("one spot", np.stack([100 - xx, 50 - yy], -1)), ("one line", np.stack([0 * xx, 200 - yy], -1))):
+        f = dev.DeviceBuffer.from_host(np.ascontiguousarray(vecs, np.float32))
+        out, valid = dev.DeviceBuffer(h * w * 4), dev.DeviceBuffer(h * w)
+        info = (ctypes.c_uint64 * 3)()
+        t0 = time.perf_counter()
+        rc = lib.ofl_scatter_linear_dev(f.ptr, 1, 0, None, vals.ptr, 1, None, h, w, None, out.ptr, valid.ptr, 0, ws.ptr, ws.nbytes, info, None)
+        assert rc == nat.E_INVALID and time.perf_counter() - t0 < 20.0, (name, rc, time.perf_counter() - t0)
+        assert not valid.to_host((h, w), np.uint8).any(), name
+    # ... while a SMALL degenerate set is simply triangulated as far as it goes (nothing to interpolate on: all invalid)
+    hs, wsm = 12, 16
+    ys, xs = np.mgrid[:hs, :wsm].astype(np.float32)
+    f = dev.DeviceBuffer.from_host(np.ascontiguousarray(np.stack([0 * xs, 5 - ys], -1), np.float32))
+    out, valid = dev.DeviceBuffer(hs * wsm * 4), dev.DeviceBuffer(hs * wsm)
+    dev.scatter_linear(f, +1, None, dev.DeviceBuffer.from_host(np.ones((hs, wsm, 1), np.float32)), 1, None, hs, wsm, None, out, valid, 0)
+    assert valid.to_host((hs, wsm), np.uint8).sum() <= wsm                  # at most the nodes ON the line
+
+
 def test_delaunay_path_without_counts(gpu, golden2):
     """info_host == NULL: the Delaunay path sizes every launch on the device and reads nothing back (the entry only
     enqueues); the result is bit-identical to the call that asks for the counts.  What can only be known after the

@@ -1548,8 +1548,10 @@ namespace {
 
 // Bins, stars and the owner map of rows [row0, row0 + rows).  Asynchronous unless the caller asks for the counts.
 int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows,
-                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s, DlWs &ws, unsigned &far_base_out)
+                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s, DlWs &ws, unsigned &far_base_out,
+                  int &late_error)      // OFL_E_NOPOINTS / capacity errors known only after the fact: the owner map is complete (empty) all the same
 {
+    late_error = OFL_OK;
     const size_t n = (size_t)H * W;
     if (n >= (1ull << 27)) return fail(OFL_E_INVALID, "ofl_scatter_linear: the exact path takes fields below 2^27 pixels");
     if (workspace_bytes < ofl_sc::exact_workspace_bytes(H, W)) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small for the exact path");
@@ -1661,8 +1663,8 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = h.n_left; }
         if (debug) fprintf(stderr, "[ofl exact] kept %u, clip pass %u, unfinished %u, left over %u\n", h.kept, h.n_todo, h.n_far, h.n_left);
         if (!info_host) return OFL_OK;
-        if (h.kept == 0) return fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
-        if (h.err) return fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
+        if (h.kept == 0) late_error = fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
+        else if (h.err) late_error = fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
                                               "neighbours, 2 = neighbour pool, 4 = large-triangle list, 8 = unfinished stars beyond the "
                                               "triangle-id space, 16 = degenerate point set: thousands of coincident points or hundreds of "
                                               "thousands of unbounded cells)", h.err, kFarCap);
@@ -1683,12 +1685,14 @@ int exact_scatter(const float *flow, int sign_pp, const uint8_t *pmask, const VT
 {
     DlWs ws;
     unsigned far_base = 0;
-    OFL_TRY(exact_prepare(flow, sign_pp, pmask, H, W, row0, rows, workspace, workspace_bytes, info_host, s, ws, far_base));
+    int late = OFL_OK;
+    OFL_TRY(exact_prepare(flow, sign_pp, pmask, H, W, row0, rows, workspace, workspace_bytes, info_host, s, ws, far_base, late));
+    // (the outputs are written even when the call reports no points / a refused point set: all zero, all invalid)
     const dim3 grid((W + 31) / 32, (rows + 7) / 8);
     hipLaunchKernelGGL(dl_resolve_kernel<VT>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
                        out, valid, valid_rule, ws, far_base);
     OFL_HIP(hipGetLastError());
-    return OFL_OK;
+    return late;
 }
 
 // arbitrary positions through the exact path (see walk_query_launch for the two layouts)
@@ -1698,8 +1702,9 @@ int exact_query(const float *flow, int sign_pp, const uint8_t *pmask, const floa
 {
     DlWs ws;
     unsigned far_base = 0;
-    OFL_TRY(exact_prepare(flow, sign_pp, pmask, H, W, 0, H, workspace, workspace_bytes, info_host, s, ws, far_base));
-    if (n == 0) return OFL_OK;
+    int late = OFL_OK;
+    OFL_TRY(exact_prepare(flow, sign_pp, pmask, H, W, 0, H, workspace, workspace_bytes, info_host, s, ws, far_base, late));
+    if (n == 0) return late;
     const size_t nb = (n + 255) / 256;
     const dim3 grid((unsigned)(nb < (1u << 20) ? nb : (1u << 20)));
     if (sparse)
@@ -1707,7 +1712,7 @@ int exact_query(const float *flow, int sign_pp, const uint8_t *pmask, const floa
     else
         hipLaunchKernelGGL(dl_query_kernel<false>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, query, n, out, valid, valid_rule, ws, far_base);
     OFL_HIP(hipGetLastError());
-    return OFL_OK;
+    return late;
 }
 
 template int exact_scatter<float>(const float *, int, const uint8_t *, const float *, int, const uint8_t *, int, int, int, int,

@@ -259,8 +259,8 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes);
  */
 typedef struct ofl_mesh_cert {
     uint32_t certified;        /* 1: cell-wise mesh == Delaunay triangulation of the warped points (up to co-circular cells) */
-    uint32_t folded_cells;     /* cells whose two triangles are not both positively oriented */
-    uint32_t bad_edges;        /* interior mesh edges failing the local Delaunay (in-circle) test beyond rounding */
+    uint32_t folded_cells;     /* cells whose two triangles are not both positively oriented (counted exactly up to ~65 000, a lower bound beyond) */
+    uint32_t bad_edges;        /* interior mesh edges failing the local Delaunay (in-circle) test beyond rounding (likewise) */
     uint32_t dropped;          /* 1: pmask drops points */
     double   border_dev;       /* px: largest distance of a border point from the straight side between its corners */
     double   corner[4][2];     /* warped image corners (x, y): (0,0), (W-1,0), (W-1,H-1), (0,H-1) */

@@ -608,9 +608,13 @@ void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__r
 // order, by the whole workgroup (vertex flags and the shift of the surviving vertices in parallel).
 //   wave pass (CAP 256, NT 64): fine buckets around the point, then rings of the COARSE grid of unfinished points with
 //     the security-radius test -- rims of holes, motion boundaries, anything whose cell spans tens of pixels;
-//   workgroup pass (CAP 2560, NT 256): what is left -- hull points (unbounded cells), rims of very large holes, fan
-//     apexes of border pockets -- against the same candidates plus ALL other points left (a Delaunay neighbour of a
-//     left-over point beyond the coarse rings is itself left over).
+//   left-over pass (CAP 512, NT 64; then CAP 2560, NT 256 for the few cells that overflow): what is left -- hull points
+//     (unbounded cells: the points of the image border come here directly), rims of very large holes, fan apexes of
+//     border pockets -- against the same candidates plus ALL other points left (a Delaunay neighbour of a left-over point
+//     beyond the coarse rings is itself left over).  A hull cell has half a dozen edges and most chunks of the sweep cut
+//     nothing: the pass waits -- on the chain of loads that finds the point and its seeds, on votes -- far more than it
+//     computes, so it runs as single waves, which puts three times as many points in flight per CU as workgroups of 256
+//     did (4K, axis-parallel border: 0.77 -> 0.50 ms; a rotated border, whose sliver cells keep more chunks: 1.2 -> 1.3).
 template <int CAP, int NT>
 struct FarLds {
     double vx[CAP], vy[CAP];
@@ -833,14 +837,15 @@ __device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, con
 template <int K, int CAP, int NT, class RelFn>
 __device__ void far_chunks(FarLds<CAP, NT> &L, int p, const P2 &pp, const int (&cand)[K], const P2 (&q)[K], RelFn rel)
 {
-    P2 C[K];
-    bool hit[K], any = false;
+    unsigned hits = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { hit[k] = far_test(L, p, pp, cand[k], q[k], rel, C[k]); any = any || hit[k]; }
-    if (!__syncthreads_or(any)) return;
+    for (int k = 0; k < K; ++k) { P2 C; if (far_test(L, p, pp, cand[k], q[k], rel, C)) hits |= 1u << k; }
+    if (!__syncthreads_or(hits != 0)) return;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (__syncthreads_or(hit[k])) far_commit(L, p, cand[k], C[k], hit[k], rel);
+    for (int k = 0; k < K; ++k) {
+        const bool hit = (hits >> k) & 1u;
+        if (__syncthreads_or(hit)) far_commit(L, p, cand[k], P2{ q[k].x - pp.x, q[k].y - pp.y }, hit, rel);
+    }
 }
 
 // The runs in L.run_lo / L.run_pre (lengths, turned into a prefix here) are walked as ONE dense list, NT candidates per
@@ -986,6 +991,13 @@ __device__ void mid_point(FarLds<kMidCap, 64> &L, unsigned &s_off, unsigned rank
     const int t = threadIdx.x;
     const int p = (int)far_idx[rank];
     if (deg[p] != kDegFar) return;                         // finished by the second per-thread pass
+    // Points of the image border are hull points more often than not: their cells never close, whatever this pass applies
+    // (it used to give them kMidRings rings, which the next pass then applied again).  They go straight to the left-over list.
+    const int py = (int)((unsigned)p / (unsigned)W), px = p - py * W;
+    if (px == 0 || py == 0 || px == W - 1 || py == H - 1) {
+        if (t == 0) { far_deg[rank] = kDegLeft; far_wide[rank] = 0; }
+        return;
+    }
     const Grid g = head->grid, g1 = head->grid1;
     const PosFn pos(flow, sign, W);
     const P2 pp = pos(p);
@@ -1001,12 +1013,9 @@ __device__ void mid_point(FarLds<kMidCap, 64> &L, unsigned &s_off, unsigned rank
     far_near_rows(L, p, pp, g, bstart, sorted, sorted_xy, rel);
     // Rings of the coarse grid until the cell is final: every unfinished point within twice its farthest vertex has been
     // applied -- points in unvisited coarse cells are at least r * s1 away (finished points farther than the fine rings
-    // cannot be neighbours: they would not have finished) -- or the rings have left the grid.  Points of the image border
-    // are hull points more often than not (their cells never close): they stop after kMidRings and go to the workgroup
-    // pass; the others -- rims of holes and tears, whose cells close once the far side has been applied -- go on.
-    const int py = (int)((unsigned)p / (unsigned)W), px = p - py * W;
-    const bool likely_hull = px == 0 || py == 0 || px == W - 1 || py == H - 1;
-    const int rmax = likely_hull ? kMidRings : kMidRingsMax;
+    // cannot be neighbours: they would not have finished) -- or the rings have left the grid (rims of holes and tears: their
+    // cells close once the far side has been applied).
+    const int rmax = kMidRingsMax;
     const int cbx = g1.bx(pp.x), cby = g1.by(pp.y);
     const int rgrid = max(max(cbx, g1.gx - 1 - cbx), max(cby, g1.gy - 1 - cby));
     bool done = false;
@@ -1052,8 +1061,8 @@ void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     }
 }
 
-template <int CAP>
-__device__ void far_point(FarLds<CAP, 256> &L, unsigned &s_off, unsigned li, unsigned n_left,
+template <int CAP, int NT>
+__device__ void far_point(FarLds<CAP, NT> &L, unsigned &s_off, unsigned li, unsigned n_left,
                           const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
@@ -1080,12 +1089,12 @@ __device__ void far_point(FarLds<CAP, 256> &L, unsigned &s_off, unsigned li, uns
     far_seeds(L, p, pp, nbr, pos, rel);
     far_near_rows(L, p, pp, g, bstart, sorted, sorted_xy, rel);
     far_coarse_annulus(L, p, pp, -1, kMidRings, g1, b1start, sorted1_pt, sorted1_xy, rel);
-    // Every other left-over point, 4 x 256 per step -- but only the chunks of 256 whose bounding box could hold a site
+    // Every other left-over point, kVote x NT per vote -- but only the chunks of 256 whose bounding box could hold a site
     // that cuts the cell AS IT STANDS NOW (later the cell only shrinks: its reach falls, its far vertices stay inside the
     // present cone and below the present largest distance, so what cannot cut now cannot cut later).  The test is
     // far_test's, applied to a box: nearer than the reach of the near vertices, or not excluded by the far cone.
     const unsigned n_chunks = (n_left + 255) / 256;
-    for (unsigned cbase = 0; cbase < n_chunks; cbase += 256) {
+    for (unsigned cbase = 0; cbase < n_chunks; cbase += NT) {
         __syncthreads();
         bool keep = false;
         const unsigned ck = cbase + t;
@@ -1121,23 +1130,25 @@ __device__ void far_point(FarLds<CAP, 256> &L, unsigned &s_off, unsigned li, uns
         if ((t & 63) == 0) L.hit[t >> 6] = bal;
         __syncthreads();
         unsigned before = 0, total = 0;
-        for (int w = 0; w < 4; ++w) { const unsigned c = (unsigned)__popcll(L.hit[w]); if (w < (t >> 6)) before += c; total += c; }
+        for (int w = 0; w < NT / 64; ++w) { const unsigned c = (unsigned)__popcll(L.hit[w]); if (w < (t >> 6)) before += c; total += c; }
         if (keep) L.clist[before + (unsigned)__popcll(bal & ((1ull << (t & 63)) - 1ull))] = ck;
         __syncthreads();
-        for (unsigned k0 = 0; k0 < total; k0 += 4) {
-            int cand[4];
-            P2  q[4];
-            unsigned cks[4];
+        constexpr int kVote = NT == 64 ? 2 : 4;            // steps under one vote
+        constexpr int kPer = 256 / NT;                     // steps of NT candidates per chunk of 256
+        for (unsigned k0 = 0; k0 < total * kPer; k0 += kVote) {
+            int cand[kVote];
+            P2  q[kVote];
+            unsigned cks[kVote];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cks[k] = k0 + k < total ? L.clist[k0 + k] : 0xFFFFFFFFu;
+            for (int k = 0; k < kVote; ++k) cks[k] = (k0 + k) / kPer < total ? L.clist[(k0 + k) / kPer] : 0xFFFFFFFFu;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned j = cks[k] * 256u + t;
+            for (int k = 0; k < kVote; ++k) {
+                const unsigned j = cks[k] * 256u + ((k0 + k) % kPer) * NT + t;
                 const bool in = cks[k] != 0xFFFFFFFFu && j < n_left;
                 cand[k] = in ? (int)left_pt[j] : -1;
                 q[k] = in ? left_xy[j] : pp;
             }
-            far_chunks<4>(L, p, pp, cand, q, rel);
+            far_chunks<kVote>(L, p, pp, cand, q, rel);
         }
     }
     __syncthreads();
@@ -1145,8 +1156,8 @@ __device__ void far_point(FarLds<CAP, 256> &L, unsigned &s_off, unsigned li, uns
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
 }
 
-template <int CAP>          // first with a small cell capacity (several workgroups per CU), then -- for the few fans that overflowed it -- the large one
-__global__ __launch_bounds__(256, CAP <= 512 ? 4 : 1)     // (small cells: room for four workgroups per CU -- the sweep waits on votes and loads)
+template <int CAP, int NT>          // first single waves with a small cell capacity, then -- for the few fans that overflowed it -- workgroups with the large one
+__global__ __launch_bounds__(NT)
 void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
@@ -1155,12 +1166,12 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
                         const unsigned *__restrict__ nbr, unsigned *__restrict__ far_deg, unsigned *__restrict__ far_off, int *__restrict__ pool,
                         unsigned long long pool_cap)
 {
-    __shared__ FarLds<CAP, 256> L;
+    __shared__ FarLds<CAP, NT> L;
     __shared__ unsigned s_off;
     const unsigned n_left = head->n_left;
     for (unsigned li = blockIdx.x; li < n_left; li += gridDim.x) {
         __syncthreads();
-        far_point<CAP>(L, s_off, li, n_left, flow, sign, H, W, head, bstart, sorted, sorted_xy, b1start, sorted1_pt, sorted1_xy, far_idx,
+        far_point<CAP, NT>(L, s_off, li, n_left, flow, sign, H, W, head, bstart, sorted, sorted_xy, b1start, sorted1_pt, sorted1_xy, far_idx,
                        left_idx, left_pt, left_xy, left_box, nbr, far_deg, far_off, pool, pool_cap);
     }
 }
@@ -1638,12 +1649,12 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
         hipLaunchKernelGGL(dl_left_box_kernel, dim3(rblk), dim3(256), 0, s, (const DlHead *)ws.head, W, (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, ws.left_box);
-        hipLaunchKernelGGL(dl_star_far_kernel<512>, dim3(walk), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+        hipLaunchKernelGGL((dl_star_far_kernel<512, 64>), dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
                            (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
                            ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
-        hipLaunchKernelGGL(dl_star_far_kernel<kFarCap>, dim3(std::min<unsigned>(walk, 2048u)), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
+        hipLaunchKernelGGL((dl_star_far_kernel<kFarCap, 256>), dim3(std::min<unsigned>(walk, 2048u)), dim3(256), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
                            (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,

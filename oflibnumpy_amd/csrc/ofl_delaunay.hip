@@ -1073,11 +1073,11 @@ __device__ void far_point(FarLds<CAP, NT> &L, unsigned &s_off, unsigned li, unsi
 {
     const int t = threadIdx.x;
     const unsigned rank = left_idx[li];
+    const int p = (int)left_pt[li];                      // (= far_idx[rank], and its position: one round trip instead of three)
+    const P2 pp = left_xy[li];
     if (far_deg[rank] != kDegLeft) return;               // finished by the pass with the smaller capacity
-    const int p = (int)far_idx[rank];
     const Grid g = head->grid, g1 = head->grid1;
     const PosFn pos(flow, sign, W);
-    const P2 pp = pos(p);
     auto rel = [&](int q) { const P2 v = pos(q); return P2{ v.x - pp.x, v.y - pp.y }; };
     if (t == 0) {
         Poly P{ L.vx, L.vy, L.tag, 1, CAP, 0 };

@@ -604,25 +604,27 @@ void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__r
 
 // ------------------------------------------------------------------------------------------------ stars, cooperative passes
 // One workgroup of NT threads per unfinished point.  The cell lives in LDS; candidates are tested NT at a time against
-// the current cell (one candidate per thread), and the few that cut it are applied one after the other, in candidate
-// order, by the whole workgroup (vertex flags and the shift of the surviving vertices in parallel).
+// the current cell (one candidate per thread), and the few that cut it are applied one after the other, nearest first,
+// by the whole workgroup (vertex flags and the shift of the surviving vertices in parallel).
 //   wave pass (CAP 256, NT 64): fine buckets around the point, then rings of the COARSE grid of unfinished points with
 //     the security-radius test -- rims of holes, motion boundaries, anything whose cell spans tens of pixels;
-//   left-over pass (CAP 512, NT 64; then CAP 2560, NT 256 for the few cells that overflow): what is left -- hull points
+//   left-over pass (CAP 384, NT 64; then CAP 2560, NT 256 for the few cells that overflow): what is left -- hull points
 //     (unbounded cells: the points of the image border come here directly), rims of very large holes, fan apexes of
 //     border pockets -- against the same candidates plus ALL other points left (a Delaunay neighbour of a left-over point
 //     beyond the coarse rings is itself left over).  A hull cell has half a dozen edges and most chunks of the sweep cut
 //     nothing: the pass waits -- on the chain of loads that finds the point and its seeds, on votes -- far more than it
-//     computes, so it runs as single waves, which puts three times as many points in flight per CU as workgroups of 256
-//     did (4K, axis-parallel border: 0.77 -> 0.50 ms; a rotated border, whose sliver cells keep more chunks: 1.2 -> 1.3).
+//     computes, so it runs as single waves, which puts four times as many points in flight per CU as workgroups of 256
+//     did (121 VGPRs, 9.4 KB of LDS: 16 per CU), and since a vote within one wave costs next to nothing, every step of 64
+//     candidates is tested against the cell as it stands (4K, axis-parallel border: 0.77 -> 0.38 ms; a rotated border:
+//     1.25 -> 1.17 ms).
 template <int CAP, int NT>
 struct FarLds {
     double vx[CAP], vy[CAP];
     int    tag[CAP];
     unsigned char cut[CAP];
-    int    cidx[NT];
+    int    cidx[1];            // the candidate being applied (far_chunks)
     unsigned clist[NT];        // chunk numbers the sweep of the workgroup pass keeps (of a group of NT chunks)
-    double ccx[NT], ccy[NT];
+    double ccx[1], ccy[1];
     unsigned long long hit[NT / 64];
     double wmax[NT / 64], wfar[NT / 64];
     unsigned run_lo[64];       // candidate runs of the current step (ranges of a sorted list) ...
@@ -673,7 +675,7 @@ __device__ void far_shift(FarLds<CAP, NT> &L, int s0, int s1, int d0)
 
 // reach, far list and far cone of the current cell; all threads, ends with a barrier
 template <int CAP, int NT>
-__device__ void far_refresh(FarLds<CAP, NT> &L)
+__device__ __noinline__ void far_refresh(FarLds<CAP, NT> &L)
 {
     const int t = threadIdx.x, n = L.n;
     const double t2 = L.t2;
@@ -792,60 +794,96 @@ __device__ __forceinline__ bool far_test(const FarLds<CAP, NT> &L, int p, const 
                 if (!inside && fmax(fmax(m0, m1), 0.0) + 1e-9 * (fabs(C.x) + fabs(C.y)) < d2 * L.kcone) some = false;
             }
             if (some && L.nfar < 0) { all = true; some = false; }
-            if (all) { for (int k = 0; k < n && !hit; ++k) hit = vertex_cut(P, k, n, C, cand, p, h, rel); }
-            else if (some) { const int nf = L.nfar; for (int i = 0; i < nf && !hit; ++i) hit = vertex_cut(P, L.farlist[i], n, C, cand, p, h, rel); }
+            // Every vertex, or the far list: four at a time.  The first look of vertex_cut -- is v . c - h beyond the margin,
+            // either way? -- needs a vertex and the two tags beside it; a loop that asks vertex_cut one vertex after the other
+            // (and stops at the first cut) is a chain of dependent LDS reads, 100+ cycles each, which is what the sweeps of
+            // these passes spent their time on.  Here the reads of four vertices are in flight together, the look is taken on
+            // all four, and only a vertex inside the margin goes through vertex_cut itself (same decision: its own first look).
+            const int cnt = all ? n : (some ? L.nfar : 0);
+            for (int i0 = 0; i0 < cnt && !hit; i0 += 4) {
+                int kk[4], ta[4], tb[4];
+                double x[4], y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[j] = i0 + j < cnt ? (all ? i0 + j : L.farlist[i0 + j]) : -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = kk[j] < 0 ? 0 : kk[j];
+                    ta[j] = L.tag[k == 0 ? n - 1 : k - 1]; tb[j] = L.tag[k]; x[j] = L.vx[k]; y[j] = L.vy[k];
+                }
+                unsigned unsure = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (kk[j] < 0 || cand == ta[j] || cand == tb[j]) continue;      // (the candidate already carries an edge at this vertex)
+                    const double tx = x[j] * C.x, ty = y[j] * C.y, d = tx + ty - h, m = kDecide * (fabs(tx) + fabs(ty) + h);
+                    if (d > m) hit = true;
+                    else if (!(d < -m)) unsure |= 1u << j;
+                }
+                if (!hit && unsure) {
+#pragma unroll 1
+                    for (int j = 0; j < 4 && !hit; ++j)
+                        if ((unsure >> j) & 1u) hit = vertex_cut(P, kk[j], n, C, cand, p, h, rel);
+                }
+            }
         }
     }
     return hit;
 }
 
-// the candidates of a chunk that cut the cell (per-thread flag `hit`; the workgroup knows there is at least one) are
-// applied one after the other, in thread order, by the whole workgroup
-template <int CAP, int NT, class RelFn>
-__device__ void far_commit(FarLds<CAP, NT> &L, int p, int cand, const P2 &C, bool hit, RelFn rel)
-{
-    const int t = threadIdx.x;
-    L.cidx[t] = cand; L.ccx[t] = C.x; L.ccy[t] = C.y;
-    const unsigned long long m = __ballot(hit);
-    if ((t & 63) == 0) L.hit[t >> 6] = m;
-    __syncthreads();
-    for (int w = 0; w < NT / 64; ++w) {
-        unsigned long long bits = L.hit[w];
-        while (bits) {
-            const int j = w * 64 + __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            far_apply(L, P2{ L.ccx[j], L.ccy[j] }, L.cidx[j], p, rel);
-        }
-    }
-    __syncthreads();
-}
-
-// one chunk of up to NT candidates (thread t holds candidate cand, or -1).  Most chunks cut nothing: they cost ONE barrier
-// (the vote), the cell is only touched -- and the workgroup only synchronises further -- when some candidate cuts it.
-template <int CAP, int NT, class RelFn>
-__device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const P2 &q, RelFn rel)
-{
-    P2 C;
-    const bool hit = far_test(L, p, pp, cand, q, rel, C);
-    if (!__syncthreads_or(hit)) return;                 // (every application below ends with a barrier: the cell is stable here)
-    far_commit(L, p, cand, C, hit, rel);
-}
-
-// K chunks under ONE vote (the long sweeps over the left-over points cut next to nothing).  A candidate that does not cut
-// the cell now cannot cut the smaller cell later, and far_apply re-tests what it is given, so the flags taken before the
-// vote stay valid while the chunks are committed in order.
+// K steps of up to NT candidates each (thread t holds candidates cand[0 .. K), or -1) under ONE vote per round.  Most steps
+// cut nothing: they cost one barrier (the vote); the cell is only touched -- and the workgroup only synchronises further --
+// when some candidate cuts it.  The candidates that do are applied NEAREST FIRST: they arrive in bucket or index order,
+// and applied in that order a row of sites that approaches the cell's site clips it once per site (stripes, folds, a wavy
+// image border: a step of 64 sites meant up to 64 cooperative clips of which the last few survive), whereas after the
+// nearest ones most of the others no longer cut anything, which far_apply finds out with one cooperative pass over the
+// vertices (a lane per vertex) and no clip.  A candidate that does not cut the cell now cannot cut the smaller cell
+// later, so the flags taken before the first vote stay valid.
 template <int K, int CAP, int NT, class RelFn>
 __device__ void far_chunks(FarLds<CAP, NT> &L, int p, const P2 &pp, const int (&cand)[K], const P2 (&q)[K], RelFn rel)
 {
-    unsigned hits = 0;
+    const int t = threadIdx.x;
+    unsigned pend = 0;                                     // bit k: candidate k of this lane cuts the cell as it stands now
+    double d2[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { P2 C; if (far_test(L, p, pp, cand[k], q[k], rel, C)) hits |= 1u << k; }
-    if (!__syncthreads_or(hits != 0)) return;
+    for (int k = 0; k < K; ++k) { P2 C; if (far_test(L, p, pp, cand[k], q[k], rel, C)) pend |= 1u << k; d2[k] = C.x * C.x + C.y * C.y; }
+    for (;;) {
+        double best = 1e300;
+        int bestk = -1;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const bool hit = (hits >> k) & 1u;
-        if (__syncthreads_or(hit)) far_commit(L, p, cand[k], P2{ q[k].x - pp.x, q[k].y - pp.y }, hit, rel);
+        for (int k = 0; k < K; ++k) if (((pend >> k) & 1u) && d2[k] < best) { best = d2[k]; bestk = k; }
+        if (!__syncthreads_or(bestk >= 0)) return;         // (every application below ends with a barrier: the cell is stable here)
+        // the nearest cutting candidate of the workgroup: lowest lane of the wave minimum, lowest wave of equal minima
+        double wmin = best;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            wmin = fmin(wmin, __hiloint2double(__shfl_xor(__double2hiint(wmin), off), __shfl_xor(__double2loint(wmin), off)));
+        const unsigned long long eq = __ballot(bestk >= 0 && best == wmin);
+        const int lead = (t & ~63) + (eq ? __ffsll((long long)eq) - 1 : 0);
+        bool mine = t == lead && eq != 0;
+        if (NT > 64) {
+            if (mine) L.wmax[t >> 6] = wmin;
+            if ((t & 63) == 0 && eq == 0) L.wmax[t >> 6] = 1e300;
+            __syncthreads();
+            int wbest = 0;
+            for (int w = 1; w < NT / 64; ++w) if (L.wmax[w] < L.wmax[wbest]) wbest = w;
+            mine = mine && (t >> 6) == wbest;
+        }
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (k == bestk) { L.cidx[0] = cand[k]; L.ccx[0] = q[k].x - pp.x; L.ccy[0] = q[k].y - pp.y; }
+            pend &= ~(1u << bestk);
+        }
+        __syncthreads();
+        far_apply(L, P2{ L.ccx[0], L.ccy[0] }, L.cidx[0], p, rel);
     }
+}
+
+template <int CAP, int NT, class RelFn>
+__device__ void far_chunk(FarLds<CAP, NT> &L, int p, const P2 &pp, int cand, const P2 &q, RelFn rel)
+{
+    const int c1[1] = { cand };
+    const P2  q1[1] = { q };
+    far_chunks<1>(L, p, pp, c1, q1, rel);
 }
 
 // The runs in L.run_lo / L.run_pre (lengths, turned into a prefix here) are walked as ONE dense list, NT candidates per
@@ -1043,7 +1081,7 @@ __device__ void mid_point(FarLds<kMidCap, 64> &L, unsigned &s_off, unsigned rank
 }
 
 // one wave per unfinished point; the grid is fixed and walks the ranks (their number stays on the device)
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, 4)                        // (the pass waits on loads and votes: four waves per SIMD)
 void dl_star_mid_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
@@ -1133,7 +1171,7 @@ __device__ void far_point(FarLds<CAP, NT> &L, unsigned &s_off, unsigned li, unsi
         for (int w = 0; w < NT / 64; ++w) { const unsigned c = (unsigned)__popcll(L.hit[w]); if (w < (t >> 6)) before += c; total += c; }
         if (keep) L.clist[before + (unsigned)__popcll(bal & ((1ull << (t & 63)) - 1ull))] = ck;
         __syncthreads();
-        constexpr int kVote = NT == 64 ? 2 : 4;            // steps under one vote
+        constexpr int kVote = NT == 64 ? 1 : 4;            // steps under one vote (a wave's own vote is cheap)
         constexpr int kPer = 256 / NT;                     // steps of NT candidates per chunk of 256
         for (unsigned k0 = 0; k0 < total * kPer; k0 += kVote) {
             int cand[kVote];
@@ -1649,7 +1687,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
         hipLaunchKernelGGL(dl_left_box_kernel, dim3(rblk), dim3(256), 0, s, (const DlHead *)ws.head, W, (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, ws.left_box);
-        hipLaunchKernelGGL((dl_star_far_kernel<512, 64>), dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
+        hipLaunchKernelGGL((dl_star_far_kernel<384, 64>), dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
                            (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,

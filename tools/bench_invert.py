@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One operation in a loop for profiling: python tools/bench_invert.py [--op invert|switch|speckle|hole|stripes|object|config5] [--iters N]"""
+"""One operation in a loop for profiling: python tools/bench_invert.py [--op invert|switch|speckle|wobble|hole|stripes|object|config5] [--iters N]"""
 import argparse
 import os
 import sys
@@ -25,6 +25,13 @@ def main():
     elif args.op == "speckle":
         m = np.random.default_rng(0).random((h, w)) > 0.05
         d = dev.DeviceFlow.from_host(f.vecs, 's', m)
+    elif args.op == "wobble":                                # the speckle mask on a non-affine field: no co-circular cells
+        yy, xx = np.mgrid[:h, :w].astype(np.float32)
+        v = f.vecs.copy()
+        v[..., 0] += 3.0 * np.sin(2 * np.pi * xx / 97) * np.cos(2 * np.pi * yy / 131)
+        v[..., 1] += 3.0 * np.cos(2 * np.pi * xx / 97) * np.sin(2 * np.pi * yy / 131)
+        m = np.random.default_rng(0).random((h, w)) > 0.05
+        d = dev.DeviceFlow.from_host(v, 's', m)
     elif args.op == "hole":
         m = np.ones((h, w), bool)
         m[h // 4:h // 4 + h // 5, w // 4:w // 4 + w // 5] = False

@@ -107,6 +107,18 @@ def main():
     ds.stats()
     t = timed(lambda: ds.invert(), it)
     report("invert s->s, 5 % random invalid points incl. a corner (K3)", (h, w), 18, *t, note="points dropped (consider_mask): Delaunay path")
+    # the same with SURVEY 8(d)'s non-affine term on top: no cell of this mesh is co-circular (the similarity transforms and
+    # lattices above are, cell by cell -- every decision of theirs is a tie), and the certificate fails here and there
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    wob = f3.vecs.copy()
+    wob[..., 0] += 3.0 * np.sin(2 * np.pi * xx / 97) * np.cos(2 * np.pi * yy / 131)
+    wob[..., 1] += 3.0 * np.cos(2 * np.pi * xx / 97) * np.sin(2 * np.pi * yy / 131)
+    del yy, xx
+    dw = dev.DeviceFlow.from_host(wob, 's', spk)
+    dw.stats()
+    t = timed(lambda: dw.invert(), it)
+    report("invert s->s, the same mask on a non-affine field (3-px sinusoid) (K3)", (h, w), 18, *t, note="generic positions: Delaunay path")
+    del wob, dw
     hole = np.ones((h, w), bool)
     hole[500:900, 1000:1800] = False
     dh = dev.DeviceFlow.from_host(f3.vecs, 's', hole)

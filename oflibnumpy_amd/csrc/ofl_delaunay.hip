@@ -46,6 +46,7 @@ constexpr int      kNear2Open = 3;       // ... which gives up a cell that is st
 constexpr int      kMidCap   = 256;      // polygon capacity of the wave pass (unfinished points against the coarse grid of unfinished points)
 constexpr int      kMidRings = 8;        // rings of that coarse grid every unfinished point is given ...
 constexpr int      kMidRingsMax = 160;   // ... and the rings a BOUNDED cell may go on for (rims of large holes) before it is left to the workgroup pass
+constexpr double   kFarBuckets = 256.0;  // far threshold of the cooperative cells, in buckets (dl_params_kernel)
 constexpr int      kFarList  = 48;       // cell vertices beyond the data (unbounded directions, sliver fans of a straight border) tested one by one
 constexpr int      kMidScale = 8;        // ... whose cells are this many fine buckets wide
 constexpr int      kFarCap   = 2560;     // polygon capacity of the workgroup pass (LDS: 20 B per vertex)
@@ -232,9 +233,12 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
         }
         g.ox = x0; g.oy = y0; g.s = s; g.inv_s = 1.0 / s;
         g.gx = (int)(floor(bw / s) + 1.0); g.gy = (int)(floor(bh / s) + 1.0);
-        // beyond the data from any site in it (float32 flows of hundreds of pixels leave a straight border 1e-5 px rough:
-        // its sliver triangles have circumcentres 1e4 px out, which must count as far for the reach of the near ones to mean anything)
-        const double t = 1.5 * (bw + bh) + 8.0 * s;
+        // Cell vertices farther than this from their site count as FAR: they are excluded by the cone they lie in rather than by
+        // the reach of the near ones.  A straight border that float32 leaves 1e-5 px rough has sliver triangles with
+        // circumcentres 1e4 px out, a wavy one (3 px over 100 px) 400 - 4 000 px out: as near vertices their reach covers every
+        // candidate of the left-over sweep.  kFarBuckets point spacings (never more than the data's own extent) is where the
+        // rim of a hole -- whose cells do reach that far, in all directions -- still pays nothing for it.
+        const double t = fmin(kFarBuckets * s, 1.5 * (bw + bh) + 8.0 * s);
         head->far_t2 = t * t;
     } else head->far_t2 = 1.0;
     head->grid = g;

@@ -483,6 +483,36 @@ def test_exact_path_medium_field_against_scipy(gpu, oracle, near2_always):
     assert not (bad & ~amb).any(), (int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:4].tolist())
 
 
+def test_wavy_border_against_scipy(gpu, oracle):
+    """The benchmark's non-affine case at 480 x 640 (tools/bench_ops.py: a rotation and scaling plus SURVEY 8(d)'s 3-px
+    sinusoid, 5 % of the points dropped): the image border is a wavy line whose bays are bridged by sliver triangles with
+    circumcentres hundreds of pixels out -- the cells the far threshold, the far cone and the sweep over nine chunks of
+    left-over points are there for.  The whole result equals SciPy's outside non-unique simplices."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev
+    h, w = 480, 640
+    f = of.Flow.from_transforms([['rotation', w / 2, h / 2, -20], ['scaling', w / 3.84, h / 2.7, 0.9]], [h, w], 's')
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    vecs = f.vecs.copy()
+    vecs[..., 0] += 3.0 * np.sin(2 * np.pi * xx / 97) * np.cos(2 * np.pi * yy / 131)
+    vecs[..., 1] += 3.0 * np.cos(2 * np.pi * xx / 97) * np.sin(2 * np.pi * yy / 131)
+    rng = np.random.default_rng(5)
+    pm = rng.random((h, w)) > 0.05
+    vals = rng.random((h, w, 2), dtype=np.float32)
+    fb, dv, dpm = (dev.DeviceBuffer.from_host(a) for a in (vecs, vals, pm.astype(np.uint8)))
+    out, valid = dev.DeviceBuffer(h * w * 8), dev.DeviceBuffer(h * w)
+    info = dev.scatter_linear(fb, +1, dpm, dv, 2, None, h, w, None, out, valid, 0)
+    assert info[0] == int(pm.sum()) and info[2] > 1500                      # the border goes through the left-over pass
+    got, gv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+    want = O.scatter_griddata(vecs, np.concatenate([vals, np.ones((h, w, 1), np.float32)], -1), pm)
+    pts = np.stack([(xx + vecs[..., 0].astype(np.float64)).ravel(), (yy + vecs[..., 1].astype(np.float64)).ravel()], 1)[pm.ravel()]
+    amb, inside = nonunique_nodes(pts, (h, w))
+    assert amb.mean() < 0.02
+    np.testing.assert_array_equal(gv[~amb], (want[..., -1] == 1)[~amb])
+    bad = ~np.isclose(got, want[..., :2], rtol=RTOL, atol=ATOL).all(-1)
+    assert not (bad & ~amb).any(), (int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:4].tolist())
+
+
 def test_exact_path_random_fields_against_scipy(gpu, oracle, near2_always):
     """Seeded sweep on ragged shapes: smooth non-affine fields, folds, random point masks with holes, both signs, random
     image values -- the full result (values and validity of a random value mask) equals SciPy's outside non-unique

@@ -940,7 +940,7 @@ __device__ void far_near_rows(FarLds<CAP, NT> &L, int p, const P2 &pp, const Gri
 {
     const int t = threadIdx.x, bx = g.bx(pp.x), by = g.by(pp.y);
     __syncthreads();
-    if (t <= 2 * kRings) far_set_run(L, t, g, bstart, by - kRings + t, bx - kRings, bx + kRings);
+    if (t <= 2 * kRings) far_set_run(L, t, g, bstart, (t & 1) ? by - ((t + 1) >> 1) : by + (t >> 1), bx - kRings, bx + kRings);      // (rows from the point's own outwards)
     far_dense(L, p, pp, 2 * kRings + 1, rel, sorted, sorted_xy);
 }
 
@@ -959,7 +959,13 @@ __device__ void far_coarse_annulus(FarLds<CAP, NT> &L, int p, const P2 &pp, int 
         __syncthreads();
         if (t < cnt) {
             const int i = b0 + t;
-            if (i < nt) far_set_run(L, t, g1, b1start, by - rb + i, bx - rb, bx + rb);
+            if (ra < 0) {
+                // the whole square: rows from the point's own outwards, nearest first (from the top row down, the sites of a
+                // stretch of border arrive APPROACHING the nearest one, and each of them clips the cell)
+                const int k = i >> 1;
+                far_set_run(L, t, g1, b1start, (i & 1) ? by - k : by + k, bx - rb, bx + rb);
+            }
+            else if (i < nt) far_set_run(L, t, g1, b1start, by - rb + i, bx - rb, bx + rb);
             else if (i < 2 * nt) far_set_run(L, t, g1, b1start, by + ra + 1 + (i - nt), bx - rb, bx + rb);
             else {
                 const int m = i - 2 * nt, row = by - ra + (m >> 1);

@@ -287,10 +287,16 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
 // A cell that is still unbounded (an edge on the initial box) after `open_rings` rings is given up at once: hull points
 // and rims of holes do not close within the ring search, and the cooperative passes pick them up with the sites found
 // so far as seeds.
-template <class PolyX, class PosFn>
+// `rescue`: called once on a cell that is still unbounded after `open_rings` rings, it may clip the cell with sites of its
+// own choosing (the GPU pass: the site's grid neighbours -- across a tear of the mesh the neighbour on the other side is
+// the site that closes the cell, twenty pixels away where the ring search reaches seven); returns < 0 on overflow.
+struct NoRescue { template <class PolyX> DL_HD int operator()(PolyX &) const { return 0; } };
+
+template <class PolyX, class PosFn, class RescueFn = NoRescue>
 DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
                     PosFn pos, int rings, const P2 *sorted_xy = nullptr, int open_rings = 1 << 30,
-                    int *rings_done = nullptr)               // receives the last ring that was applied completely (-1: none)
+                    int *rings_done = nullptr,               // receives the last ring that was applied completely (-1: none)
+                    RescueFn rescue = RescueFn())
 {
     poly_init(P);
     const int bx = g.bx(pp.x), by = g.by(pp.y);
@@ -304,7 +310,8 @@ DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned
         if (r >= open_rings) {
             bool open = false;
             for (int k = 0; k < P.n; ++k) open = open || P.T(k) < 0;
-            if (open) return 0;
+            if (open) return rescue(P) < 0 ? -1 : 0;      // (closed by the rescue or not: the later passes, which look at the
+                                                          // sparse coarse grid before the dense fine rings, take it from here)
         }
     }
     return 0;

@@ -120,7 +120,24 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
         if (near_cap < 0) {
             PolyT<float> P{ fx.data(), fy.data(), tag.data(), 1, -near_cap, 0 };
             int rdone = -1;
-            const int rc = star_near(P, p, pos(p), g, bstart.data(), sorted.data(), pos, rings, (const P2 *)nullptr, 2, &rdone);
+            // as the GPU's clip pass: a cell still unbounded at the open-ring check is clipped with the site's grid neighbours
+            auto rescue = [&](PolyT<float> &Q) -> int {
+                if (W <= 0) return 0;
+                const P2 pp = pos(p);
+                auto rel = [&](int t) { const P2 v = pos(t); return P2{ v.x - pp.x, v.y - pp.y }; };
+                const int x = p % W, y = p / W;
+                for (int sl = 0; sl < 8; ++sl) {
+                    const int dx = (int)((0x901Au >> (2 * sl)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * sl)) & 3u) - 1;
+                    if (x + dx < 0 || x + dx >= W || y + dy < 0 || y + dy >= H) continue;
+                    const int q = p + dy * W + dx;
+                    if (!is_kept(q)) continue;
+                    const P2 C = rel(q);
+                    if (C.x == 0.0 && C.y == 0.0) continue;
+                    if (poly_clip(Q, C, q, p, rel) < 0) return -1;
+                }
+                return 0;
+            };
+            const int rc = star_near(P, p, pos(p), g, bstart.data(), sorted.data(), pos, rings, (const P2 *)nullptr, 2, &rdone, rescue);
             bool ok = rc == 1;
             for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
             if (ok) {

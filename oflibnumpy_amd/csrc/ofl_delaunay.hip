@@ -440,7 +440,7 @@ void dl_dedupe_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bs
 // One thread per point: a point whose eight grid neighbours are kept proposes the star of the cell-wise mesh and verifies
 // it against the sites under its circumcircles (ofl_dl::star_fan).  Verified stars are final; everything else is marked
 // for the clip pass.
-__global__ __launch_bounds__(kFanBlock)
+__global__ __launch_bounds__(kFanBlock, 5)                    // (five waves per SIMD: the pass waits on its candidate loads)
 void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
                         const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
                         const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy, const unsigned char *__restrict__ dup,

@@ -124,7 +124,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # launcher mode: nothing below this line has run, the GPU is untouched in this process
         from oflibnumpy_amd import sharding
-        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                            timeout=float(os.environ.get("OFL_SPAWN_TIMEOUT", "900"))))
     h, w = args.height, args.width
     global PATTERN, ANGLE
     PATTERN = args.pattern

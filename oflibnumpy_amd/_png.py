@@ -17,16 +17,22 @@ _CHANNELS = {0: 1, 2: 3, 4: 2, 6: 4}
 def _unfilter(raw, height, stride, bpp):
     # a real KITTI flow PNG is 1242 x 375 x 6 bytes, mostly Sub / Average / Paeth rows: the byte loop below takes
     # seconds on it, the library's host helper milliseconds
+    # (pure host code: no GPU involved; the Python loop is the same algorithm and serves when the library cannot be
+    # loaded at all -- not built, or libamdhip64 missing on a CPU-only box)
     try:
         from . import _native as nat
         lib = nat.load()
-        out = np.empty((height, stride), np.uint8)
-        buf = np.frombuffer(raw, np.uint8)
+    except (ImportError, OSError):
+        return _unfilter_py(raw, height, stride, bpp)
+    out = np.empty((height, stride), np.uint8)
+    buf = np.frombuffer(raw, np.uint8)
+    try:
         nat.check(lib.ofl_png_unfilter(buf.ctypes.data, buf.size, height, stride, bpp, out.ctypes.data))
-        return out
-    except ImportError:
-        pass
-    return _unfilter_py(raw, height, stride, bpp)
+    except nat.NativeError as e:
+        # corrupt data (unknown filter byte, truncated IDAT): the same exception type as the Python loop, so that the loaders
+        # report "could not be loaded" like the reference does when cv2.imread returns None (utils.py:437-439)
+        raise ValueError("PNG: {}".format(e)) from None
+    return out
 
 
 def _unfilter_py(raw, height, stride, bpp):

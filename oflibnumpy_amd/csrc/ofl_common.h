@@ -31,6 +31,20 @@ inline hipStream_t stream_of(void *s) { return s ? (hipStream_t)s : rt().stream;
         if (e__ != hipSuccess) return ofl::hip_fail(e__, #call);           \
     } while (0)
 
+// Tuning / test knobs read from the environment exist only in the EXPERIMENTS build (-DOFL_EXPERIMENTS, linked as
+// libofl_hip_exp.so by build_native.build_experiments() for tools/ and for the tests of the non-default routes);
+// the shipped library evaluates them to their defaults at compile time and never calls getenv.
+#ifdef OFL_EXPERIMENTS
+#include <stdlib.h>
+#define OFL_KNOB_INT(name, dflt)    (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define OFL_KNOB_DOUBLE(name, dflt) (getenv(name) ? atof(getenv(name)) : (dflt))
+#define OFL_KNOB_SET(name)          (getenv(name) != nullptr)
+#else
+#define OFL_KNOB_INT(name, dflt)    (dflt)
+#define OFL_KNOB_DOUBLE(name, dflt) (dflt)
+#define OFL_KNOB_SET(name)          (false)
+#endif
+
 #define OFL_TRY(call)                                                      \
     do {                                                                   \
         int rc__ = (call);                                                 \

@@ -1646,7 +1646,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     OFL_HIP(hipMemsetAsync(ws.nbr, 0, ws.bcap * 4, s));                 // bucket cursors
     const unsigned nblk = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 1024 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
-    static const double bucket_scale = getenv("OFL_DL_BUCKET") ? atof(getenv("OFL_DL_BUCKET")) : 1.0;      // development knob
+    static const double bucket_scale = OFL_KNOB_DOUBLE("OFL_DL_BUCKET", 1.0);      // development knob (experiments build only)
     hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W);
     OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
     hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup);
@@ -1699,11 +1699,12 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                            (const DlHead *)ws.head, 1, (const unsigned *)ws.b1start, ws.sorted1);
         hipLaunchKernelGGL(dl_list_xy_kernel<1>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
                            (const unsigned *)ws.sorted1, (const unsigned *)ws.far_idx, ws.sorted1_xy, ws.sorted1_pt);
-        const char *n2 = getenv("OFL_DL_NEAR2_MIN");               // test knob: 0 runs the per-thread pass on the smallest field
+        // (experiments build only) OFL_DL_NEAR2_MIN = 0 runs the per-thread pass on the smallest field: tests/test_gpu_scatter_exact.py
+        const unsigned near2_min = (unsigned)OFL_KNOB_INT("OFL_DL_NEAR2_MIN", (int)kNear2MinPoints);
         hipLaunchKernelGGL(dl_star_near2_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 8192u)), dim3(64), 0, s, flow, sign_pp, H, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
                            (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start, (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy,
-                           ws.deg, ws.nbr, ws.far_deg, ws.far_wide, n2 ? (unsigned)atoi(n2) : kNear2MinPoints);
+                           ws.deg, ws.nbr, ws.far_deg, ws.far_wide, near2_min);
         hipLaunchKernelGGL(dl_star_mid_kernel, dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned char *)ws.deg, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
@@ -1734,7 +1735,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     far_base_out = (unsigned)far_base;
     OFL_HIP(hipGetLastError());
-    static const bool debug = getenv("OFL_DL_DEBUG") != nullptr;                 // development aid
+    static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
     if (info_host || debug) {
         DlHead h;
         OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));

@@ -11,7 +11,6 @@
 // float results and the validity masks are bit-identical to the CPU restatement.
 #include "ofl_common.h"
 #include <type_traits>
-#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -150,8 +149,15 @@ struct C3Args {
     float th;
     int swz_group;         // one-shot kernel: workgroups per XCD-swizzle group (0 = natural order)
     int xpose_rows;        // transposed-gather kernel: source rows a streamed 128-px segment may cross on the direct path
-    int ablate;            // development knob (OFL_C3_ABLATE): 1 = skip the gather, 2 = skip the stores; 0 in production
+#ifdef OFL_EXPERIMENTS
+    int ablate;            // OFL_C3_ABLATE (experiments build only): 1 = skip the gather, 2 = skip the stores, ...
+#endif
 };
+#ifdef OFL_EXPERIMENTS
+#define OFL_ABLATE(a, bit) (((a).ablate & (bit)) != 0)
+#else
+#define OFL_ABLATE(a, bit) false
+#endif
 
 struct C3Stream {          // one lane's share of a tile row of the streamed field fb/mb
     float4   v[2];
@@ -228,13 +234,13 @@ __device__ __forceinline__ void c3_finish(const C3Args &a, size_t row, const int
 {
     // Mask bytes leave as DWORDS when the row length allows aligned ones: the lane pairs (2k, 2k + 1) own four consecutive
     // pixels, the even lane stores both lanes' bytes (sub-dword stores cost as much per instruction as 16-byte ones)
-    const bool quad = (a.W & 3) == 0 && !(a.ablate & 64);
+    const bool quad = (a.W & 3) == 0 && !OFL_ABLATE(a, 64);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int jj = 2 * g;
         const uint32_t mine = ((ok[jj] && bm[jj]) ? 1u : 0u) | ((ok[jj + 1] && bm[jj + 1]) ? 0x100u : 0u);
         const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1);
-        if (act[g] && !((a.ablate & 2) && su[2 * g] != 12345.0f)) {
+        if (act[g] && !(OFL_ABLATE(a, 2) && su[2 * g] != 12345.0f)) {
             const int j = 2 * g;
             const float4 o4 = make_float4(__fadd_rn(bu[j], su[j]), __fadd_rn(bv[j], sv[j]),
                                           __fadd_rn(bu[j + 1], su[j + 1]), __fadd_rn(bv[j + 1], sv[j + 1]));
@@ -289,7 +295,7 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
         outside = outside && (out_j || !act[j >> 1]);
     }
     if (H < 2) inside = false;
-    if (a.ablate & 1) outside = true;
+    if (OFL_ABLATE(a, 1)) outside = true;
 
     float su[kC3Px], sv[kC3Px];
     bool  ok[kC3Px];
@@ -310,13 +316,13 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
         for (int g = 0; g < 2; ++g)
             share = share && (!act[g] || (tp[2 * g].iy == tp[2 * g + 1].iy && (unsigned)(tp[2 * g + 1].ix - tp[2 * g].ix) <= 2u &&
                                           tp[2 * g].ix + 3 < W));
-        share = __all(share) && !(a.ablate & 32);
+        share = __all(share) && !OFL_ABLATE(a, 32);
 #pragma unroll
         for (int j = 0; j < kC3Px; ++j) {
             const size_t s0 = act[j >> 1] ? (size_t)tp[j].iy * W + tp[j].ix : 0;
             p0[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
             p1[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * (s0 + W));
-            if (a.ablate & 16) { m0[j] = 0x0101u; m1[j] = 0x0101u; continue; }       // TA-cost probe: no mask gathers
+            if (OFL_ABLATE(a, 16)) { m0[j] = 0x0101u; m1[j] = 0x0101u; continue; }       // TA-cost probe: no mask gathers
             if (share) {
                 if ((j & 1) == 0) {
                     m0[j] = reinterpret_cast<const U32u *>(ma + s0)->v;
@@ -371,6 +377,11 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
     c3_finish<STATS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
 }
 
+#ifndef OFL_C3_ONESHOT_WAVES
+#define OFL_C3_ONESHOT_WAVES 6       // waves per SIMD the register allocator is asked to leave room for
+#endif
+
+#ifdef OFL_EXPERIMENTS   // ---- non-default compose variants (OFL_C3_VARIANT = 0 / 2): measured, kept for A/B runs only
 // Persistent form: gridDim.x workgroups (a multiple of 8, sized to the chip's residency) walk the tile
 // list with stride gridDim.x.  The stream loads of the NEXT tile are issued before the gathers of the
 // current one are consumed, which takes the fb round trip out of every tile's dependency chain
@@ -429,9 +440,6 @@ void compose3_kernel(const C3Args a)
 
 // One workgroup per tile (no persistence, no prefetch): the hardware dispatcher keeps every wave slot
 // filled and the active tiles form a window that sweeps memory in order.
-#ifndef OFL_C3_ONESHOT_WAVES
-#define OFL_C3_ONESHOT_WAVES 6       // waves per SIMD the register allocator is asked to leave room for
-#endif
 template <int QUANT, bool STATS>
 __global__ __launch_bounds__(256, OFL_C3_ONESHOT_WAVES)
 void compose3_oneshot_kernel(const C3Args a)
@@ -450,7 +458,9 @@ void compose3_oneshot_kernel(const C3Args a)
     c3_tile<QUANT, STATS>(a, tile, in, st);
     if (STATS) c3_flush_stats(a, tile / a.tiles_per_field, st);
 }
+#endif  // OFL_EXPERIMENTS
 
+#ifdef OFL_EXPERIMENTS   // ---- LDS-staged compose variant (OFL_C3_VARIANT = 1)
 // ------------------------------------------------------------------------------------ K2, LDS-staged form
 // The direct form above fetches 36 B per output pixel through the texture path (two unaligned 16-byte
 // gathers + two 2-byte mask gathers) and its row-strip tiles lose L1 locality when the sampling grid is
@@ -488,6 +498,7 @@ __device__ __forceinline__ int wave_minmax(int v)
 #undef OFL_DPP_STEP
     return __builtin_amdgcn_readlane(v, 63);
 }
+#endif  // OFL_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------
 // K2, transposed-gather form (variant 3).  The streaming layout (a wave = 2 rows x 128 px) is what the stream loads
@@ -644,6 +655,7 @@ void compose3_xpose_kernel(const C3Args a)
     if (STATS) c3_flush_stats(a, tile / a.tiles_per_field, st);
 }
 
+#ifdef OFL_EXPERIMENTS
 template <int QUANT, bool STATS>
 __device__ __forceinline__ void c3_tile_lds(const C3Args &a, int tile, const C3Stream &in, C3Stat &st,
                                             float4 *lds, int *box_now, int *box_next)
@@ -670,7 +682,7 @@ __device__ __forceinline__ void c3_tile_lds(const C3Args &a, int tile, const C3S
     for (int j = 0; j < kC3Px; ++j) {
         tp[j] = c3_pos<QUANT>(xg[j >> 1] + (j & 1), y, bu[j], bv[j], sign);
         const bool out_j = tp[j].ix < -1 || tp[j].ix >= W || tp[j].iy < -1 || tp[j].iy >= H;
-        use[j] = act[j >> 1] && !out_j && !(a.ablate & 1);
+        use[j] = act[j >> 1] && !out_j && !OFL_ABLATE(a, 1);
         if (use[j]) {
             bx0 = min(bx0, max(tp[j].ix, 0));     bx1 = max(bx1, min(tp[j].ix + 1, W - 1));
             by0 = min(by0, max(tp[j].iy, 0));     by1 = max(by1, min(tp[j].iy + 1, H - 1));
@@ -690,7 +702,7 @@ __device__ __forceinline__ void c3_tile_lds(const C3Args &a, int tile, const C3S
     const bool any    = X1 >= X0 && Y1 >= Y0;
     const int  bw     = any ? ((X1 - X0 + 2) & ~1) : 0;                // even number of columns covering X0..X1
     const int  bh     = any ? (Y1 - Y0 + 1) : 0;
-    const bool staged = any && bw * bh <= kLdsCap && !(a.ablate & 4);
+    const bool staged = any && bw * bh <= kLdsCap && !OFL_ABLATE(a, 4);
 
     if (staged) {
         const int pairs = bw >> 1, total = pairs * bh;
@@ -710,7 +722,7 @@ __device__ __forceinline__ void c3_tile_lds(const C3Args &a, int tile, const C3S
 #pragma unroll
     for (int j = 0; j < kC3Px; ++j) { su[j] = 0.0f; sv[j] = 0.0f; ok[j] = false; }
 
-    if (staged && !(a.ablate & 8)) {
+    if (staged && !OFL_ABLATE(a, 8)) {
 #pragma unroll
         for (int j = 0; j < kC3Px; ++j) {
             if (!use[j]) continue;
@@ -798,6 +810,7 @@ void compose3_lds_kernel(const C3Args a)
     }
     if (STATS) c3_flush_stats(a, cur_b, st);
 }
+#endif  // OFL_EXPERIMENTS
 
 // Generic-shape fallback (any W >= 1, one pixel per thread, no vector accesses).
 template <int QUANT>
@@ -1313,8 +1326,8 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
     if (W % 2 == 0 && C >= 1 && C <= 4 && (unsigned long long)H * W * C * sizeof(T) < (1ull << 32) && (unsigned long long)fH * fW * 8 < (1ull << 32)) {
         const int tiles_x = (W + 127) / 128, tiles_y = (rows + 7) / 8;
         const int nblocks = tiles_x * tiles_y;
-        static const int swz = getenv("OFL_G2_SWZ") ? atoi(getenv("OFL_G2_SWZ")) : 0;          // tuning knob: 1 = XCD swizzle
-        static const int xpose_rows = getenv("OFL_G2_XPOSE_ROWS") ? atoi(getenv("OFL_G2_XPOSE_ROWS")) : kXposeRows;   // tuning knob
+        static const int swz = OFL_KNOB_INT("OFL_G2_SWZ", 0);                      // 1 = XCD swizzle (experiments build only)
+        static const int xpose_rows = OFL_KNOB_INT("OFL_G2_XPOSE_ROWS", kXposeRows);   // (experiments build only)
 #define OFL_GATHER2_LAUNCH(CT)                                                                           \
         hipLaunchKernelGGL((gather2_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, H, W, \
                            flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,   \
@@ -1347,6 +1360,7 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
     return OFL_OK;
 }
 
+#ifdef OFL_EXPERIMENTS
 // resident workgroups per CU of each compose3 instantiation (queried once per process)
 template <typename K>
 int c3_query_blocks(K kernel)
@@ -1377,6 +1391,7 @@ int c3_blocks_per_cu(int quant, bool with_stats, bool lds)
     }
     return v;
 }
+#endif  // OFL_EXPERIMENTS
 
 size_t dtype_size(int dtype)
 {
@@ -1426,31 +1441,36 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
     const float th = 1e-3f;   // DEFAULT_THRESHOLD, utils.py:22 (compared in float32)
 
     if (W % 2 == 0) {
-        static const int ablate = getenv("OFL_C3_ABLATE") ? atoi(getenv("OFL_C3_ABLATE")) : 0;
-        // -1 / 3 (default): one workgroup per tile in natural order -- the dispatcher keeps every wave slot filled
-        // and all XCDs sweep one window of memory (measured +2..7 % over the persistent kernel at 1..8 4K pairs
-        // per launch) -- with the gather transposed through LDS in workgroups whose sampling grid is rotated;
-        // 2 the same without the transposition; 0 persistent grid with stream prefetch; 1 source tile staged in LDS
-        static const int variant_env = getenv("OFL_C3_VARIANT") ? atoi(getenv("OFL_C3_VARIANT")) : -1;
-        int variant = variant_env;
-        const bool use_lds = variant == 1;
-        const int tw = use_lds ? 4 * kLdsLX : kC3TileW, thh = use_lds ? 256 / kLdsLX : kC3TileH;
-        const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + thh - 1) / thh;
-        const long long nt = (long long)tiles_x * tiles_y * batch;
+        // One workgroup per 128 x 8 tile in natural order -- the dispatcher keeps every wave slot filled and all XCDs sweep
+        // one window of memory (measured +2..7 % over a persistent grid at 1..8 4K pairs per launch) -- with the gather
+        // transposed through LDS in workgroups whose sampling grid is rotated.
+        int tiles_x = (W + kC3TileW - 1) / kC3TileW, tiles_y = (H + kC3TileH - 1) / kC3TileH;
+        long long nt = (long long)tiles_x * tiles_y * batch;
         if (nt > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
-        static const int swz = getenv("OFL_C3_SWZ") ? atoi(getenv("OFL_C3_SWZ")) : 0;             // tuning knob (0 = natural order: measured best)
-        static const int xpose_rows = getenv("OFL_C3_XPOSE_ROWS") ? atoi(getenv("OFL_C3_XPOSE_ROWS")) : kXposeRows;   // tuning knob
+        static const int xpose_rows = OFL_KNOB_INT("OFL_C3_XPOSE_ROWS", kXposeRows);
+#ifdef OFL_EXPERIMENTS
+        // A/B variants: OFL_C3_VARIANT = 2 the same without the transposition, 0 persistent grid with stream prefetch,
+        // 1 source tile staged in LDS; OFL_C3_ABLATE switches parts of the kernel off, OFL_C3_SWZ tries XCD-aware tile orders
+        static const int ablate = OFL_KNOB_INT("OFL_C3_ABLATE", 0);
+        static const int variant = OFL_KNOB_INT("OFL_C3_VARIANT", 3);
+        static const int swz = OFL_KNOB_INT("OFL_C3_SWZ", 0);
+        const bool use_lds = variant == 1;
+        if (use_lds) {
+            tiles_x = (W + 4 * kLdsLX - 1) / (4 * kLdsLX); tiles_y = (H + 256 / kLdsLX - 1) / (256 / kLdsLX);
+            nt = (long long)tiles_x * tiles_y * batch;
+        }
         C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, swz, xpose_rows, ablate };
-        // persistent grid: what the chip keeps resident (a multiple of 8 = one share per XCD), or one
-        // workgroup per tile when the problem is smaller than that
-        int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr, use_lds);
-        if (variant < 0) variant = 3;
+        int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr, use_lds);      // persistent variants: what the chip keeps resident
         if (grid > (int)nt) grid = (int)nt;
         if (grid >= 8) grid &= ~7;
 #define OFL_C3(Q, S) do { if (use_lds) hipLaunchKernelGGL((compose3_lds_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
                           else if (variant == 2) hipLaunchKernelGGL((compose3_oneshot_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); \
-                          else if (variant == 3) hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); \
-                          else hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); } while (0)
+                          else if (variant == 0) hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
+                          else hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); } while (0)
+#else
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, 0, xpose_rows };
+#define OFL_C3(Q, S) hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a)
+#endif
         if (quant == OFL_QUANT_OPENCV) { if (stats) OFL_C3(OFL_QUANT_OPENCV, true); else OFL_C3(OFL_QUANT_OPENCV, false); }
         else                           { if (stats) OFL_C3(OFL_QUANT_EXACT, true);  else OFL_C3(OFL_QUANT_EXACT, false); }
 #undef OFL_C3

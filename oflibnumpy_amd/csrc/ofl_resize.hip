@@ -231,7 +231,7 @@ int ofl_resize_flow_dev(const float *vecs, const uint8_t *mask, int H, int W, in
     if ((mask == nullptr) != (mout == nullptr)) return fail(OFL_E_INVALID, "ofl_resize_flow: mask and mout go together");
     const unsigned gy = (unsigned)((Ho + 3) / 4), gx = (unsigned)((Wo + 127) / 128);
     if (gy > 65535u) return fail(OFL_E_INVALID, "ofl_resize_flow: output too tall");
-    static const bool no4 = getenv("OFL_RS_NO4") != nullptr;         // development knob (A/B)
+    static const bool no4 = OFL_KNOB_SET("OFL_RS_NO4");              // development knob (A/B; experiments build only)
     if (!no4 && scale_x <= 1.0 && (Wo & 3) == 0 && W >= 6) {
         if (scale_x == 0.5)
             hipLaunchKernelGGL(resize_flow4_kernel<true>, dim3((unsigned)((Wo + 255) / 256), gy), dim3(64, 4), 0, stream_of(stream),

@@ -238,8 +238,7 @@ int stream_grid(size_t n_items)
     if (nb < 1) nb = 1;
     // One workgroup per 256 items, no persistent cap: on MI355X a copy that is dispatched as one workgroup per
     // chunk streams at 6.0-6.3 TB/s, the same loop on a resident-sized grid at 5.1-5.3 (tools/copy_sweep.hip).
-    const char *env = getenv("OFL_STREAM_GRID_CAP");          // tuning knob: workgroups per CU, 0 = uncapped
-    const size_t per_cu = env ? (size_t)atoi(env) : 0;
+    const size_t per_cu = (size_t)OFL_KNOB_INT("OFL_STREAM_GRID_CAP", 0);      // workgroups per CU, 0 = uncapped (experiments build only)
     const size_t cap = per_cu ? (size_t)rt().n_cu * per_cu : (size_t)0x7fffffff;
     return (int)(nb < cap ? nb : cap);
 }

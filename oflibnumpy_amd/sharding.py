@@ -54,14 +54,19 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(script, argv, world, timeout=None, env=None):
+def spawn_ranks(script, argv, world, timeout=900.0, env=None, grace=10.0):
     """Self-launch: run `script argv` once per rank as FRESH child processes (subprocess, never os.exec*) with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them, relay rank 0's
     stdout to ours and return the worst child exit code.  The caller must not have touched the GPU: the parent stays a
-    plain launcher.  Ranks > 0 write their stdout to our stderr (the contract is ONE JSON line on stdout)."""
+    plain launcher.  Ranks > 0 write their stdout to our stderr (the contract is ONE JSON line on stdout).
+
+    Every child is polled: the first rank that exits with an error takes the others down after `grace` seconds (a rank
+    that died at start-up would otherwise leave its peers in the rendezvous until torch's own timeout, tens of minutes),
+    and `timeout` seconds bound the whole launch (exit code 124, as timeout(1))."""
     import os
     import subprocess
     import sys
+    import threading
     import time
     if world < 1:
         raise ValueError("world must be >= 1")
@@ -74,24 +79,33 @@ def spawn_ranks(script, argv, world, timeout=None, env=None):
         e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world))
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
                                       stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # drains rank 0's pipe
+    reader.start()
     deadline = None if timeout is None else time.monotonic() + timeout
-    out0 = b""
-    try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for p in procs[1:]:
-            p.wait(timeout=None if deadline is None else max(1.0, deadline - time.monotonic()))
-    except subprocess.TimeoutExpired:
+    first_bad, bad_since, timed_out = 0, None, False
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
         for p in procs:
-            if p.poll() is None:
-                p.kill()
-        for p in procs:
-            p.wait()
-        sys.stdout.write(out0.decode("utf-8", "replace") if out0 else "")
-        sys.stdout.flush()
-        return 124
-    sys.stdout.write(out0.decode("utf-8", "replace"))
+            rc = p.poll()
+            if rc not in (None, 0) and first_bad == 0:
+                first_bad, bad_since = (rc if rc > 0 else 128 - rc), now
+        if deadline is not None and now > deadline:
+            timed_out = True
+        if timed_out or (bad_since is not None and now - bad_since > grace):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    reader.join(5.0)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode("utf-8", "replace"))
     sys.stdout.flush()
-    worst = 0
+    if timed_out:
+        return 124
+    worst = first_bad
     for p in procs:
         rc = p.returncode
         if rc != 0 and worst == 0:

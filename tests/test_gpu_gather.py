@@ -529,9 +529,10 @@ def test_combine_flows_batch_api(gpu, oracle):
 
 
 def test_lds_staged_variant_in_subprocess(gpu):
-    """The opt-in compose kernel variants (OFL_C3_VARIANT, read once per process) produce the same bits
-    as the oracle: small and large footprints (the latter exceed the LDS budget and take the in-kernel
-    direct path), both references, odd tile remainders."""
+    """The A/B compose kernel variants of the EXPERIMENTS build (libofl_hip_exp.so, OFL_C3_VARIANT read once per process;
+    the shipped library holds only the default kernel and reads no environment) produce the same bits as the oracle:
+    small and large footprints (the latter exceed the LDS budget and take the in-kernel direct path), both references,
+    odd tile remainders."""
     import os
     import subprocess
     import sys
@@ -555,8 +556,11 @@ print("lds-variant-ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # variant 1 = source tile staged in LDS, 2 = one-shot without the transposed gather, 0 = persistent grid;
     # the default (3, transposed gather for rotated sampling grids) is what every other test runs
+    from oflibnumpy_amd import build_native
+    if not os.path.exists(build_native.EXP_OUT):
+        build_native.build_experiments()
     for variant in ("1", "2", "0"):
-        env = dict(os.environ, OFL_C3_VARIANT=variant)
+        env = dict(os.environ, OFL_C3_VARIANT=variant, OFL_LIB=build_native.EXP_OUT)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0 and "lds-variant-ok" in p.stdout, (variant, p.stderr[-2000:])
 

@@ -183,6 +183,7 @@ def test_invert_and_switch_ref_analytic(gpu):
                       (f_t.switch_ref(), f_s), (f_s.switch_ref(), f_t)):
         assert got.ref == want.ref
         assert got.mask.sum() > 100000
+        print("invert / switch_ref vs analytic: max abs error", float(np.abs(got.vecs[got.mask] - want.vecs[got.mask]).max()))
         np.testing.assert_allclose(got.vecs[got.mask], want.vecs[got.mask], rtol=1e-3, atol=1e-3)
     np.testing.assert_array_equal(of.invert_flow(f_s.vecs, 's'), f_s.invert().vecs)
     np.testing.assert_array_equal(of.switch_flow_ref(f_t.vecs, 't'), f_t.switch_ref().vecs)
@@ -222,7 +223,7 @@ def test_combine_modes_vs_oracle(gpu, oracle, ref):
         # or not by Qhull's handling of the sliver facets there; everything else is exact
         assert diff.sum() <= (1 if (mode, ref) == (2, 't') else 0), (mode, ref, int(diff.sum()))
         assert both.sum() > 0.5 * want.mask.sum()
-        np.testing.assert_allclose(got.vecs[both], want.vecs[both], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(got.vecs[both], want.vecs[both], rtol=RTOL, atol=ATOL)      # every node; stage by stage: test_gpu_chains.py
 
 
 @pytest.mark.parametrize("ref", ['s', 't'])
@@ -285,10 +286,12 @@ def test_scatter_4k_invert(gpu):
     inv = f.invert()
     want = of.Flow.from_transforms([['scaling', 1000, 800, 1 / 0.9]], shape, 's')
     assert inv.mask.mean() > 0.75
+    print("4K invert vs analytic: max abs error", float(np.abs(inv.vecs[inv.mask] - want.vecs[inv.mask]).max()))
     np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-4, atol=2e-3)
     # round trip: inverting twice returns the original inside the doubly valid area
     back = inv.invert()
     m = back.mask
+    print("4K invert round trip: max abs error", float(np.abs(back.vecs[m] - f.vecs[m]).max()))
     np.testing.assert_allclose(back.vecs[m], f.vecs[m], rtol=1e-4, atol=2e-3)
 
 
@@ -474,6 +477,7 @@ def test_strong_magnification_all_triangles_large(gpu):
     inv = f.invert()
     want = of.Flow.from_transforms([['scaling', 550, 550, 1 / 40.0]], s, 's')
     assert inv.mask.mean() > 0.99
+    print("40x magnification vs analytic: max abs error", float(np.abs(inv.vecs[inv.mask] - want.vecs[inv.mask]).max()))
     np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-3, atol=1e-3)
     assert f.valid_target().mean() > 0.99
 
@@ -684,29 +688,27 @@ def test_integer_targets_valid_area_s(gpu, oracle):
     fm = rng.random(shape) > 0.08
     f, o = of.Flow(vecs, 's', fm), O.OFlow(vecs, 's', fm)
     tm = np.ones(shape, bool)
-    tm[10:22, 15:40] = False            # a solid invalid region: which triangle covers a node only matters along its outline
-    from scipy import ndimage
-    edge = ndimage.binary_dilation(~tm, iterations=3) & ndimage.binary_dilation(tm, iterations=3)
+    tm[10:22, 15:40] = False            # a solid invalid region: its outline is where the rounded rule and the float rule differ
+    # nodes in simplices SciPy itself cannot pin (none on this non-affine field unless the speckle leaves co-circular sites):
+    # everything else is compared exactly -- no band around the outline, no tolerance on counts
+    amb_kept, amb_all = ambiguous_for(vecs, fm), ambiguous_for(vecs)
+    print("non-unique nodes: {} with the speckled point set, {} with every point".format(int(amb_kept.sum()), int(amb_all.sum())))
     for dt in (np.uint8, np.int16):
         img = (rng.random(shape + (3,)) * 200).astype(dt)
         for tmask in (None, tm):
             got, valid = f.apply(img, tmask, return_valid_area=True)
             want, wvalid = o.apply(img, tmask, return_valid_area=True)
-            sel = np.ones(shape, bool)
-            if tmask is not None:           # the outline of the region lands ~2 px away under this flow: leave a generous band out
-                sel = ~ndimage.binary_dilation(edge, iterations=4)
-            np.testing.assert_array_equal(valid[sel], wvalid[sel], err_msg=str((dt, tmask is None)))
-        # the rounding rule really is looser than the float rule along the outline -- and the kernel follows it
-        v_int = f.apply(img, tm, return_valid_area=True)[1]
+            np.testing.assert_array_equal(valid[~amb_kept], wvalid[~amb_kept], err_msg=str((dt, tmask is None)))
+            d = np.abs(got.astype(int) - want.astype(int)).max(-1)[~amb_kept & wvalid]
+            assert (d <= 1).all() and (d > 0).mean() < 1e-3, (dt, tmask is None)       # a value within 1e-6 of x.5 may round the other way
+        # the rounding rule really is looser than the float rule along the outline -- and the kernel follows it node for node
         w_int = o.apply(img, tm, return_valid_area=True)[1]
         w_flt = o.apply(img.astype(np.float32), tm, return_valid_area=True)[1]
         assert w_int.sum() > w_flt.sum() + 20
-        assert abs(int(v_int.sum()) - int(w_int.sum())) < 0.25 * (w_int.sum() - w_flt.sum())
         # values with all points kept
         got, valid = of.Flow(vecs, 's').apply(img, tm, return_valid_area=True)
         want, wvalid = O.OFlow(vecs, 's').apply(img, tm, return_valid_area=True)
-        sel = ~ndimage.binary_dilation(edge, iterations=4)
-        np.testing.assert_array_equal(valid[sel], wvalid[sel])
-        inner = of.Flow(vecs, 's').valid_target()
+        np.testing.assert_array_equal(valid[~amb_all], wvalid[~amb_all])
+        inner = of.Flow(vecs, 's').valid_target() & ~amb_all
         d = np.abs(got.astype(int) - want.astype(int)).max(-1)
-        assert (d[inner] <= 1).all() and (d[inner] > 0).mean() < 0.02
+        assert (d[inner] <= 1).all() and (d[inner] > 0).mean() < 1e-3

@@ -10,6 +10,7 @@ bit-exact, values within 1e-4 relative wherever the Delaunay triangulation is un
 squares of translations / axis-aligned scalings -- are the only exemption: Qhull itself is arbitrary there).
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -37,13 +38,32 @@ def wobble(shape, ax=0.5, ay=0.4):
     return np.stack([ax * np.sin(xx / 9) * np.cos(yy / 7), ay * np.cos(xx / 8) * np.sin(yy / 6)], -1).astype(np.float32)
 
 
-@pytest.fixture(params=["default", "near2"])
-def near2_always(request, monkeypatch):
-    """The second per-thread star pass only runs for fields with tens of thousands of unfinished points; "near2" makes it
-    run on the small fixtures as well (OFL_DL_NEAR2_MIN=0), so both routes through the star passes are compared."""
-    if request.param == "near2":
-        monkeypatch.setenv("OFL_DL_NEAR2_MIN", "0")
-    return request.param
+@pytest.fixture
+def near2_always():
+    """Marks the tests that cross the star passes.  The second per-thread pass only runs for fields with tens of thousands of
+    unfinished points; test_near2_route_on_the_experiments_build re-runs exactly these tests in a child process on the
+    experiments build (libofl_hip_exp.so) with OFL_DL_NEAR2_MIN=0, which sends the small fixtures through that pass as
+    well -- the shipped library has no such knob."""
+    return "near2" if os.environ.get("OFL_DL_NEAR2_MIN") == "0" else "default"
+
+
+def test_near2_route_on_the_experiments_build(gpu):
+    """Both routes through the star passes give the same results: the near2-marked tests of this file, once more, in a
+    child process that loads the experiments build with the per-thread pass forced on (see near2_always)."""
+    import subprocess
+    import sys
+    if os.environ.get("OFL_DL_NEAR2_MIN") == "0":
+        pytest.skip("this IS the child run")
+    from oflibnumpy_amd import build_native
+    if not os.path.exists(build_native.EXP_OUT):
+        build_native.build_experiments()
+    env = dict(os.environ, OFL_LIB=build_native.EXP_OUT, OFL_DL_NEAR2_MIN="0")
+    here = os.path.abspath(__file__)
+    p = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "reference_outputs or bands_and_determinism or notch_open or medium_field or random_fields"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    tail = p.stdout[-1500:] + p.stderr[-1500:]
+    assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, tail
 
 
 def test_certificates(gpu):

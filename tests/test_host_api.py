@@ -31,6 +31,20 @@ def test_abi_exports_every_declared_symbol():
     assert nat.load().ofl_abi_version() == 1
 
 
+def test_shipped_library_is_lean():
+    """The product library reads no environment knobs and carries none of the A/B kernel variants (they live in the
+    experiments build, libofl_hip_exp.so, which tools/ and two subprocess tests load through OFL_LIB)."""
+    import subprocess
+    from oflibnumpy_amd import build_native
+    assert os.path.basename(nat.LIB_PATH) == "libofl_hip.so" or os.environ.get("OFL_LIB")
+    und = subprocess.run(["nm", "-D", "--undefined-only", build_native.OUT], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    blob = open(build_native.OUT, "rb").read()
+    for name in (b"compose3_lds_kernel", b"compose3_oneshot_kernel", b"OFL_C3_VARIANT", b"OFL_C3_ABLATE", b"OFL_DL_NEAR2_MIN"):
+        assert name not in blob, name
+    assert b"compose3_xpose_kernel" in blob
+
+
 def test_no_cpu_fallback_without_device():
     if nat.device_count() > 0:
         pytest.skip("a GPU is present")
@@ -384,3 +398,15 @@ def test_png_reader_all_filter_types_native_equals_python(tmp_path):
                            chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
     np.testing.assert_array_equal(_png.read_png(path), img.astype(np.uint16))
     np.testing.assert_array_equal(_png._unfilter(bytes(raw), h, stride, bpp), _png._unfilter_py(bytes(raw), h, stride, bpp))
+    # corrupt files fail like they do in the reference (cv2.imread returns None -> ValueError "could not be loaded"),
+    # through the native helper and through the Python loop alike: an unknown filter byte, a truncated IDAT
+    bad = bytearray(raw)
+    bad[0] = 7
+    for data, what in ((bytes(bad), "filter byte 7"), (bytes(raw[:len(raw) // 2]), "truncated")):
+        p2 = str(tmp_path / "bad.png")
+        open(p2, 'wb').write(_png._SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) +
+                             chunk(b"IDAT", zlib.compress(data)) + chunk(b"IEND", b""))
+        with pytest.raises(ValueError, match="could not be loaded"):
+            of.load_kitti(p2)
+        with pytest.raises((ValueError, IndexError)):
+            _png._unfilter_py(data, h, stride, bpp)

@@ -118,6 +118,35 @@ def test_self_spawn_relays_rank0_and_worst_exit_code(tmp_path):
         assert d == {"rank": 0, "world": 2, "max_rank": 1.0, "argv": ["2", str(want_rc)]}
 
 
+STUCK = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, {root!r})
+    if "WORLD_SIZE" not in os.environ:
+        from oflibnumpy_amd import sharding
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], 2, timeout=float(sys.argv[2]), grace=1.0))
+    rank = int(os.environ["RANK"])
+    if sys.argv[1] == "dies" and rank == 1:
+        sys.exit(7)                     # a rank that fails at start-up (bad device, import error)
+    print("rank0 waits", flush=True)
+    time.sleep(600)                     # its peer sits in the rendezvous / a barrier
+""")
+
+
+def test_self_spawn_does_not_hang_on_a_dead_or_stuck_rank(tmp_path):
+    """A rank that dies at start-up takes the launch down with ITS exit code within the grace period, and a launch whose
+    ranks never finish ends with 124 at the timeout -- the driver's `python bench.py --gpus N` cannot hang forever."""
+    import time
+    script = tmp_path / "stuck.py"
+    script.write_text(STUCK.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for mode, limit, want in (("dies", "300", 7), ("stuck", "3", 124)):
+        t0 = time.monotonic()
+        p = subprocess.run([sys.executable, str(script), mode, limit], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == want, (mode, p.returncode, p.stderr[-1000:])
+        assert time.monotonic() - t0 < 60, mode
+        assert "rank0 waits" in p.stdout           # what rank 0 printed before it was stopped is still relayed
+
+
 def test_bench_launcher_mode_is_reached_before_the_engine_loads():
     """bench.py / tools/bench_bands.py with --gpus N > 1 and no WORLD_SIZE must hand over to spawn_ranks before
     loading the native library / selecting a device (the parent never touches the GPU)."""

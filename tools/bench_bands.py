@@ -31,7 +31,7 @@ def main():
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # launcher mode: spawn the ranks before touching the GPU
         from oflibnumpy_amd import sharding
-        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=900.0))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))

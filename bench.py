@@ -28,7 +28,7 @@ import numpy as np
 H, W = 2160, 3840
 BYTES_PER_PX = 27            # 2 x (8 + 1) read + (8 + 1) written
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
-TRAFFIC_FILES = ("profiles/r02_compose3_traffic.json", "profiles/r01_compose3_traffic.json")
+TRAFFIC_FILES = ("profiles/r03_compose3_traffic.json", "profiles/r02_compose3_traffic.json", "profiles/r01_compose3_traffic.json")
 
 
 PATTERN = "scale"
@@ -340,12 +340,20 @@ def main():
             line["roofline"]["other_patterns"] = secondary
         for rel in TRAFFIC_FILES:
             tpath = os.path.join(ROOT, rel)
-            if os.path.exists(tpath) and (h, w) == (H, W) and PATTERN == "scale":
-                # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-                # correction + WRITE_SIZE), scaled from the profiled batch to this run's batch -- not measured in this run
-                line["roofline"]["traffic"] = round(json.load(open(tpath))["hbm_bytes_per_field"] * B)
-                line["roofline"]["traffic_source"] = rel
-                break
+            if os.path.exists(tpath) and (h, w) == (H, W):
+                # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS sampling pattern (FETCH_SIZE doubled
+                # per the gfx950 correction + WRITE_SIZE; tools/prof_bench.sh), scaled from the profiled batch to this run's
+                # batch -- a profiler cannot run inside the timed region, so it is not measured in this run
+                tj = json.load(open(tpath))
+                per_field = tj.get("patterns", {}).get(PATTERN, {}).get("hbm_bytes_per_field") or (tj.get("hbm_bytes_per_field") if PATTERN == "scale" else None)
+                if per_field:
+                    line["roofline"]["traffic"] = round(per_field * B)
+                    line["roofline"]["traffic_source"] = rel
+                    for name in secondary:
+                        pf = tj.get("patterns", {}).get(name, {}).get("hbm_bytes_per_field")
+                        if pf:
+                            secondary[name]["traffic"] = round(pf * B)
+                    break
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(h, w, ref)
         print(json.dumps(line), flush=True)

@@ -479,22 +479,35 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
 }
 
 // ------------------------------------------------------------------------------------------------ stars, clip pass (near)
+// One thread per point the fans did not settle, scheduled BY BUCKET TILE, not by point index: a wave takes the unsettled
+// sites of a kNearTile x kNearTile block of buckets, so its 64 ring searches read the same few hundred candidates (L1 / L2
+// hits instead of one HBM round trip per candidate run).  In index order the sites of a wave are neighbours in the SOURCE
+// grid -- on a folded field (BASELINE config 5: u = x * y) their warped positions lie hundreds of buckets apart, and the
+// pass moved 32 x the case's algorithmic bytes waiting for them (round 2: 12.5 of config 5's 24 ms).  A star does not
+// depend on the order in which stars are built, so the schedule changes nothing else; it also needs no compacted list:
+// every wave finds its sites itself (the bucket runs of its tile, filtered by deg == kDegTodo).
+constexpr int kNearTile = 8;
+
 __global__ __launch_bounds__(64)
 void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, const unsigned char *__restrict__ dup, int H, int W,
-                         const DlHead *__restrict__ head, const unsigned *__restrict__ todo,
-                         const unsigned *__restrict__ bstart,
+                         DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
                          const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
-                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
+                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr, int count_todo)
 {
     __shared__ float s_vx[kNearCap][64], s_vy[kNearCap][64];
     __shared__ int   s_tag[kNearCap][64];
-    const unsigned n_todo = head->n_todo;
+    __shared__ unsigned s_queue[128];
+    if (head->err & kErrDegenerate) return;                 // a refused point set: no star pass runs (ring loops are sized for ordinary buckets)
     const Grid g = head->grid;
     const PosFn pos(flow, sign, W);
-    for (unsigned base = blockIdx.x * 64; base < n_todo; base += gridDim.x * 64) {
-        if (base + threadIdx.x >= n_todo) return;
-        const size_t p = todo[base + threadIdx.x];
-        PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
+    const int lane = threadIdx.x;
+    const int tiles_x = (g.gx + kNearTile - 1) / kNearTile, tiles_y = (g.gy + kNearTile - 1) / kNearTile;
+    const long long n_tiles = (long long)tiles_x * tiles_y;
+    const unsigned per = gridDim.x >> 3;                    // (grid = a multiple of 8) one contiguous run of tiles per XCD and sweep
+    unsigned n_done = 0;
+
+    auto one_site = [&](size_t p) {
+        PolyT<float> P{ &s_vx[0][lane], &s_vy[0][lane], &s_tag[0][lane], 64, kNearCap, 0 };
         int rings_done;
         const P2 pp = pos((int)p);
         // A cell that is still unbounded after kOpenRings rings is clipped with the site's GRID neighbours before it is given
@@ -527,11 +540,53 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
             for (int k = 0; k < P.n; ++k) nbr[p * kSlots + 2 + k] = (unsigned)P.T(k);
             nbr[p * kSlots + 1] = (unsigned)P.n;
             nbr[p * kSlots + 14] = (unsigned)rings_done;
-            continue;
+            return;
         }
         deg[p] = (unsigned char)P.n;
         for (int k = 0; k < P.n; ++k) nbr[p * kSlots + k] = (unsigned)P.T(k);
+    };
+
+    for (long long t0 = 0; t0 < n_tiles; t0 += gridDim.x) {
+        const long long tile = t0 + (long long)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (tile >= n_tiles) continue;
+        const int ty = (int)(tile / tiles_x), tx = (int)(tile - (long long)ty * tiles_x);
+        const int x0 = tx * kNearTile, x1 = min(x0 + kNearTile, g.gx);
+        const int rows_here = min(kNearTile, g.gy - ty * kNearTile);
+        int nq = 0, r = -1;                                  // sites waiting in the queue; the bucket row being read (all wave-uniform)
+        unsigned j0 = 0, hi = 0;
+        while (true) {
+            // fill the queue from the tile's bucket runs until a full wave of sites waits (or the tile is exhausted) ...
+            while (nq < 64) {
+                if (j0 >= hi) {
+                    if (++r >= rows_here) break;
+                    const size_t b0 = (size_t)(ty * kNearTile + r) * g.gx;
+                    j0 = bstart[b0 + x0]; hi = bstart[b0 + x1];
+                    continue;
+                }
+                const unsigned j = j0 + lane;
+                unsigned c = 0xFFFFFFFFu;
+                if (j < hi) c = sorted[j];
+                const bool want = c != 0xFFFFFFFFu && deg[c] == kDegTodo;
+                const unsigned long long m = __ballot(want);
+                if (want) s_queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                nq += __popcll(m);
+                j0 += 64;
+            }
+            if (nq == 0) break;
+            // ... and build the stars of up to 64 of them (ONE call site: the clip code is large)
+            const int take = min(nq, 64);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned p = s_queue[lane];
+            const unsigned spill = s_queue[lane + 64];
+            __builtin_amdgcn_wave_barrier();
+            s_queue[lane] = spill;
+            __builtin_amdgcn_wave_barrier();
+            nq -= take;
+            n_done += take;
+            if (lane < take) one_site(p);
+        }
     }
+    if (count_todo && lane == 0 && n_done) atomicAdd(&head->n_todo, n_done);      // (debug builds print it; nothing reads it otherwise)
 }
 
 // ------------------------------------------------------------------------------------------------ stars, second per-thread pass
@@ -1665,14 +1720,11 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     hipLaunchKernelGGL(dl_star_fan_kernel, dim3((unsigned)(((n + kFanBlock - 1) / kFanBlock + 7) / 8 * 8)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                        (const unsigned char *)ws.dup, ws.deg, ws.nbr);
-    // what the fans did not settle, in index order, for the clip pass
-    hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
-    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
-                       ws.todo_idx, fblk - 1, (unsigned *)nullptr);
-    hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
-                       (const DlHead *)ws.head, (const unsigned *)ws.todo_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
-                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr);
+    // what the fans did not settle: the clip pass, scheduled by bucket tile (every wave collects its own sites)
+    static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
+    hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n / 48 + 8) / 8 * 8), 65536u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
+                       ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
+                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr, debug ? 1 : 0);
     OFL_HIP(hipGetLastError());
     // unfinished points in index order
     hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
@@ -1735,7 +1787,6 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     far_base_out = (unsigned)far_base;
     OFL_HIP(hipGetLastError());
-    static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
     if (info_host || debug) {
         DlHead h;
         OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));

@@ -184,7 +184,8 @@ def test_invert_and_switch_ref_analytic(gpu):
         assert got.ref == want.ref
         assert got.mask.sum() > 100000
         print("invert / switch_ref vs analytic: max abs error", float(np.abs(got.vecs[got.mask] - want.vecs[got.mask]).max()))
-        np.testing.assert_allclose(got.vecs[got.mask], want.vecs[got.mask], rtol=1e-3, atol=1e-3)
+        # (the reference's own bar is 1e-3, tests/test_flow_class.py:528-572; measured: 1.5e-5 = one float32 ulp of a 180-px vector)
+        np.testing.assert_allclose(got.vecs[got.mask], want.vecs[got.mask], rtol=1e-4, atol=1e-4)
     np.testing.assert_array_equal(of.invert_flow(f_s.vecs, 's'), f_s.invert().vecs)
     np.testing.assert_array_equal(of.switch_flow_ref(f_t.vecs, 't'), f_t.switch_ref().vecs)
 
@@ -287,12 +288,12 @@ def test_scatter_4k_invert(gpu):
     want = of.Flow.from_transforms([['scaling', 1000, 800, 1 / 0.9]], shape, 's')
     assert inv.mask.mean() > 0.75
     print("4K invert vs analytic: max abs error", float(np.abs(inv.vecs[inv.mask] - want.vecs[inv.mask]).max()))
-    np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-4, atol=2e-4)      # measured 3e-5: one ulp of a 400-px vector
     # round trip: inverting twice returns the original inside the doubly valid area
     back = inv.invert()
     m = back.mask
     print("4K invert round trip: max abs error", float(np.abs(back.vecs[m] - f.vecs[m]).max()))
-    np.testing.assert_allclose(back.vecs[m], f.vecs[m], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(back.vecs[m], f.vecs[m], rtol=1e-4, atol=2e-4)
 
 
 def test_track_pts_matches_reference(gpu, golden):
@@ -478,7 +479,7 @@ def test_strong_magnification_all_triangles_large(gpu):
     want = of.Flow.from_transforms([['scaling', 550, 550, 1 / 40.0]], s, 's')
     assert inv.mask.mean() > 0.99
     print("40x magnification vs analytic: max abs error", float(np.abs(inv.vecs[inv.mask] - want.vecs[inv.mask]).max()))
-    np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(inv.vecs[inv.mask], want.vecs[inv.mask], rtol=1e-4, atol=1e-4)      # measured: exact
     assert f.valid_target().mean() > 0.99
 
 

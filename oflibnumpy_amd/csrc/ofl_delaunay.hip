@@ -56,6 +56,7 @@ constexpr unsigned kNoOwner  = 0xFFFFFFFFu;
 constexpr int      kSmallArea = 1024;
 constexpr unsigned char kDegFar = 0xFF;
 constexpr unsigned char kDegTodo = 0xFE;  // not settled by the mesh-fan pass: the clip pass builds this star
+constexpr unsigned char kDegFan = 0xFD;   // not settled by the mesh-cell pass: the fan pass looks at this site
 constexpr int      kFanSpan  = 6;        // buckets per axis a fan's circumcircles may span (wider: clip pass)
 constexpr int      kFanBlock = 128;
 constexpr unsigned kMaxBucket = 4096;     // sites one bucket may hold (coincident / collinear points in bulk: the point set is degenerate)
@@ -69,8 +70,8 @@ struct DlHead {                           // device header of the exact path (25
     Grid     grid, grid1;                    // fine buckets (all kept points), coarse buckets (unfinished points)
     unsigned kept, n_far, n_left, pool_used, err;    // err bit 0: far polygon overflow, bit 1: pool overflow, bit 2: big list overflow, bit 3: triangle-id space
     unsigned long long big_n;
-    unsigned n_todo;                                 // points the mesh-fan pass left to the clip pass
-    unsigned pad0;
+    unsigned n_todo;                                 // points the mesh-fan pass left to the clip pass (counted in debug runs only)
+    unsigned n_fan;                                  // points the mesh-cell pass left to the fan pass
     double   far_t2;                                 // squared distance beyond which a cell vertex counts as "far" (well outside the data)
     unsigned pad[12];
 };
@@ -82,7 +83,8 @@ struct DlWs {
     unsigned *scan_tmp;    // block sums of the scan levels
     unsigned *sorted;      // [N] point indices bucket by bucket
     unsigned char *deg;    // [N] 0 .. 16, kDegTodo, kDegFar
-    unsigned *todo_idx;    // [N] points for the clip pass, ascending
+    unsigned *todo_idx;    // [N] points for the fan pass (what the cell pass did not settle), ascending
+    unsigned char *cellflag; // [N] per grid cell (x, y): 0 = not verified, 1 / 2 = both triangles Delaunay, diagonal a - c / b - d (ofl_dl::cell_verify)
     unsigned char *dup;    // [N] 1 = an exact duplicate of a site with a smaller index (not a site of the triangulation)
     unsigned *nbr;         // [N][kSlots]   (doubles as the bucket cursors while sorting)
     unsigned *far_idx;     // [N]
@@ -436,78 +438,120 @@ void dl_dedupe_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bs
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stars, mesh-cell pass
+// One thread per grid cell: both triangles of an intact, convex, positively oriented cell are verified ONCE against the
+// sites under their circumcircles (ofl_dl::cell_verify) instead of three times from their three vertices; then one thread
+// per site reads the flags of its four cells -- all verified: the star is written without touching a candidate.
+__global__ __launch_bounds__(256)
+void dl_cell_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                    const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
+                    const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy, const unsigned char *__restrict__ dup,
+                    unsigned char *__restrict__ cellflag, int tiles_x, int ntiles)
+{
+    const unsigned per = gridDim.x >> 3;                        // (grid padded to a multiple of 8) one contiguous eighth per XCD
+    const int tile = (int)((blockIdx.x & 7u) * per + (blockIdx.x >> 3));
+    if (tile >= ntiles) return;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x = tx * 32 + (threadIdx.x & 31), y = ty * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const size_t ia = (size_t)y * W + x;
+    int flag = 0;
+    if (x < W - 1 && y < H - 1 && !(head->err & kErrDegenerate) &&
+        kept_pt(pmask, ia) && kept_pt(pmask, ia + 1) && kept_pt(pmask, ia + W) && kept_pt(pmask, ia + W + 1) &&
+        !(dup[ia] | dup[ia + 1] | dup[ia + W] | dup[ia + W + 1])) {
+        const D2 a = point_of(flow, sign, W, x, y), b = point_of(flow, sign, W, x + 1, y);
+        const D2 c = point_of(flow, sign, W, x + 1, y + 1), d = point_of(flow, sign, W, x, y + 1);
+        flag = cell_verify((int)ia, W, P2{ a.x, a.y }, P2{ b.x, b.y }, P2{ c.x, c.y }, P2{ d.x, d.y }, head->grid, bstart, sorted, sorted_xy,
+                           PosFn(flow, sign, W), kFanSpan);
+    }
+    cellflag[ia] = (unsigned char)flag;
+}
+
+__global__ __launch_bounds__(256)
+void dl_site_cells_kernel(const uint8_t *__restrict__ pmask, int H, int W, const DlHead *__restrict__ head,
+                          const unsigned char *__restrict__ dup, const unsigned char *__restrict__ cellflag,
+                          unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (size_t)H * W) return;
+    if (!kept_pt(pmask, p) || dup[p]) { deg[p] = 0; return; }
+    if (head->err & kErrDegenerate) { deg[p] = kDegTodo; return; }           // (no star pass runs on a refused point set)
+    const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
+    int n = 0;
+    if (x > 0 && y > 0 && x < W - 1 && y < H - 1) {
+        unsigned out[8];
+        n = star_from_cells((int)p, W, cellflag[p], cellflag[p - 1], cellflag[p - W - 1], cellflag[p - W], out);
+        if (n > 0) {
+            uint4 *row = reinterpret_cast<uint4 *>(nbr + p * kSlots);
+            row[0] = make_uint4(out[0], out[1], out[2], out[3]);
+            row[1] = make_uint4(out[4], n > 5 ? out[5] : 0u, n > 6 ? out[6] : 0u, n > 7 ? out[7] : 0u);
+        }
+    }
+    deg[p] = n > 0 ? (unsigned char)n : kDegFan;
+}
+
 // ------------------------------------------------------------------------------------------------ stars, mesh-fan pass
 // One thread per point: a point whose eight grid neighbours are kept proposes the star of the cell-wise mesh and verifies
 // it against the sites under its circumcircles (ofl_dl::star_fan).  Verified stars are final; everything else is marked
 // for the clip pass.
 __global__ __launch_bounds__(kFanBlock, 5)                    // (five waves per SIMD: the pass waits on its candidate loads)
 void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
-                        const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
+                        const DlHead *__restrict__ head, const unsigned *__restrict__ todo, const unsigned *__restrict__ bstart,
                         const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy, const unsigned char *__restrict__ dup,
                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
     __shared__ P2 s_rel[8][kFanBlock];
-    const unsigned per = gridDim.x >> 3;                        // (grid padded to a multiple of 8) one contiguous eighth per XCD
-    const size_t p = (size_t)((blockIdx.x & 7u) * per + (blockIdx.x >> 3)) * kFanBlock + threadIdx.x;
-    if (p >= (size_t)H * W) return;
-    if (!kept_pt(pmask, p) || dup[p]) { deg[p] = 0; return; }
-    if (head->err & kErrDegenerate) { deg[p] = kDegTodo; return; }           // (the clip pass then sees n_todo = 0)
-    const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
-    // which of the eight grid neighbours exist: inside the grid, kept by the point mask, not a dropped duplicate
-    unsigned kept8 = 0;
+    const unsigned n_fan = head->n_fan;                         // the sites the cell pass did not settle, in index order
+    for (unsigned i = blockIdx.x * kFanBlock + threadIdx.x; i < n_fan; i += gridDim.x * kFanBlock) {
+        const size_t p = todo[i];
+        const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
+        // which of the eight grid neighbours exist: inside the grid, kept by the point mask, not a dropped duplicate
+        unsigned kept8 = 0;
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-        const int dx = (int)((0x901Au >> (2 * sl)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * sl)) & 3u) - 1;
-        const bool in = (unsigned)(x + dx) < (unsigned)W && (unsigned)(y + dy) < (unsigned)H;
-        const size_t q = in ? (size_t)((long long)p + dx + (long long)dy * W) : p;
-        if (in && kept_pt(pmask, q) && !dup[q]) kept8 |= 1u << sl;
-    }
-    int n = 0;
-    {
-        const Grid g = head->grid;
-        const PosFn pos(flow, sign, W);
-        auto npos = [&](int sl) {                               // slot -> grid offset at compile time (the loops over slots are unrolled)
+        for (int sl = 0; sl < 8; ++sl) {
             const int dx = (int)((0x901Au >> (2 * sl)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * sl)) & 3u) - 1;
-            const D2 q = point_of(flow, sign, W, x + dx, y + dy);
-            return P2{ q.x, q.y };
-        };
-        const D2 c = point_of(flow, sign, W, x, y);
-        n = star_fan((int)p, W, P2{ c.x, c.y }, kept8, pos, npos, g, bstart, sorted, sorted_xy, kFanSpan, &s_rel[0][threadIdx.x], kFanBlock,
-                     nbr + p * kSlots);
+            const bool in = (unsigned)(x + dx) < (unsigned)W && (unsigned)(y + dy) < (unsigned)H;
+            const size_t q = in ? (size_t)((long long)p + dx + (long long)dy * W) : p;
+            if (in && kept_pt(pmask, q) && !dup[q]) kept8 |= 1u << sl;
+        }
+        int n = 0;
+        {
+            const Grid g = head->grid;
+            const PosFn pos(flow, sign, W);
+            auto npos = [&](int sl) {                               // slot -> grid offset at compile time (the loops over slots are unrolled)
+                const int dx = (int)((0x901Au >> (2 * sl)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * sl)) & 3u) - 1;
+                const D2 q = point_of(flow, sign, W, x + dx, y + dy);
+                return P2{ q.x, q.y };
+            };
+            const D2 c = point_of(flow, sign, W, x, y);
+            n = star_fan((int)p, W, P2{ c.x, c.y }, kept8, pos, npos, g, bstart, sorted, sorted_xy, kFanSpan, &s_rel[0][threadIdx.x], kFanBlock,
+                         nbr + p * kSlots);
+        }
+        deg[p] = n > 0 ? (unsigned char)n : kDegTodo;
     }
-    deg[p] = n > 0 ? (unsigned char)n : kDegTodo;
 }
 
 // ------------------------------------------------------------------------------------------------ stars, clip pass (near)
-// One thread per point the fans did not settle, scheduled BY BUCKET TILE, not by point index: a wave takes the unsettled
-// sites of a kNearTile x kNearTile block of buckets, so its 64 ring searches read the same few hundred candidates (L1 / L2
-// hits instead of one HBM round trip per candidate run).  In index order the sites of a wave are neighbours in the SOURCE
-// grid -- on a folded field (BASELINE config 5: u = x * y) their warped positions lie hundreds of buckets apart, and the
-// pass moved 32 x the case's algorithmic bytes waiting for them (round 2: 12.5 of config 5's 24 ms).  A star does not
-// depend on the order in which stars are built, so the schedule changes nothing else; it also needs no compacted list:
-// every wave finds its sites itself (the bucket runs of its tile, filtered by deg == kDegTodo).
-constexpr int kNearTile = 8;
-
+// One thread per point the cells and fans did not settle.  The list is compacted in BUCKET order (the order of `sorted`), not
+// in index order: 64 consecutive entries are neighbours in the plane, whatever the field does -- on a folded field (BASELINE
+// config 5) the sites of one source row lie hundreds of buckets apart -- so the ring searches of a wave read the same
+// candidates.  A star does not depend on the order in which stars are built.
 __global__ __launch_bounds__(64)
 void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, const unsigned char *__restrict__ dup, int H, int W,
-                         DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
+                         const DlHead *__restrict__ head, const unsigned *__restrict__ todo,
+                         const unsigned *__restrict__ bstart,
                          const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
-                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr, int count_todo)
+                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
     __shared__ float s_vx[kNearCap][64], s_vy[kNearCap][64];
     __shared__ int   s_tag[kNearCap][64];
-    __shared__ unsigned s_queue[128];
-    if (head->err & kErrDegenerate) return;                 // a refused point set: no star pass runs (ring loops are sized for ordinary buckets)
+    const unsigned n_todo = head->n_todo;
     const Grid g = head->grid;
     const PosFn pos(flow, sign, W);
-    const int lane = threadIdx.x;
-    const int tiles_x = (g.gx + kNearTile - 1) / kNearTile, tiles_y = (g.gy + kNearTile - 1) / kNearTile;
-    const long long n_tiles = (long long)tiles_x * tiles_y;
-    const unsigned per = gridDim.x >> 3;                    // (grid = a multiple of 8) one contiguous run of tiles per XCD and sweep
-    unsigned n_done = 0;
-
-    auto one_site = [&](size_t p) {
-        PolyT<float> P{ &s_vx[0][lane], &s_vy[0][lane], &s_tag[0][lane], 64, kNearCap, 0 };
+    for (unsigned base = blockIdx.x * 64; base < n_todo; base += gridDim.x * 64) {
+        if (base + threadIdx.x >= n_todo) return;
+        const size_t p = todo[base + threadIdx.x];
+        PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
         int rings_done;
         const P2 pp = pos((int)p);
         // A cell that is still unbounded after kOpenRings rings is clipped with the site's GRID neighbours before it is given
@@ -540,53 +584,11 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
             for (int k = 0; k < P.n; ++k) nbr[p * kSlots + 2 + k] = (unsigned)P.T(k);
             nbr[p * kSlots + 1] = (unsigned)P.n;
             nbr[p * kSlots + 14] = (unsigned)rings_done;
-            return;
+            continue;
         }
         deg[p] = (unsigned char)P.n;
         for (int k = 0; k < P.n; ++k) nbr[p * kSlots + k] = (unsigned)P.T(k);
-    };
-
-    for (long long t0 = 0; t0 < n_tiles; t0 += gridDim.x) {
-        const long long tile = t0 + (long long)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-        if (tile >= n_tiles) continue;
-        const int ty = (int)(tile / tiles_x), tx = (int)(tile - (long long)ty * tiles_x);
-        const int x0 = tx * kNearTile, x1 = min(x0 + kNearTile, g.gx);
-        const int rows_here = min(kNearTile, g.gy - ty * kNearTile);
-        int nq = 0, r = -1;                                  // sites waiting in the queue; the bucket row being read (all wave-uniform)
-        unsigned j0 = 0, hi = 0;
-        while (true) {
-            // fill the queue from the tile's bucket runs until a full wave of sites waits (or the tile is exhausted) ...
-            while (nq < 64) {
-                if (j0 >= hi) {
-                    if (++r >= rows_here) break;
-                    const size_t b0 = (size_t)(ty * kNearTile + r) * g.gx;
-                    j0 = bstart[b0 + x0]; hi = bstart[b0 + x1];
-                    continue;
-                }
-                const unsigned j = j0 + lane;
-                unsigned c = 0xFFFFFFFFu;
-                if (j < hi) c = sorted[j];
-                const bool want = c != 0xFFFFFFFFu && deg[c] == kDegTodo;
-                const unsigned long long m = __ballot(want);
-                if (want) s_queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = c;
-                nq += __popcll(m);
-                j0 += 64;
-            }
-            if (nq == 0) break;
-            // ... and build the stars of up to 64 of them (ONE call site: the clip code is large)
-            const int take = min(nq, 64);
-            __builtin_amdgcn_wave_barrier();
-            const unsigned p = s_queue[lane];
-            const unsigned spill = s_queue[lane + 64];
-            __builtin_amdgcn_wave_barrier();
-            s_queue[lane] = spill;
-            __builtin_amdgcn_wave_barrier();
-            nq -= take;
-            n_done += take;
-            if (lane < take) one_site(p);
-        }
     }
-    if (count_todo && lane == 0 && n_done) atomicAdd(&head->n_todo, n_done);      // (debug builds print it; nothing reads it otherwise)
 }
 
 // ------------------------------------------------------------------------------------------------ stars, second per-thread pass
@@ -626,15 +628,17 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
 }
 
 // compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx,
-// MODE 2 = points with deg == kDegTodo -> todo_idx
+// MODE 2 = points with deg == kDegFan -> todo_idx (what the cell pass left to the fan pass),
+// MODE 3 = entries j of `sorted` (src; aux = deg) whose point has deg == kDegTodo -> their POINT indices, in bucket order, for the clip pass
 // MODE 1 also lists the ranks the wave pass finished beyond kMidRings coarse rings (aux = far_wide): they are not computed
 // again, but the workgroup pass searches the coarse grid only that far around a point, and a neighbour whose own cell
 // reaches farther would otherwise be missing from its candidates.
 template <int MODE>
 __device__ __forceinline__ bool flagged(const void *src, const unsigned char *aux, size_t i)
 {
+    if (MODE == 3) { const unsigned c = ((const unsigned *)src)[i]; return c != 0xFFFFFFFFu && aux[c] == kDegTodo; }
     return MODE == 0 ? ((const unsigned char *)src)[i] == kDegFar
-         : MODE == 2 ? ((const unsigned char *)src)[i] == kDegTodo : (((const unsigned *)src)[i] == kDegLeft || aux[i] != 0);
+         : MODE == 2 ? ((const unsigned char *)src)[i] == kDegFan : (((const unsigned *)src)[i] == kDegLeft || aux[i] != 0);
 }
 
 template <int MODE>
@@ -667,7 +671,7 @@ void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__r
     for (int k = 0; k < 8; ++k)
         if (base + k < n && flagged<MODE>(src, aux, base + k)) {
             if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
-            list[at++] = (unsigned)(base + k);
+            list[at++] = MODE == 3 ? ((const unsigned *)src)[base + k] : (unsigned)(base + k);
         }
     if (blockIdx.x == last_block && threadIdx.x == 0) {
         unsigned cnt = offs[blockIdx.x] + total;
@@ -677,7 +681,7 @@ void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__r
         }
         if ((MODE == 0 && cnt > kMaxFar) || (MODE == 1 && cnt > kMaxLeft)) { atomicOr(&head->err, kErrDegenerate); cnt = 0; }
         if (head->err & kErrDegenerate) cnt = 0;           // a degenerate point set: no star pass runs (their loops are sized for ordinary buckets)
-        if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else head->n_todo = cnt;
+        if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else if (MODE == 2) head->n_fan = cnt; else head->n_todo = cnt;
     }
 }
 
@@ -1364,11 +1368,22 @@ __device__ __forceinline__ bool star_has(const DlWs &ws, unsigned s, unsigned a,
 // one triangle by one thread; large bounding boxes go to the list swept by whole waves.  Every triangle is listed by
 // each of its three sites; the copy of the site with the smallest index is the one that is drawn -- unless that
 // site's star does not list the triangle (stars that disagree on a co-circular cell), in which case this copy is drawn too.
-__device__ __forceinline__ void thread_raster(unsigned id, unsigned self, const PosFn &pos, int H, int W, const DlWs &ws, unsigned far_base)
+// `trust`: bit 0 = `self` was settled by the mesh-cell pass (its neighbours are grid neighbours), bits 1 .. 4 = so were its
+// grid neighbours NW, N, NE, W -- the only ones with a smaller index.  A star that came from the cell flags lists every
+// triangle of its four (verified) cells, so the copy held by such a neighbour IS drawn and this one need not look it up.
+__device__ __forceinline__ void thread_raster(unsigned id, unsigned self, const PosFn &pos, int H, int W, const DlWs &ws, unsigned far_base,
+                                              unsigned trust = 0)
 {
     const TriRef tr = dl_decode(id, far_base, ws);
     if (!tr.ok) return;
-    if (tr.i0 != self && star_has(ws, tr.i0, tr.i1, tr.i2)) return;
+    if (tr.i0 != self) {
+        bool skip = false;
+        if (trust & 1u) {
+            const int dv = (int)self - (int)tr.i0;
+            skip = (dv == W + 1 && (trust & 2u)) || (dv == W && (trust & 4u)) || (dv == W - 1 && (trust & 8u)) || (dv == 1 && (trust & 16u));
+        }
+        if (skip || star_has(ws, tr.i0, tr.i1, tr.i2)) return;
+    }
     const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
     const TriBox b = box_rows(q0, q1, q2, W, H, ws);
     if (b.x1 < b.x0 || b.y1 < b.y0) return;
@@ -1383,22 +1398,48 @@ __device__ __forceinline__ void thread_raster(unsigned id, unsigned self, const 
     for (int gy = b.y0; gy <= b.y1; ++gy)
         for (int gx = b.x0; gx <= b.x1; ++gx)
             if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+    // (per-row intervals as in dl_raster_big_kernel were measured here for the wide boxes of sheared lattices: the extra
+    // registers and code slow every field down by 4 - 10 %, config 5 included)
 }
 
 __global__ __launch_bounds__(256)
-void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base)
+void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base, int by_bucket)
 {
     // workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the field, so that the neighbour
     // rows a point looks up (the stars of the sites above and below it) are in ITS L2
     const unsigned nb = gridDim.x, per = (nb + 7) / 8;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (blk >= nb) return;
-    const size_t p = (size_t)blk * 256 + threadIdx.x;
+    size_t p = (size_t)blk * 256 + threadIdx.x;
     if (p >= (size_t)H * W) return;
+    if (by_bucket) {                                           // (experiments build) sites in bucket order instead of index order
+        const unsigned c = ws.sorted[p];
+        if (c == 0xFFFFFFFFu) return;
+        p = c;
+    }
     const unsigned d = ws.deg[p];
     if (d == 0 || d > kSlots) return;
+    // which of this site and its four smaller-index grid neighbours were settled from the cell flags (three dword loads)
+    unsigned trust = 0;
+    {
+        const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
+        if (x >= 2 && y >= 2 && x <= W - 3 && y <= H - 2) {
+            const unsigned char *f = ws.cellflag + (size_t)(y - 2) * W + (x - 2);
+            struct __attribute__((packed, aligned(1))) U32u { unsigned v; };
+            const unsigned r0 = reinterpret_cast<const U32u *>(f)->v, r1 = reinterpret_cast<const U32u *>(f + W)->v,
+                           r2 = reinterpret_cast<const U32u *>(f + 2 * (size_t)W)->v;
+            auto nz = [](unsigned r, int k) { return ((r >> (8 * k)) & 0xFFu) != 0u; };
+            if (nz(r2, 2) && nz(r2, 1) && nz(r1, 1) && nz(r1, 2)) {
+                trust = 1u;
+                if (nz(r1, 1) && nz(r1, 0) && nz(r0, 0) && nz(r0, 1)) trust |= 2u;       // NW
+                if (nz(r1, 2) && nz(r1, 1) && nz(r0, 1) && nz(r0, 2)) trust |= 4u;       // N
+                if (nz(r1, 3) && nz(r1, 2) && nz(r0, 2) && nz(r0, 3)) trust |= 8u;       // NE
+                if (nz(r2, 1) && nz(r2, 0) && nz(r1, 0) && nz(r1, 1)) trust |= 16u;      // W
+            }
+        }
+    }
     const PosFn pos(flow, sign, W);
-    for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, (unsigned)p, pos, H, W, ws, far_base);
+    for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, (unsigned)p, pos, H, W, ws, far_base, trust);
 }
 
 // one WAVE per unfinished point (their stars run to hundreds of triangles: a thread per point would crawl)
@@ -1620,6 +1661,7 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.sorted = (unsigned *)p;              p += align_up(n * 4, 256);
     ws.deg = (unsigned char *)p;            p += align_up(n, 256);
     ws.todo_idx = (unsigned *)p;            p += align_up(n * 4, 256);
+    ws.cellflag = (unsigned char *)p;       p += align_up(n, 256);
     ws.dup = (unsigned char *)p;            p += align_up(n, 256);
     ws.nbr = (unsigned *)p;                 p += align_up(std::max(n * kSlots, ws.bcap) * 4, 256);
     ws.far_idx = (unsigned *)p;             p += align_up(n * 4, 256);
@@ -1704,6 +1746,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     static const double bucket_scale = OFL_KNOB_DOUBLE("OFL_DL_BUCKET", 1.0);      // development knob (experiments build only)
     hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W);
     OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
+    OFL_HIP(hipMemsetAsync(ws.sorted, 0xFF, n * 4, s));                  // entries past the last bucket stay blank
     hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup);
     OFL_HIP(hipGetLastError());
     OFL_TRY(scan_exclusive(ws.bstart, ws.bcap + 1, ws.scan_tmp, s));
@@ -1717,14 +1760,31 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy, ws.dup);
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
     unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
-    hipLaunchKernelGGL(dl_star_fan_kernel, dim3((unsigned)(((n + kFanBlock - 1) / kFanBlock + 7) / 8 * 8)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
-                       (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
+    // mesh cells (one verification per triangle), the sites they settle, then the fans of the rest (compacted in index order)
+    {
+        const int ctx = (W + 31) / 32, cty = (H + 7) / 8;
+        hipLaunchKernelGGL(dl_cell_kernel, dim3((unsigned)((ctx * cty + 7) / 8 * 8)), dim3(256), 0, s, flow, sign_pp, pmask, H, W,
+                           (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
+                           (const unsigned char *)ws.dup, ws.cellflag, ctx, ctx * cty);
+        hipLaunchKernelGGL(dl_site_cells_kernel, dim3(nblk), dim3(256), 0, s, pmask, H, W, (const DlHead *)ws.head,
+                           (const unsigned char *)ws.dup, (const unsigned char *)ws.cellflag, ws.deg, ws.nbr);
+    }
+    hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
+    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
+    hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
+                       ws.todo_idx, fblk - 1, (unsigned *)nullptr);
+    hipLaunchKernelGGL(dl_star_fan_kernel, dim3(std::min<unsigned>((unsigned)((n + kFanBlock - 1) / kFanBlock), 16384u)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
+                       (const DlHead *)ws.head, (const unsigned *)ws.todo_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                        (const unsigned char *)ws.dup, ws.deg, ws.nbr);
-    // what the fans did not settle: the clip pass, scheduled by bucket tile (every wave collects its own sites)
+    // what cells and fans did not settle, in BUCKET order, for the clip pass (the unfilled tail of `sorted` is 0xFFFFFFFF)
     static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
-    hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n / 48 + 8) / 8 * 8), 65536u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
-                       ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
-                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr, debug ? 1 : 0);
+    hipLaunchKernelGGL(dl_flag_count_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.sorted, (const unsigned char *)ws.deg, (const DlHead *)ws.head, n, fcnt);
+    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
+    hipLaunchKernelGGL(dl_flag_write_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.sorted, (const unsigned char *)ws.deg, ws.head, n, (const unsigned *)fcnt,
+                       ws.far_idx, fblk - 1, (unsigned *)nullptr);           // (far_idx is free until the unfinished points are listed)
+    hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
+                       (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
+                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr);
     OFL_HIP(hipGetLastError());
     // unfinished points in index order
     hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
@@ -1782,7 +1842,8 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                            ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
         OFL_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(dl_raster_small_kernel, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
+    hipLaunchKernelGGL(dl_raster_small_kernel, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base,
+                       OFL_KNOB_INT("OFL_DL_RASTER_BUCKET", 0));
     hipLaunchKernelGGL(dl_raster_far_kernel, dim3(std::min<unsigned>(walk, 4096u)), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     far_base_out = (unsigned)far_base;
@@ -1792,7 +1853,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         OFL_HIP(hipMemcpyAsync(&h, ws.head, sizeof(h), hipMemcpyDeviceToHost, s));
         OFL_HIP(hipStreamSynchronize(s));
         if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = h.n_left; }
-        if (debug) fprintf(stderr, "[ofl exact] kept %u, clip pass %u, unfinished %u, left over %u\n", h.kept, h.n_todo, h.n_far, h.n_left);
+        if (debug) fprintf(stderr, "[ofl exact] kept %u, fan pass %u, clip pass %u, unfinished %u, left over %u\n", h.kept, h.n_fan, h.n_todo, h.n_far, h.n_left);
         if (!info_host) return OFL_OK;
         if (h.kept == 0) late_error = fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
         else if (h.err) late_error = fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "

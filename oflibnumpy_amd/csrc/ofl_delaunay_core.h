@@ -509,6 +509,108 @@ DL_HD int star_fan(int p, int W, const P2 &pp, unsigned kept8, PosFn pos, SlotPo
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------ mesh cells
+// The fan pass above verifies every triangle of the warped mesh THREE times (once from each of its vertices) after a
+// float64 set-up of eight triangles per site.  The same empty-circle property can be established once per CELL: a grid
+// cell (corners a = (x, y), b = (x + 1, y), c = (x + 1, y + 1), d = (x, y + 1), all kept) that is convex and positively
+// oriented is split along its Delaunay diagonal -- decided by the expression star_fan uses, so a site that has to fall
+// back to its fan sees the same diagonal -- and its two triangles are tested against the sites of the buckets under
+// their circumcircles (float32 first look, float64 inside its margin, the in-circle predicate inside that one's).  A site
+// whose four surrounding cells are verified has its star for free: the axis neighbours plus the diagonal neighbour of
+// every cell whose diagonal passes through it -- the angles of four convex cells at a common corner add up to one turn,
+// and triangles with empty circumcircles around a vertex ARE its Delaunay star.  Ties (a site exactly ON a circle that
+// is not a corner of the cell) and everything else unusual fail the cell; its corners then take the fan / clip path, so
+// the cells -- like the fans -- never change WHAT is computed.
+// Returns 0 (not verified), 1 (verified, diagonal a - c) or 2 (verified, diagonal b - d).
+template <class PosFn>
+DL_HD int cell_verify(int ia, int W, const P2 &A, const P2 &B, const P2 &C, const P2 &D, const Grid &g,
+                      const unsigned *bstart, const unsigned *sorted, const P2 *sorted_xy, PosFn pos, int max_span)
+{
+    auto cross = [](const P2 &o, const P2 &u, const P2 &v) { return (u.x - o.x) * (v.y - o.y) - (u.y - o.y) * (v.x - o.x); };
+    if (!(cross(A, B, C) > 0.0 && cross(A, C, D) > 0.0 && cross(B, C, D) > 0.0 && cross(B, D, A) > 0.0)) return 0;
+    const bool ac = incircle_origin(P2{ B.x - A.x, B.y - A.y }, P2{ D.x - A.x, D.y - A.y }, P2{ C.x - A.x, C.y - A.y }) >= 0.0;
+    const P2 O = ac ? A : B;                                      // the vertex both triangles share
+    // triangle t = (O, U[t], V[t]), counter-clockwise: (a, b, c), (a, c, d)  or  (b, c, d), (b, d, a)
+    const P2 q0 = ac ? B : C, q1 = ac ? C : D, q2 = ac ? D : A;
+    const P2 U[2] = { P2{ q0.x - O.x, q0.y - O.y }, P2{ q1.x - O.x, q1.y - O.y } };
+    const P2 V[2] = { P2{ q1.x - O.x, q1.y - O.y }, P2{ q2.x - O.x, q2.y - O.y } };
+    float o[2], u[2], w[2];
+    float Mmax = 0.0f, bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+    for (int t = 0; t < 2; ++t) {
+        const double a2 = U[t].x * U[t].x + U[t].y * U[t].y, b2 = V[t].x * V[t].x + V[t].y * V[t].y;
+        const double ot = U[t].x * V[t].y - U[t].y * V[t].x;
+        const double ut = U[t].y * b2 - a2 * V[t].y, wt = a2 * V[t].x - U[t].x * b2;
+        const double mo = fabs(U[t].x * V[t].y) + fabs(U[t].y * V[t].x), mu = fabs(U[t].y) * b2 + a2 * fabs(V[t].y), mw = a2 * fabs(V[t].x) + fabs(U[t].x) * b2;
+        if (!(ot > 0.0)) return 0;
+        o[t] = (float)ot; u[t] = (float)ut; w[t] = (float)wt;
+        Mmax = fmaxf(Mmax, (float)fmax(mo, fmax(mu, mw)));
+        const float inv = 0.5f / (float)ot;
+        const float cx = -(float)ut * inv, cy = -(float)wt * inv;
+        const float r = sqrtf(cx * cx + cy * cy);
+        const float pad = r * 1.0001f + 1e-5f * (fabsf(cx) + fabsf(cy)) + 1e-30f;
+        bx0 = fminf(bx0, cx - pad); bx1 = fmaxf(bx1, cx + pad);
+        by0 = fminf(by0, cy - pad); by1 = fmaxf(by1, cy + pad);
+    }
+    if (!(bx1 - bx0 < 3e30f) || !(by1 - by0 < 3e30f) || !(Mmax < 3e30f)) return 0;          // also catches NaN
+    Mmax = Mmax * 1.000001f + 1e-37f;
+    const int cb0 = g.bx(O.x + (double)bx0), cb1 = g.bx(O.x + (double)bx1);
+    const int rb0 = g.by(O.y + (double)by0), rb1 = g.by(O.y + (double)by1);
+    if (cb1 - cb0 >= max_span || rb1 - rb0 >= max_span) return 0;
+    for (int row = rb0; row <= rb1; ++row) {
+        const unsigned lo = bstart[(size_t)row * g.gx + cb0], hi = bstart[(size_t)row * g.gx + cb1 + 1];
+        for (unsigned j = lo; j < hi; ++j) {
+            const P2 qa = sorted_xy ? sorted_xy[j] : pos((int)sorted[j]);
+            const P2 Cq = { qa.x - O.x, qa.y - O.y };
+            const float cxf = (float)Cq.x, cyf = (float)Cq.y, c2f = cxf * cxf + cyf * cyf;
+            const float marg = kFanEpsF * (c2f + fabsf(cxf) + fabsf(cyf)) * Mmax;
+            const bool n0 = !(c2f * o[0] + (cxf * u[0] + cyf * w[0]) > marg), n1 = !(c2f * o[1] + (cxf * u[1] + cyf * w[1]) > marg);
+            if (!(n0 || n1)) continue;                               // well outside both circles (a blanked entry holds its old position: harmless)
+            const int qi = (int)sorted[j];
+            if (qi < 0) continue;                                    // a dropped duplicate
+            if (qi == ia || qi == ia + 1 || qi == ia + W || qi == ia + W + 1) continue;      // the cell's own corners: vertices, or settled by the diagonal
+            const double c2 = Cq.x * Cq.x + Cq.y * Cq.y;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+            for (int t = 0; t < 2; ++t) {                            // (unrolled: a run-time index would move U / V out of registers)
+                if (!(t ? n1 : n0)) continue;
+                const P2 Ut = U[t], Vt = V[t];
+                const double a2 = Ut.x * Ut.x + Ut.y * Ut.y, b2 = Vt.x * Vt.x + Vt.y * Vt.y;
+                const double t0 = c2 * (Ut.x * Vt.y - Ut.y * Vt.x), t1 = Cq.x * (Ut.y * b2 - a2 * Vt.y), t2 = Cq.y * (a2 * Vt.x - Ut.x * b2);
+                const double sum = t0 + (t1 + t2);
+                const double mag = c2 * (fabs(Ut.x * Vt.y) + fabs(Ut.y * Vt.x)) + fabs(Cq.x) * (fabs(Ut.y) * b2 + a2 * fabs(Vt.y))
+                                 + fabs(Cq.y) * (a2 * fabs(Vt.x) + fabs(Ut.x) * b2);
+                if (sum > kFanEps * mag) continue;                   // outside
+                if (sum < -kFanEps * mag) return 0;                  // inside: not a Delaunay triangle
+                if (!(incircle_origin(Ut, Vt, Cq) < 0.0)) return 0;  // inside, or exactly on the circle (a tie: left to the fan / clip path)
+            }
+        }
+    }
+    return ac ? 1 : 2;
+}
+
+// The star of an interior site from the flags of its four cells (cell_verify; f_se = the cell whose corner a is the site,
+// f_sw / f_nw / f_ne = the cells to its lower left / upper left / upper right): slots E, SE, S, SW, W, NW, N, NE as in
+// star_fan, the diagonal ones only where the cell's diagonal passes through the site.  Returns the number of neighbours
+// (4 .. 8), or 0 when a cell is not verified.
+DL_HD int star_from_cells(int p, int W, int f_se, int f_sw, int f_nw, int f_ne, unsigned *nbr_out)
+{
+    if (!(f_se && f_sw && f_nw && f_ne)) return 0;
+    int n = 0;
+    nbr_out[n++] = (unsigned)(p + 1);
+    if (f_se == 1) nbr_out[n++] = (unsigned)(p + W + 1);            // cell (a = p, b = E, c = SE, d = S): diagonal a - c
+    nbr_out[n++] = (unsigned)(p + W);
+    if (f_sw == 2) nbr_out[n++] = (unsigned)(p + W - 1);            // cell (a = W, b = p, c = S, d = SW): diagonal b - d
+    nbr_out[n++] = (unsigned)(p - 1);
+    if (f_nw == 1) nbr_out[n++] = (unsigned)(p - W - 1);            // cell (a = NW, b = N, c = p, d = W): diagonal a - c
+    nbr_out[n++] = (unsigned)(p - W);
+    if (f_ne == 2) nbr_out[n++] = (unsigned)(p - W + 1);            // cell (a = N, b = NE, c = E, d = p): diagonal b - d
+    return n;
+}
+
 // The polygon of a cell from the cyclic sequence of its edges' sites (box sides: -1 .. -4) -- what a pass that had to
 // leave the cell unfinished hands on: vertex k is where the lines of tags[k - 1] and tags[k] meet.  One step instead of one
 // clip per site.  Returns false (polygon untouched) when a vertex does not come out finite: the caller then clips the

@@ -42,7 +42,8 @@ int poly_clip_any(Poly &P, const P2 &C, int ctag, int ptag, RelFn rel, std::vect
 }  // namespace
 
 // pts [n][2]; tri_out receives (p, a, b) for every pair of consecutive real neighbours of every star ("emit all");
-// info[8]: [0] far sites, [1] polygon overflows in the near pass, [2] grid gx, [3] grid gy, [4] largest star
+// info[8]: [0] far sites, [1] polygon overflows in the near pass, [2] grid gx, [3] grid gy, [4] largest star, [5] sites settled by
+// mesh fans, [6] by the second per-thread pass, [7] by the mesh-cell pass
 // kept (or null: all) marks the sites that exist; with W > 0 the sites are the points of a warped H x W grid in row-major
 // order and intact neighbourhoods take the mesh-fan shortcut first (info[5] counts them), as the GPU path does
 static int stars_impl(const double *pts, int n, const unsigned char *kept, int W, int rings, int near_cap, int *tri_out,
@@ -91,10 +92,34 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
     std::vector<float> fx(64), fy(64);
     std::vector<std::vector<unsigned>> seed_of(n);
     std::vector<int> rd_of(n, -1);
-    int fans = 0, near2 = 0;
+    int fans = 0, near2 = 0, by_cells = 0;
     const int H = W > 0 ? n / W : 0;
+    // the GPU's mesh-cell pass: every intact cell verified once (cell_verify), sites with four verified cells settled from the flags
+    std::vector<unsigned char> cellflag(W > 0 ? n : 0, 0);
+    if (W > 0)
+        for (int y = 0; y + 1 < H; ++y)
+            for (int x = 0; x + 1 < W; ++x) {
+                const int ia = y * W + x;
+                if (!(is_kept(ia) && is_kept(ia + 1) && is_kept(ia + W) && is_kept(ia + W + 1))) continue;
+                cellflag[ia] = (unsigned char)cell_verify(ia, W, pos(ia), pos(ia + 1), pos(ia + W + 1), pos(ia + W), g, bstart.data(), sorted.data(),
+                                                          (const P2 *)nullptr, pos, 6);
+            }
     for (int p = 0; p < n; ++p) {
         if (!is_kept(p)) continue;
+        if (W > 0) {
+            const int xs = p % W, ys = p / W;
+            if (xs > 0 && ys > 0 && xs < W - 1 && ys < H - 1) {
+                unsigned nb8[8];
+                const int m = star_from_cells(p, W, cellflag[p], cellflag[p - 1], cellflag[p - W - 1], cellflag[p - W], nb8);
+                if (m > 0) {
+                    for (int k = 0; k < m; ++k) tag[k] = (int)nb8[k];
+                    Poly Q{ vx.data(), vy.data(), tag.data(), 1, 64, m };
+                    emit(p, Q);
+                    ++by_cells;
+                    continue;
+                }
+            }
+        }
         if (W > 0) {
             const int x = p % W, y = p / W;
             unsigned kept8 = 0;
@@ -210,7 +235,7 @@ static int stars_impl(const double *pts, int n, const unsigned char *kept, int W
         emit(p, P);
     }
     *n_tri = nt;
-    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy; info[4] = maxdeg; info[5] = fans; info[6] = near2;
+    info[0] = (int)far.size(); info[1] = overflow; info[2] = g.gx; info[3] = g.gy; info[4] = maxdeg; info[5] = fans; info[6] = near2; info[7] = by_cells;
     return 0;
 }
 

@@ -224,6 +224,16 @@ int ofl_axpy_dev(const float *a, const uint8_t *ma, const float *b, const uint8_
  * sheared cells -- gets a real Delaunay triangulation of the kept points on the GPU.
  * valid_rule | OFL_SCATTER_UNCERTIFIED skips the entry's own certificate pass (and its read-back) for callers that know
  * the answer is "not certified"; the result is the same either way.
+ * A certificate says that the mesh is the triangulation, not that the one-kernel path finds every node's triangle in it
+ * (a certified field may squeeze a third of the image into a sliver): that kernel counts the nodes it could not locate,
+ * the entry -- which has synchronised for the certificate anyway -- reads the count back and, if it is not zero, computes
+ * the call on the Delaunay path instead.  The results are SciPy's either way.
+ * Degenerate point sets: exact duplicates are ONE site (Qhull's Qc; a flow may collapse a whole image block onto one pixel:
+ * buckets of thousands of coincident points are reduced through a hash table of positions).  What remains degenerate is
+ * refused like Qhull refuses a flat initial simplex (the reference raises QhullError): all points on one spot or one
+ * axis-parallel line, more than 65 536 distinct sites crowded into buckets of more than 4 096, more than 2^20 unfinished
+ * or 2^18 unbounded cells (bulk collinearity) -- OFL_E_INVALID for callers that pass info_host, an all-zero / all-invalid
+ * result for everybody (also after any capacity error: never a partial warp).
  */
 int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                            const float *vals, int C, const uint8_t *vmask, int H, int W,
@@ -269,7 +279,10 @@ int ofl_scatter_certify_dev(const float *flow, int sign, int point_precision, co
                             void *workspace, size_t workspace_bytes, ofl_mesh_cert *cert_host, void *stream);
 /* Rows [row0, row0 + rows) of the grid result for a CERTIFIED field (cert->certified must be 1, no point mask):
  * out_rows [rows][W][C], valid_rows [rows][W] as in ofl_scatter_linear_dev; asynchronous.  fail_count_dev (device
- * uint32, may be NULL) counts nodes inside the hull for which no triangle was found -- 0 for a true certificate. */
+ * uint32, may be NULL; the caller zeroes it) counts nodes well inside the hull for which the kernel found no triangle
+ * (written as 0 / invalid).  It is 0 for every affine field; a caller that keeps a certificate should check it once per
+ * (field, sign) -- which nodes are found depends on nothing else -- and send a field that loses nodes through
+ * ofl_scatter_linear_dev with OFL_SCATTER_UNCERTIFIED (the Python layer does exactly that). */
 int ofl_scatter_certified_dev(const float *flow, int sign, int point_precision, const float *vals, int C,
                               const uint8_t *vmask, int H, int W, int row0, int rows, float *out_rows,
                               uint8_t *valid_rows, int valid_rule, const ofl_mesh_cert *cert,
@@ -284,7 +297,10 @@ int ofl_scatter_linear(const float *flow, int sign, int point_precision, const u
  *                           pts_rc / out_rc are [n][2] in (row, col) order; points must lie inside the field
  *   ofl_scatter_query_dev   'ref t' (utils.py:610-615) and s_exact_mode (:599-603): griddata(points, values, pts):
  *                           same triangulation as ofl_scatter_linear_dev, evaluated at n_query float64 points
- *                           query_xy [n][2] = (x, y); out float64 [n][C]; found[i] = 0 where griddata gives NaN
+ *                           query_xy [n][2] = (x, y); out float64 [n][C]; found[i] = 0 where griddata gives NaN.
+ *                           Synchronises: the point counts and error flags of the triangulation are read back inside, so
+ *                           "no point kept" (OFL_E_NOPOINTS) and a refused / overflowing point set (OFL_E_INVALID) are
+ *                           ERRORS here, never a list of found = 0 that looks like "outside the hull".
  */
 int ofl_sample_points_dev(const float *flow, int H, int W, const double *pts_rc, size_t n, double *out_rc, void *stream);
 int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,

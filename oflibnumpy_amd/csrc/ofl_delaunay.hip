@@ -59,7 +59,9 @@ constexpr unsigned char kDegTodo = 0xFE;  // not settled by the mesh-fan pass: t
 constexpr unsigned char kDegFan = 0xFD;   // not settled by the mesh-cell pass: the fan pass looks at this site
 constexpr int      kFanSpan  = 6;        // buckets per axis a fan's circumcircles may span (wider: clip pass)
 constexpr int      kFanBlock = 128;
-constexpr unsigned kMaxBucket = 4096;     // sites one bucket may hold (coincident / collinear points in bulk: the point set is degenerate)
+constexpr unsigned kMaxBucket = 4096;     // entries beyond which a bucket counts as huge ...
+constexpr unsigned kMaxLiveHuge = 1u << 16;   // ... and the DISTINCT sites all huge buckets together may hold (more: the point set is degenerate)
+constexpr unsigned kDedupeSmall = 256;    // buckets up to this size drop their duplicates by pairwise comparison, larger ones through a hash table
 constexpr unsigned kMaxFar   = 1u << 20;  // unfinished stars ...
 constexpr unsigned kMaxLeft  = 1u << 18;  // ... and stars for the workgroup pass (quadratic in their number) before the call gives up
 constexpr unsigned kErrDegenerate = 16u;  // err bit: one of the three limits above -- Qhull, too, refuses such input ("initial simplex is flat")
@@ -73,7 +75,9 @@ struct DlHead {                           // device header of the exact path (25
     unsigned n_todo;                                 // points the mesh-fan pass left to the clip pass (counted in debug runs only)
     unsigned n_fan;                                  // points the mesh-cell pass left to the fan pass
     double   far_t2;                                 // squared distance beyond which a cell vertex counts as "far" (well outside the data)
-    unsigned pad[12];
+    unsigned n_big;                                  // sorted entries that live in buckets of more than kDedupeSmall entries
+    unsigned live_huge;                              // distinct sites left in buckets of more than kMaxBucket entries
+    unsigned pad[10];
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
 
@@ -225,6 +229,8 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
         x0 = fmax(x0, fmin(-m, x1 - 1.0)); x1 = fmin(x1, fmax((double)W + m, x0 + 1.0));
         y0 = fmax(y0, fmin(-m, y1 - 1.0)); y1 = fmin(y1, fmax((double)H + m, y0 + 1.0));
         const double bw = x1 - x0, bh = y1 - y0;
+        // every point on one spot or on one axis-parallel line: nothing to triangulate (Qhull: "initial simplex is flat")
+        if (n >= 3 && (!(okey_inv(head->kx1) > okey_inv(head->kx0)) || !(okey_inv(head->ky1) > okey_inv(head->ky0)))) atomicOr(&head->err, kErrDegenerate);
         double s = bucket_scale * sqrt(fmax(bw * bh, 1e-300) / (double)n);             // ~bucket_scale^2 points per bucket
         s = fmax(s, (bw + bh) / (double)n);
         if (!(s > 0.0) || !isfinite(s)) s = 1.0;
@@ -427,13 +433,81 @@ void dl_dedupe_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bs
     const size_t nb = (size_t)head->grid.gx * head->grid.gy;
     for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
         const unsigned lo = bstart[b], hi = bstart[b + 1];
-        if (hi - lo > kMaxBucket) atomicOr(&head->err, kErrDegenerate);
-        if (hi - lo < 2 || hi - lo > 256) continue;
+        if (hi - lo > kDedupeSmall) atomicAdd(&head->n_big, hi - lo);     // rare: dl_big_* below take these buckets
+        if (hi - lo < 2 || hi - lo > kDedupeSmall) continue;
         for (unsigned j = lo + 1; j < hi; ++j) {
             const P2 q = sorted_xy[j];
             bool same = false;
             for (unsigned i = lo; i < j && !same; ++i) same = sorted[i] != 0xFFFFFFFFu && sorted_xy[i].x == q.x && sorted_xy[i].y == q.y;
             if (same) { dup[sorted[j]] = 1; sorted[j] = 0xFFFFFFFFu; }
+        }
+    }
+}
+
+// Buckets of more than kDedupeSmall entries -- a flow that collapses a whole block of the image onto one pixel is legal
+// input to Flow.apply, and Qhull (option Qc) treats coincident points as ONE vertex -- drop their duplicates through an
+// open-addressing table of point indices keyed by the position's bits (`table`: T = 2^k >= 2 n_big entries of the
+// neighbour pool, which nothing uses yet): insertion keeps the SMALLEST index of every location, a second pass over the
+// entries blanks the others.  All three kernels return at once when no such bucket exists (n_big == 0).
+__device__ __forceinline__ unsigned dl_big_size(const DlHead *head, unsigned long long cap)
+{
+    unsigned long long t = 1024;
+    while (t < 2ull * head->n_big) t <<= 1;
+    return (unsigned)(t < cap ? t : cap);          // (cap = pool entries >= 8 n > 4 n_big: never binding)
+}
+
+__device__ __forceinline__ unsigned dl_pos_hash(const P2 &q)
+{
+    unsigned long long a = (unsigned long long)__double_as_longlong(q.x), b = (unsigned long long)__double_as_longlong(q.y);
+    a ^= a >> 33; a *= 0xff51afd7ed558ccdull; a ^= a >> 33;
+    b ^= b >> 29; b *= 0xc4ceb9fe1a85ec53ull; b ^= b >> 32;
+    a ^= b + 0x9e3779b97f4a7c15ull + (a << 6) + (a >> 2);
+    return (unsigned)(a ^ (a >> 32));
+}
+
+__global__ __launch_bounds__(256)
+void dl_big_clear_kernel(const DlHead *__restrict__ head, unsigned *__restrict__ table, unsigned long long cap)
+{
+    if (head->n_big == 0) return;
+    const unsigned T = dl_big_size(head, cap);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < T; i += gridDim.x * 256) table[i] = 0xFFFFFFFFu;
+}
+
+// PASS 0: insert (smallest index of a location wins), PASS 1: blank every entry that is not its location's smallest index
+template <int PASS>
+__global__ __launch_bounds__(256)
+void dl_big_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted,
+                   const P2 *__restrict__ sorted_xy, unsigned char *__restrict__ dup, unsigned *__restrict__ table,
+                   unsigned long long cap, size_t n_entries, const float *__restrict__ flow, int sign, int W)
+{
+    if (head->n_big == 0) return;
+    const unsigned T = dl_big_size(head, cap), mask = T - 1;
+    const Grid g = head->grid;
+    const PosFn pos(flow, sign, W);
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n_entries; j += (size_t)gridDim.x * 256) {
+        const unsigned c = sorted[j];
+        if (c == 0xFFFFFFFFu) continue;
+        const P2 q = sorted_xy[j];
+        const size_t b = (size_t)g.by(q.y) * g.gx + g.bx(q.x);
+        const unsigned cnt = bstart[b + 1] - bstart[b];
+        if (cnt <= kDedupeSmall) continue;
+        unsigned h = dl_pos_hash(q) & mask;
+        for (unsigned probe = 0; probe < T; ++probe, h = (h + 1) & mask) {
+            if (PASS == 0) {
+                const unsigned cur = atomicCAS(&table[h], 0xFFFFFFFFu, c);
+                if (cur == 0xFFFFFFFFu) break;                           // a new location
+                const P2 o = pos((int)cur);                              // (whatever index the slot holds now or later: the same location)
+                if (o.x == q.x && o.y == q.y) { atomicMin(&table[h], c); break; }
+            } else {
+                const unsigned cur = table[h];
+                if (cur == 0xFFFFFFFFu) break;                           // (cannot happen: every entry was inserted)
+                const P2 o = pos((int)cur);
+                if (o.x == q.x && o.y == q.y) {
+                    if (cur != c) { dup[c] = 1; sorted[j] = 0xFFFFFFFFu; }
+                    else if (cnt > kMaxBucket && atomicAdd(&head->live_huge, 1u) + 1u > kMaxLiveHuge) atomicOr(&head->err, kErrDegenerate);
+                    break;
+                }
+            }
         }
     }
 }
@@ -1758,6 +1832,14 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        (const unsigned *)ws.sorted, (const unsigned *)nullptr, ws.sorted_xy, (unsigned *)nullptr);
     hipLaunchKernelGGL(dl_dedupe_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
                        ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy, ws.dup);
+    {   // buckets too large for the pairwise dedupe (whole image blocks collapsed onto one spot): no-ops when there are none
+        const unsigned gb = std::min<unsigned>(nblk, 16384u);
+        hipLaunchKernelGGL(dl_big_clear_kernel, dim3(gb), dim3(256), 0, s, (const DlHead *)ws.head, (unsigned *)ws.pool, (unsigned long long)ws.pool_cap);
+        hipLaunchKernelGGL(dl_big_kernel<0>, dim3(gb), dim3(256), 0, s, ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy,
+                           ws.dup, (unsigned *)ws.pool, (unsigned long long)ws.pool_cap, n, flow, sign_pp, W);
+        hipLaunchKernelGGL(dl_big_kernel<1>, dim3(gb), dim3(256), 0, s, ws.head, (const unsigned *)ws.bstart, ws.sorted, (const P2 *)ws.sorted_xy,
+                           ws.dup, (unsigned *)ws.pool, (unsigned long long)ws.pool_cap, n, flow, sign_pp, W);
+    }
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
     unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
     // mesh cells (one verification per triangle), the sites they settle, then the fans of the rest (compacted in index order)
@@ -1855,6 +1937,11 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = h.n_left; }
         if (debug) fprintf(stderr, "[ofl exact] kept %u, fan pass %u, clip pass %u, unfinished %u, left over %u\n", h.kept, h.n_fan, h.n_todo, h.n_far, h.n_left);
         if (!info_host) return OFL_OK;
+        if (h.err) {
+            // a capacity or degeneracy error leaves SOME stars rasterised: blank the owner map, so that the result is what
+            // include/ofl.h promises for an error -- all zero, all invalid -- rather than a partial warp
+            OFL_HIP(hipMemsetAsync(ws.owner + (size_t)row0 * W, 0xFF, (size_t)rows * W * 4, s));
+        }
         if (h.kept == 0) late_error = fail(OFL_E_NOPOINTS, "ofl_scatter_linear: no valid source points");
         else if (h.err) late_error = fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
                                               "neighbours, 2 = neighbour pool, 4 = large-triangle list, 8 = unfinished stars beyond the "

@@ -23,7 +23,19 @@ using namespace ofl_sc;
 
 namespace {
 
-constexpr size_t kMinWorkspace = 4096;            // the certificate's device record
+constexpr size_t kMinWorkspace = 4096;            // the certificate's device record (first 256 bytes) + the walk kernel's failure counter
+constexpr size_t kWalkFailAt   = 1024;            // byte offset of that counter
+
+// A certificate proves that the cell-wise mesh IS the Delaunay triangulation, not that the walk kernel's Newton steps find
+// every node's triangle in it (a certified field may compress 99 % of the image into a corner): the kernel counts the nodes
+// it could not locate although they lie well inside the hull, the entry reads the count back -- it has synchronised for the
+// certificate already -- and a non-zero count sends the call through the Delaunay path, which searches nothing.
+int walk_failures(void *workspace, hipStream_t s, uint32_t &n)
+{
+    OFL_HIP(hipMemcpyAsync(&n, (char *)workspace + kWalkFailAt, 4, hipMemcpyDeviceToHost, s));
+    OFL_HIP(hipStreamSynchronize(s));
+    return OFL_OK;
+}
 
 int check_common(const char *who, const float *flow, int &sign, int point_precision, int C, const void *vals, const void *out,
                  const uint8_t *valid, int valid_rule, int H, int W, void *workspace, size_t workspace_bytes)
@@ -54,8 +66,14 @@ int scatter_grid_impl(const char *who, const float *flow, int sign, int point_pr
         ofl_mesh_cert cert;
         OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));       // a point mask without zeros drops nothing
         if (cert.certified) {
-            if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
-            return walk_launch<VT>(flow, sign, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule, &cert, nullptr, s);
+            uint32_t *fail = (uint32_t *)((char *)workspace + kWalkFailAt), n_fail = 0;
+            OFL_HIP(hipMemsetAsync(fail, 0, 4, s));
+            OFL_TRY(walk_launch<VT>(flow, sign, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule, &cert, fail, s));
+            OFL_TRY(walk_failures(workspace, s, n_fail));
+            if (n_fail == 0) {
+                if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
+                return OFL_OK;
+            }
         }
     }
     return exact_scatter<VT>(flow, sign, pmask, vals, C, vmask, H, W, row0, rows, out, valid, valid_rule,
@@ -73,8 +91,14 @@ int scatter_query_impl(const char *who, const float *flow, int sign, int point_p
         ofl_mesh_cert cert;
         OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));
         if (cert.certified) {
-            if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
-            return walk_query_launch(flow, sign, vals, C, vmask, H, W, query, n, sparse, out, valid, valid_rule, &cert, s);
+            uint32_t *fail = (uint32_t *)((char *)workspace + kWalkFailAt), n_fail = 0;
+            OFL_HIP(hipMemsetAsync(fail, 0, 4, s));
+            OFL_TRY(walk_query_launch(flow, sign, vals, C, vmask, H, W, query, n, sparse, out, valid, valid_rule, &cert, fail, s));
+            OFL_TRY(walk_failures(workspace, s, n_fail));
+            if (n_fail == 0) {
+                if (info_host) { info_host[0] = (uint64_t)H * W; info_host[1] = 0; info_host[2] = 0; }
+                return OFL_OK;
+            }
         }
     }
     return exact_query(flow, sign, pmask, vals, C, vmask, H, W, query, n, sparse, out, valid, valid_rule,
@@ -167,8 +191,11 @@ int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, cons
 {
     OFL_TRY(need_device());
     if (C <= 0 || !vals || !out || !found || !query_xy) return fail(OFL_E_INVALID, "ofl_scatter_query: NULL pointer / C <= 0");
+    // the counts are read back inside (the caller downloads the few results right away, so the synchronisation is free): a
+    // point set without points, a refused one or an exceeded capacity is an ERROR here, not a list of "not found" flags
+    uint64_t info[3];
     return scatter_query_impl("ofl_scatter_query", flow, sign, point_precision, pmask, vals, C, nullptr, H, W, query_xy,
-                              n_query, true, out, found, 0, workspace, workspace_bytes, nullptr, stream_of(stream));
+                              n_query, true, out, found, 0, workspace, workspace_bytes, info, stream_of(stream));
 }
 
 int ofl_scatter_linear(const float *flow, int sign, int point_precision, const uint8_t *pmask,

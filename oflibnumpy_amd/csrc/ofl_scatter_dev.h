@@ -161,7 +161,7 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
 // float64 [n][2] (sparse: float64 out [n][C] + found flags)
 int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, const uint8_t *vmask, int H, int W,
                       const void *query, size_t n, bool sparse, void *out, uint8_t *valid, int valid_rule,
-                      const ofl_mesh_cert *cert, hipStream_t s);
+                      const ofl_mesh_cert *cert, uint32_t *fail_dev, hipStream_t s);
 
 // exact path (ofl_delaunay.hip): Delaunay triangulation of the kept points on the GPU
 size_t exact_workspace_bytes(int H, int W);

@@ -395,7 +395,8 @@ template <int SP, bool SPARSE>
 __global__ __launch_bounds__(256)
 void scatter_walk_query_kernel(const float *__restrict__ flow, const float *__restrict__ vals, int C,
                                const uint8_t *__restrict__ vmask, int H, int W, const void *__restrict__ query, size_t n,
-                               void *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, WalkCert wc)
+                               void *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, WalkCert wc,
+                               uint32_t *__restrict__ fail)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         double qx, qy;
@@ -406,7 +407,7 @@ void scatter_walk_query_kernel(const float *__restrict__ flow, const float *__re
         if (qx == qx && qy == qy) {
             const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
             found = walk_locate<SP>(flow, H, W, nx, ny, qx, qy, h);
-            if (!found) found = hull_band_locate(flow, SP, H, W, wc, qx, qy, h, nullptr);
+            if (!found) found = hull_band_locate(flow, SP, H, W, wc, qx, qy, h, fail);
         }
         if (SPARSE) {
             double *o = (double *)out + i * C;
@@ -487,7 +488,7 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
 
 int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, const uint8_t *vmask, int H, int W,
                       const void *query, size_t n, bool sparse, void *out, uint8_t *valid, int valid_rule,
-                      const ofl_mesh_cert *cert, hipStream_t s)
+                      const ofl_mesh_cert *cert, uint32_t *fail_dev, hipStream_t s)
 {
     WalkCert wc;
     for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
@@ -497,7 +498,7 @@ int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, 
     const dim3 grid((unsigned)(nb < (1u << 20) ? nb : (1u << 20))), block(256);
 #define OFL_WQ_LAUNCH(SP, SPARSE)                                                                                    \
     hipLaunchKernelGGL((scatter_walk_query_kernel<SP, SPARSE>), grid, block, 0, s, flow, vals, C, vmask, H, W, query, \
-                       n, out, valid, valid_rule, wc)
+                       n, out, valid, valid_rule, wc, fail_dev)
     if (sparse) {
         if (sign_pp == 1) OFL_WQ_LAUNCH(1, true); else if (sign_pp == -1) OFL_WQ_LAUNCH(-1, true);
         else if (sign_pp == 2) OFL_WQ_LAUNCH(2, true); else OFL_WQ_LAUNCH(-2, true);

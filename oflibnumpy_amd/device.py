@@ -718,9 +718,17 @@ def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, v
     pass (OFL_SCATTER_UNCERTIFIED)."""
     ptr = lambda b: b.ptr if b is not None else None
     if cert is not None and cert.certified and pmask is None and query is None:
+        # The certificate says the mesh IS the triangulation; that the walk kernel also FINDS every node in it is checked on
+        # the first launch with this certificate (a device counter, one read-back): which nodes it locates depends on the
+        # field and the sign only, so later launches with the same cached certificate run without any synchronisation.
+        checked = getattr(cert, "_walk_checked", False)
+        cnt = None if checked else DeviceBuffer.zeros(16, stream)
         nat.check(_lib().ofl_scatter_certified_dev(flow.ptr, sign, point_precision, ptr(vals), C, ptr(vmask), h, w, 0, h,
-                                                   ptr(out), ptr(valid), valid_rule, ctypes.byref(cert), None, stream))
-        return (h * w, 0, 0)
+                                                   ptr(out), ptr(valid), valid_rule, ctypes.byref(cert), ptr(cnt), stream))
+        if checked or int(cnt.to_host((1,), np.uint32, stream)[0]) == 0:
+            cert._walk_checked = True
+            return (h * w, 0, 0)
+        cert.certified = 0                                  # nodes were lost: this field takes the Delaunay path from now on
     if (cert is not None and not cert.certified and pmask is None) or (drops_points and pmask is not None):
         valid_rule |= nat.SCATTER_UNCERTIFIED          # the certificate pass has been run for this field: not again per call
     ws = _workspace(h, w, C)

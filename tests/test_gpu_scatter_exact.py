@@ -213,7 +213,7 @@ def test_nodes_in_the_noise_band_of_the_border(gpu, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- exact path
-from scatter_util import nonunique_nodes      # noqa: E402
+from scatter_util import nonunique_nodes, warped_points      # noqa: E402
 
 
 def fixture_case(g, tag):
@@ -414,9 +414,9 @@ def test_garbage_vectors_do_not_hurt(gpu, golden2):
 
 
 def test_degenerate_point_sets_are_refused_not_endured(gpu):
-    """Qhull refuses a flat point set ("initial simplex is flat"); here the star passes are sized for ordinary buckets and
-    a few ten thousand unbounded cells, so a field that maps a million points onto one spot, or onto one line, is reported
-    (OFL_E_INVALID, flag 16) instead of being ground through -- quickly, and with an all-invalid result."""
+    """Qhull refuses a flat point set ("initial simplex is flat" -- the reference raises QhullError, a RuntimeError); here a
+    field that maps a million points onto one spot, or onto one line, is reported (OFL_E_INVALID, flag 16) instead of being
+    ground through -- quickly, and with an all-invalid result.  The same for a small flat set."""
     import time
     of = gpu
     from oflibnumpy_amd import device as dev
@@ -433,13 +433,46 @@ def test_degenerate_point_sets_are_refused_not_endured(gpu):
         rc = lib.ofl_scatter_linear_dev(f.ptr, 1, 0, None, vals.ptr, 1, None, h, w, None, out.ptr, valid.ptr, 0, ws.ptr, ws.nbytes, info, None)
         assert rc == nat.E_INVALID and time.perf_counter() - t0 < 20.0, (name, rc, time.perf_counter() - t0)
         assert not valid.to_host((h, w), np.uint8).any(), name
-    # ... while a SMALL degenerate set is simply triangulated as far as it goes (nothing to interpolate on: all invalid)
     hs, wsm = 12, 16
     ys, xs = np.mgrid[:hs, :wsm].astype(np.float32)
     f = dev.DeviceBuffer.from_host(np.ascontiguousarray(np.stack([0 * xs, 5 - ys], -1), np.float32))
     out, valid = dev.DeviceBuffer(hs * wsm * 4), dev.DeviceBuffer(hs * wsm)
-    dev.scatter_linear(f, +1, None, dev.DeviceBuffer.from_host(np.ones((hs, wsm, 1), np.float32)), 1, None, hs, wsm, None, out, valid, 0)
-    assert valid.to_host((hs, wsm), np.uint8).sum() <= wsm                  # at most the nodes ON the line
+    with pytest.raises(RuntimeError):
+        dev.scatter_linear(f, +1, None, dev.DeviceBuffer.from_host(np.ones((hs, wsm, 1), np.float32)), 1, None, hs, wsm, None, out, valid, 0)
+    assert not valid.to_host((hs, wsm), np.uint8).any()
+
+
+def test_block_collapsed_onto_one_pixel_matches_scipy(gpu, oracle):
+    """A flow that sends a whole 70 x 70 block of a 96 x 128 image to ONE position is legal input to Flow.apply: scipy's
+    griddata (Qhull option Qc: coincident points are one vertex) triangulates the 7 389 distinct sites, and so does the
+    Delaunay path -- 4 900 coincident points are one bucket far beyond the pairwise dedupe, which a hash table of positions
+    reduces to its smallest index.  Masks bit-exact; values exact wherever SciPy's triangulation is unique and does not
+    touch the collapsed vertex (whose value is that of whichever duplicate Qhull happened to keep)."""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(31)
+    shape = (96, 128)
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float32)
+    vecs = of.from_transforms([['rotation', 60, 50, 7], ['scaling', 30, 40, 1.04]], list(shape), 's') + wobble(shape, 0.6, 0.5)
+    vecs[10:80, 20:90, 0] = 55.25 - xx[10:80, 20:90]
+    vecs[10:80, 20:90, 1] = 45.5 - yy[10:80, 20:90]
+    img = rng.random(shape + (3,), dtype=np.float32)
+    f = of.Flow(vecs, 's')
+    got, valid = f.apply(img, return_valid_area=True)
+    want, wvalid = O.OFlow(vecs, 's').apply(img, return_valid_area=True)
+    np.testing.assert_array_equal(valid, wvalid)
+    np.testing.assert_array_equal(f.valid_target(), wvalid)
+    assert valid.mean() > 0.5
+    amb, inside = nonunique_nodes(warped_points(vecs), shape)
+    assert 0.2 < amb.mean() < 0.5 and (inside & ~amb).mean() > 0.3    # the fan around the collapsed vertex fills the block's old place; the rest is unique
+    bad = ~np.isclose(got, want, rtol=RTOL, atol=ATOL).all(-1)
+    assert not (bad & ~amb).any(), (int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:5].tolist())
+    # a second, smaller collapse (below the hash-table threshold: pairwise dedupe) next to it, and determinism
+    vecs[82:92, 100:112, 0] = 108.5 - xx[82:92, 100:112]
+    vecs[82:92, 100:112, 1] = 88.25 - yy[82:92, 100:112]
+    f = of.Flow(vecs, 's')
+    np.testing.assert_array_equal(f.valid_target(), O.OFlow(vecs, 's').valid_target())
+    a, b = f.apply(img), f.apply(img)
+    np.testing.assert_array_equal(a, b)
 
 
 def test_delaunay_path_without_counts(gpu, golden2):
@@ -574,3 +607,43 @@ def test_exact_path_random_fields_against_scipy(gpu, oracle, near2_always):
         bad = ~np.isclose(got, want[..., :C], rtol=RTOL, atol=ATOL).all(-1)
         assert not (bad & ~amb).any(), (it, h, w, int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:4].tolist())
         assert amb.mean() < 0.2, (it, amb.mean())
+
+
+def test_certified_field_the_walk_cannot_follow(gpu, oracle):
+    """A certificate proves that the mesh is the triangulation, not that the walk kernel's Newton steps reach every node's
+    triangle: x' = g(x), y' = g(y) with g' between 0.03 and 1.97 keeps every cell a positively oriented rectangle (a tensor
+    grid IS its own Delaunay triangulation) and the border straight, and squeezes a third of the image into a sliver.
+    Whatever the walk kernel loses (its failure counter says how many nodes) is recomputed on the Delaunay path -- through
+    the one-shot C entry and through the Flow API with its cached certificate alike -- and the result is SciPy's."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev
+    nat, lib = of.native, of.native.load()
+    h, w = 64, 96
+    yy, xx = np.mgrid[:h, :w].astype(np.float64)
+    g = lambda t, L: -0.97 * np.sin(2 * np.pi * t / (L - 1)) * (L - 1) / (2 * np.pi)
+    vecs = np.stack([g(xx, w), g(yy, h)], -1).astype(np.float32)
+    c = certify(of, vecs)
+    assert c.certified == 1, (c.folded_cells, c.bad_edges, c.border_dev)
+    f = dev.DeviceBuffer.from_host(vecs)
+    out, valid, cnt = dev.DeviceBuffer(h * w * 8), dev.DeviceBuffer(h * w), dev.DeviceBuffer.zeros(16)
+    nat.check(lib.ofl_scatter_certified_dev(f.ptr, 1, 0, f.ptr, 2, None, h, w, 0, h, out.ptr, valid.ptr, 0, ctypes.byref(c), cnt.ptr, None))
+    lost = int(cnt.to_host((1,), np.uint32)[0])
+    print("walk kernel lost", lost, "of", h * w, "nodes on the squeezed tensor grid")
+    want = O.scatter_griddata(vecs, np.concatenate([vecs, np.ones((h, w, 1), np.float32)], -1), None)
+    # one-shot entry: certificate, walk, counter, Delaunay path if needed
+    ws = dev._workspace(h, w, 2)
+    info = (ctypes.c_uint64 * 3)()
+    nat.check(lib.ofl_scatter_linear_dev(f.ptr, 1, 0, None, f.ptr, 2, None, h, w, None, out.ptr, valid.ptr, 0, ws.ptr, ws.nbytes, info, None))
+    got, gv = out.to_host((h, w, 2), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+    np.testing.assert_array_equal(gv, want[..., 2] == 1)
+    np.testing.assert_allclose(got, want[..., :2], rtol=RTOL, atol=ATOL)
+    # Flow API (cached certificate, checked on its first use)
+    fl = of.Flow(vecs, 's')
+    wv, wm = fl.apply(of.Flow(vecs, 's')).vecs, fl.valid_target()
+    np.testing.assert_array_equal(wm, want[..., 2] == 1)
+    np.testing.assert_allclose(wv, want[..., :2], rtol=RTOL, atol=ATOL)
+    d = fl.to_device()
+    r1, r2 = d.apply(d).to_host(), d.apply(d).to_host()          # second call: the cached decision
+    np.testing.assert_array_equal(r1[0], r2[0])
+    np.testing.assert_allclose(r1[0], want[..., :2], rtol=RTOL, atol=ATOL)
+    assert lost == 0 or d.mesh_cert(+1).certified == 0

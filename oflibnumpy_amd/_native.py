@@ -23,7 +23,8 @@ STAT_NONZERO_MASKED, STAT_NONZERO_TH_MASKED, STAT_NONZERO, STAT_NONZERO_TH, STAT
 class MeshCert(ctypes.Structure):
     """ofl_mesh_cert of include/ofl.h"""
     _fields_ = [("certified", ctypes.c_uint32), ("folded_cells", ctypes.c_uint32), ("bad_edges", ctypes.c_uint32),
-                ("dropped", ctypes.c_uint32), ("border_dev", ctypes.c_double), ("corner", (ctypes.c_double * 2) * 4)]
+                ("dropped", ctypes.c_uint32), ("border_dev", ctypes.c_double), ("corner", (ctypes.c_double * 2) * 4),
+                ("diag_bits", ctypes.c_void_p)]
 
 
 class NativeError(RuntimeError):
@@ -81,7 +82,8 @@ SIGNATURES = {
     "ofl_scatter_linear_f64_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_rows_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_linear_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
-    "ofl_scatter_certify_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _ci, _vp, _cs, _vp, _vp]),
+    "ofl_scatter_diag_bytes": (_ci, [_ci, _ci, ctypes.POINTER(_cs)]),
+    "ofl_scatter_certify_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _ci, _vp, _cs, _vp, _vp, _vp]),
     "ofl_scatter_certified_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp]),
     "ofl_scatter_workspace_bytes": (_ci, [_ci, _ci, _ci, ctypes.POINTER(_cs)]),
     "ofl_scatter_linear": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci]),

@@ -25,6 +25,14 @@ namespace {
 
 constexpr size_t kMinWorkspace = 4096;            // the certificate's device record (first 256 bytes) + the walk kernel's failure counter
 constexpr size_t kWalkFailAt   = 1024;            // byte offset of that counter
+size_t diag_bytes(int H, int W) { return (size_t)H * (size_t)((W + 31) / 32) * 4; }     // the certificate's diagonal bit-plane
+// The one-shot entries keep the plane at the END of the workspace (the Delaunay path carves from the front and is only
+// entered when the certificate fails or the walk loses nodes -- by then the plane is no longer needed).
+uint32_t *diag_in(void *workspace, size_t workspace_bytes, int H, int W)
+{
+    const size_t need = (diag_bytes(H, W) + 255) / 256 * 256;
+    return workspace_bytes >= kMinWorkspace + need ? (uint32_t *)((char *)workspace + (workspace_bytes - need) / 256 * 256) : nullptr;
+}
 
 // A certificate proves that the cell-wise mesh IS the Delaunay triangulation, not that the walk kernel's Newton steps find
 // every node's triangle in it (a certified field may compress 99 % of the image into a corner): the kernel counts the nodes
@@ -64,7 +72,7 @@ int scatter_grid_impl(const char *who, const float *flow, int sign, int point_pr
         return fail(OFL_E_INVALID, "%s: rows [%d, %d) outside the %d-row grid", who, row0, row0 + rows, H);
     if (!(valid_rule & OFL_SCATTER_UNCERTIFIED)) {
         ofl_mesh_cert cert;
-        OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));       // a point mask without zeros drops nothing
+        OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, diag_in(workspace, workspace_bytes, H, W), s));       // a point mask without zeros drops nothing
         if (cert.certified) {
             uint32_t *fail = (uint32_t *)((char *)workspace + kWalkFailAt), n_fail = 0;
             OFL_HIP(hipMemsetAsync(fail, 0, 4, s));
@@ -89,7 +97,7 @@ int scatter_query_impl(const char *who, const float *flow, int sign, int point_p
     OFL_TRY(check_common(who, flow, sign, point_precision, C, vals, out, valid, valid_rule, H, W, workspace, workspace_bytes));
     if (!(valid_rule & OFL_SCATTER_UNCERTIFIED)) {
         ofl_mesh_cert cert;
-        OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, s));
+        OFL_TRY(certify_mesh(flow, sign, pmask, H, W, workspace, &cert, nullptr, s));
         if (cert.certified) {
             uint32_t *fail = (uint32_t *)((char *)workspace + kWalkFailAt), n_fail = 0;
             OFL_HIP(hipMemsetAsync(fail, 0, 4, s));
@@ -116,6 +124,7 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes)
     if (H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_workspace_bytes: bad shape");
     *bytes = kMinWorkspace;
     if ((long long)H * W < (1ll << 27)) *bytes = std::max(*bytes, exact_workspace_bytes(H, W));     // larger fields: certified meshes only
+    *bytes += (diag_bytes(H, W) + 255) / 256 * 256 + 256;                                           // + the diagonal bit-plane of the one-shot entries
     return OFL_OK;
 }
 
@@ -133,15 +142,22 @@ int ofl_scatter_linear_dev(const float *flow, int sign, int point_precision, con
                               (size_t)H * W, false, out, valid, valid_rule, workspace, workspace_bytes, info_host, s);
 }
 
+int ofl_scatter_diag_bytes(int H, int W, size_t *bytes)
+{
+    if (!bytes || H <= 0 || W <= 0) return fail(OFL_E_INVALID, "ofl_scatter_diag_bytes: bad arguments");
+    *bytes = diag_bytes(H, W);
+    return OFL_OK;
+}
+
 int ofl_scatter_certify_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask, int H, int W,
-                            void *workspace, size_t workspace_bytes, ofl_mesh_cert *cert_host, void *stream)
+                            void *workspace, size_t workspace_bytes, ofl_mesh_cert *cert_host, uint32_t *diag_bits, void *stream)
 {
     OFL_TRY(need_device());
     if (!flow || !workspace || !cert_host || workspace_bytes < 256) return fail(OFL_E_INVALID, "ofl_scatter_certify: NULL pointer / workspace < 256 bytes");
     if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 29)) return fail(OFL_E_INVALID, "ofl_scatter_certify: H*W must be in [1, 2^29)");
     if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_certify: sign must be +1 or -1");
     if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_certify: bad point_precision");
-    return certify_mesh(flow, point_precision ? 2 * sign : sign, pmask, H, W, workspace, cert_host, stream_of(stream));
+    return certify_mesh(flow, point_precision ? 2 * sign : sign, pmask, H, W, workspace, cert_host, diag_bits, stream_of(stream));
 }
 
 int ofl_scatter_certified_dev(const float *flow, int sign, int point_precision, const float *vals, int C,

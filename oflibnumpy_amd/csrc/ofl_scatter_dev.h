@@ -150,8 +150,9 @@ __device__ __forceinline__ void resolve_emit(const VT *__restrict__ vals, int C,
 }
 
 // host side of the certified fast path (ofl_scatter_walk.hip); sign_pp = sign with the point precision folded in (+-1 / +-2)
+// diag_bits (device, H * ((W + 31) / 32) words, or NULL): receives the Delaunay diagonal of every cell, one bit each
 int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, void *scratch256,
-                 ofl_mesh_cert *cert, hipStream_t s);
+                 ofl_mesh_cert *cert, uint32_t *diag_bits, hipStream_t s);
 template <typename VT>
 int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uint8_t *vmask, int H, int W,
                 int row0, int rows, VT *out, uint8_t *valid, int valid_rule, const ofl_mesh_cert *cert,

@@ -32,7 +32,7 @@ struct CertDev {                       // device record written by the certify k
 };
 static_assert(sizeof(CertDev) == 16 + 64 + 64, "CertDev layout");
 
-struct WalkCert { D2 c[4]; double delta; };
+struct WalkCert { D2 c[4]; double delta; const uint32_t *diag; int diag_stride; };
 
 __device__ __forceinline__ unsigned long long okey(double d)
 {
@@ -76,17 +76,18 @@ __device__ __forceinline__ void tri_pts(int diag, int t, const D2 &pa, const D2 
 // ------------------------------------------------------------------------------------------------ certificate
 __global__ __launch_bounds__(256)
 void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
-                            CertDev *__restrict__ out)
+                            CertDev *__restrict__ out, uint32_t *__restrict__ diag_bits, int diag_stride)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const bool inpt = x < W && y < H;
-    int fold = 0, bad = 0, drop = 0;
+    int fold = 0, bad = 0, drop = 0, diag_bit = 0;
     if (inpt && pmask && !pmask[(size_t)y * W + x]) drop = 1;
     if (x < W - 1 && y < H - 1) {
         const D2 pa = point_of(flow, sign, W, x, y), pb = point_of(flow, sign, W, x + 1, y);
         const D2 pc = point_of(flow, sign, W, x + 1, y + 1), pd = point_of(flow, sign, W, x, y + 1);
         const int diag = pick_diagonal(pa, pb, pc, pd);
+        diag_bit = diag;
         D2 u0, u1, u2, v0, v1, v2;
         tri_pts(diag, 0, pa, pb, pc, pd, u0, u1, u2);
         tri_pts(diag, 1, pa, pb, pc, pd, v0, v1, v2);
@@ -115,6 +116,13 @@ void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint
                 if (incircle_rel(t1 ? v0 : u0, t1 ? v1 : u1, t1 ? v2 : u2, opp) > kEdgeTol) bad += 1;
             }
         }
+    }
+    // The Delaunay diagonal of every cell, one bit per cell (rows padded to whole 32-bit words: a wave's two rows of 32
+    // cells are two aligned words, no atomics): the walk kernel reads the bit instead of evaluating the float64 in-circle
+    // determinant of the cell for every node that looks at it -- the same predicate on the same numbers, so the same bits out.
+    if (diag_bits) {
+        const unsigned long long m = __ballot(diag_bit != 0);
+        if ((threadIdx.x & 31) == 0 && y < H) diag_bits[(size_t)y * diag_stride + blockIdx.x] = (uint32_t)(m >> (threadIdx.x & 32));
     }
     // border: signed distance of every border point from the straight line between the two warped corners of its side
     const bool border_block = blockIdx.x == 0 || blockIdx.y == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.y == gridDim.y - 1;
@@ -197,16 +205,20 @@ __device__ __forceinline__ double rcp_newton(double d)
 // edge functions; the certificate guarantees convex, positively oriented cells, so the Delaunay diagonal is one
 // in-circle sign).  On a miss the affine map of the less-missed triangle turns the position into a new estimate
 // (ex, ey) of its source index (a Newton step on the piecewise-affine map).
-template <int SP>
+template <int SP, bool BITS>
 __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, int cx, int cy,
-                                         double qx, double qy, Hit &h, double &ex, double &ey)
+                                         double qx, double qy, Hit &h, double &ex, double &ey, const WalkCert &wc)
 {
     const uint32_t i00 = (uint32_t)cy * (uint32_t)W + (uint32_t)cx;          // H * W < 2^29
     const Pair2 r0 = *reinterpret_cast<const Pair2 *>(flow + 2 * (size_t)i00);
     const Pair2 r1 = *reinterpret_cast<const Pair2 *>(flow + 2 * (size_t)(i00 + (uint32_t)W));
     const D2 pa = warp_pt<SP>(cx, cy, r0.lo_u, r0.lo_v), pb = warp_pt<SP>(cx + 1, cy, r0.hi_u, r0.hi_v);
     const D2 pc = warp_pt<SP>(cx + 1, cy + 1, r1.hi_u, r1.hi_v), pd = warp_pt<SP>(cx, cy + 1, r1.lo_u, r1.lo_v);
-    const int diag = incircle(pa, pb, pc, pd) > 0 ? 1 : 0;             // as pick_diagonal for a convex, positive cell
+    // the cell's Delaunay diagonal: from the certificate's bit-plane, or (no plane given) as pick_diagonal decides it for a
+    // convex, positive cell
+    int diag;
+    if (BITS) diag = (int)((wc.diag[(size_t)cy * wc.diag_stride + (cx >> 5)] >> (cx & 31)) & 1u);
+    else      diag = incircle(pa, pb, pc, pd) > 0 ? 1 : 0;
     // triangle 0 = (a, b, c) or (b, c, d); its vertex-1 coordinate w1 vanishes on the cell's diagonal, so w1 also tells
     // on which side of the diagonal the position lies: the second triangle is only evaluated when it can matter
     int t = 0;
@@ -253,8 +265,9 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
     return false;
 }
 
-template <int SP>      // the position (qx, qy) starts from the grid node (x, y) next to it (a grid node: itself)
-__device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int H, int W, int x, int y, double qx, double qy, Hit &h)
+template <int SP, bool BITS>      // the position (qx, qy) starts from the grid node (x, y) next to it (a grid node: itself)
+__device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int H, int W, int x, int y, double qx, double qy, Hit &h,
+                                            const WalkCert &wc)
 {
     // first estimate of the source index: one Newton step from the node itself, i = q - J^-1 (P(q) - q), with the
     // Jacobian J = I + s * grad f from the differences to the node's right / lower neighbours (exact for affine fields;
@@ -279,7 +292,7 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
         const int cx = (int)fmin(fmax(floor(ex), 0.0), (double)(W - 2)), cy = (int)fmin(fmax(floor(ey), 0.0), (double)(H - 2));
         if ((cx == pcx && cy == pcy) || (cx == ppcx && cy == ppcy)) break;      // no progress / a 2-cycle across an edge
         ppcx = pcx; ppcy = pcy; pcx = cx; pcy = cy;
-        if (try_cell<SP>(flow, W, cx, cy, qx, qy, h, ex, ey)) return true;
+        if (try_cell<SP, BITS>(flow, W, cx, cy, qx, qy, h, ex, ey, wc)) return true;
     }
     // the estimate stopped moving without a hit (a node outside the mesh ends here, clamped to a border cell; a node on
     // a cell edge may alternate between its two sides): the cells around the last two stops decide
@@ -291,7 +304,7 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
             for (int ox = -1; ox <= 1; ++ox) {
                 const int cx = bx + ox, cy = by + oy;
                 if (cx < 0 || cy < 0 || cx > W - 2 || cy > H - 2) continue;
-                if (try_cell<SP>(flow, W, cx, cy, qx, qy, h, dx, dy)) return true;
+                if (try_cell<SP, BITS>(flow, W, cx, cy, qx, qy, h, dx, dy, wc)) return true;
             }
     }
     return false;
@@ -365,7 +378,7 @@ __device__ bool hull_band_locate(const float *__restrict__ flow, int sign, int H
 #ifndef OFL_WALK_WAVES
 #define OFL_WALK_WAVES 5      // waves per SIMD the allocator leaves room for: the kernel is VALU-bound (5: 156 us, 7: 159 us, 8 spills: 246 us at 4K)
 #endif
-template <typename VT, int SP>
+template <typename VT, int SP, bool BITS>
 __global__ __launch_bounds__(256, OFL_WALK_WAVES)
 void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ vals, int C,
                          const uint8_t *__restrict__ vmask, int H, int W, int row0, int rows,
@@ -378,7 +391,7 @@ void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ 
     const size_t o = (size_t)yl * W + x;
     Hit h;
     const int sign = SP;
-    bool found = walk_locate<SP>(flow, H, W, x, y, (double)x, (double)y, h);
+    bool found = walk_locate<SP, BITS>(flow, H, W, x, y, (double)x, (double)y, h, wc);
     if (!found) found = hull_band_locate(flow, sign, H, W, wc, (double)x, (double)y, h, fail);
     if (found) {
         const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
@@ -406,7 +419,7 @@ void scatter_walk_query_kernel(const float *__restrict__ flow, const float *__re
         bool found = false;
         if (qx == qx && qy == qy) {
             const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
-            found = walk_locate<SP>(flow, H, W, nx, ny, qx, qy, h);
+            found = walk_locate<SP, false>(flow, H, W, nx, ny, qx, qy, h, wc);
             if (!found) found = hull_band_locate(flow, SP, H, W, wc, qx, qy, h, fail);
         }
         if (SPARSE) {
@@ -431,7 +444,7 @@ namespace ofl_sc {
 
 // host side of the certificate: launch, ONE small read-back, evaluation
 int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, void *scratch128,
-                 ofl_mesh_cert *cert, hipStream_t s)
+                 ofl_mesh_cert *cert, uint32_t *diag_bits, hipStream_t s)
 {
     memset(cert, 0, sizeof(*cert));
     if (H < 2 || W < 2) return OFL_OK;                                   // no cells: never certified
@@ -441,7 +454,8 @@ int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, in
     CertDev *dev = (CertDev *)scratch128;
     OFL_HIP(hipMemcpyAsync(dev, &init, sizeof(init), hipMemcpyHostToDevice, s));
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
-    hipLaunchKernelGGL(scatter_certify_kernel, grid, block, 0, s, flow, sign_pp, pmask, H, W, dev);
+    hipLaunchKernelGGL(scatter_certify_kernel, grid, block, 0, s, flow, sign_pp, pmask, H, W, dev, diag_bits, (W + 31) / 32);
+    cert->diag_bits = diag_bits;
     OFL_HIP(hipGetLastError());
     CertDev r;
     OFL_HIP(hipMemcpyAsync(&r, dev, sizeof(r), hipMemcpyDeviceToHost, s));
@@ -473,12 +487,15 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
     WalkCert wc;
     for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
     wc.delta = cert->border_dev;
+    wc.diag = cert->diag_bits; wc.diag_stride = (W + 31) / 32;
     const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
     // (a variant that took flow-valued targets straight from the corner loads was measured SLOWER -- 168 vs 157 us at 4K:
     // its selects cost more registers than the three cached reloads it saved)
-#define OFL_WALK_LAUNCH(SP)                                                                                             \
-    hipLaunchKernelGGL((scatter_walk_kernel<VT, SP>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, out,  \
-                       valid, valid_rule, wc, fail_dev)
+#define OFL_WALK_LAUNCH(SP)                                                                                                       \
+    do { if (wc.diag) hipLaunchKernelGGL((scatter_walk_kernel<VT, SP, true>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, \
+                                         out, valid, valid_rule, wc, fail_dev);                                                          \
+         else hipLaunchKernelGGL((scatter_walk_kernel<VT, SP, false>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, out,  \
+                                 valid, valid_rule, wc, fail_dev); } while (0)
     if (sign_pp == 1) OFL_WALK_LAUNCH(1); else if (sign_pp == -1) OFL_WALK_LAUNCH(-1);
     else if (sign_pp == 2) OFL_WALK_LAUNCH(2); else OFL_WALK_LAUNCH(-2);
 #undef OFL_WALK_LAUNCH
@@ -493,6 +510,7 @@ int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, 
     WalkCert wc;
     for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
     wc.delta = cert->border_dev;
+    wc.diag = nullptr; wc.diag_stride = 0;
     if (n == 0) return OFL_OK;
     const size_t nb = (n + 255) / 256;
     const dim3 grid((unsigned)(nb < (1u << 20) ? nb : (1u << 20))), block(256);

@@ -358,8 +358,15 @@ class DeviceFlow:
             h, w = self.shape
             c = nat.MeshCert()
             ws = _workspace(h, w, 0)
+            nb = ctypes.c_size_t(0)
+            nat.check(_lib().ofl_scatter_diag_bytes(h, w, ctypes.byref(nb)))
+            bits = DeviceBuffer(nb.value)          # the cells' Delaunay diagonals, read by the walk kernel; lives with the certificate
             nat.check(_lib().ofl_scatter_certify_dev(self.vecs.ptr, sign, point_precision, None, h, w, ws.ptr, ws.nbytes,
-                                                     ctypes.byref(c), None))
+                                                     ctypes.byref(c), bits.ptr, None))
+            if c.certified:
+                c._diag_buf = bits
+            else:
+                c.diag_bits = None
             self._certs[key] = c
         return c
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 2e-5
 
 
-def certify(of, vecs, sign=1, pmask=None, pp=0):
+def certify(of, vecs, sign=1, pmask=None, pp=0, with_bits=True):
     from oflibnumpy_amd import device as dev
     nat, lib = of.native, of.native.load()
     h, w = vecs.shape[:2]
@@ -28,8 +28,12 @@ def certify(of, vecs, sign=1, pmask=None, pp=0):
     pm = dev.DeviceBuffer.from_host(pmask.astype(np.uint8)) if pmask is not None else None
     ws = dev._workspace(h, w, 0)
     c = nat.MeshCert()
+    nb = ctypes.c_size_t(0)
+    nat.check(lib.ofl_scatter_diag_bytes(h, w, ctypes.byref(nb)))
+    bits = dev.DeviceBuffer(nb.value) if with_bits else None
     nat.check(lib.ofl_scatter_certify_dev(f.ptr, sign, pp, pm.ptr if pm is not None else None, h, w, ws.ptr, ws.nbytes,
-                                          ctypes.byref(c), None))
+                                          ctypes.byref(c), bits.ptr if bits is not None else None, None))
+    c._diag_buf = bits          # the plane must outlive the certificate
     return c
 
 
@@ -647,3 +651,32 @@ def test_certified_field_the_walk_cannot_follow(gpu, oracle):
     np.testing.assert_array_equal(r1[0], r2[0])
     np.testing.assert_allclose(r1[0], want[..., :2], rtol=RTOL, atol=ATOL)
     assert lost == 0 or d.mesh_cert(+1).certified == 0
+
+
+def test_diagonal_bit_plane_changes_nothing(gpu):
+    """The certificate's per-cell diagonal bits (ofl_scatter_certify_dev, diag_bits) replace the walk kernel's per-node
+    float64 in-circle determinant: the same predicate on the same numbers, so outputs with and without the plane are
+    bit-identical -- on a similarity (every cell co-circular to rounding: the decision is a coin flip of the last bit, and
+    must be the SAME coin), an exact lattice and a generic affine map, both signs, at a size with partial words per row."""
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    nat, lib = of.native, of.native.load()
+    rng = np.random.default_rng(3)
+    shape = (61, 77)
+    h, w = shape
+    fields = [of.from_transforms([['rotation', 30, 25, 33]], list(shape), 's'), of.from_transforms([['translation', 3, -2]], list(shape), 's'),
+              of.from_transforms([['scaling', 10, 20, 0.8], ['rotation', 40, 30, -17]], list(shape), 's'), affine_field(shape, 0.15, 0.2, -0.1, 0.25, 1.3, -0.4)]
+    for vecs in fields:
+        for sign in (1, -1):
+            outs = []
+            for with_bits in (True, False):
+                c = certify(of, vecs, sign, with_bits=with_bits)
+                assert c.certified == 1 and bool(c.diag_bits) == with_bits
+                vals = rng.standard_normal((h, w, 3)).astype(np.float32) if not outs else vals
+                f, dv = dev.DeviceBuffer.from_host(np.ascontiguousarray(vecs, np.float32)), dev.DeviceBuffer.from_host(vals)
+                out, valid, cnt = dev.DeviceBuffer(h * w * 12), dev.DeviceBuffer(h * w), dev.DeviceBuffer.zeros(16)
+                nat.check(lib.ofl_scatter_certified_dev(f.ptr, sign, 0, dv.ptr, 3, None, h, w, 0, h, out.ptr, valid.ptr, 0, ctypes.byref(c), cnt.ptr, None))
+                assert int(cnt.to_host((1,), np.uint32)[0]) == 0
+                outs.append((out.to_host((h, w, 3), np.float32), valid.to_host((h, w), np.uint8)))
+            np.testing.assert_array_equal(outs[0][0], outs[1][0])
+            np.testing.assert_array_equal(outs[0][1], outs[1][1])

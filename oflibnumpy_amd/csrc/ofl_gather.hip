@@ -147,7 +147,7 @@ struct C3Args {
     float *out; uint8_t *mout; uint32_t *stats;
     int sign, H, W, tiles_x, tiles_per_field, ntiles;
     float th;
-    int swz_group;         // one-shot kernel: workgroups per XCD-swizzle group (0 = natural order)
+    int swz_group;         // default kernel: tile rows one XCD owns per group (<= 1: natural order); one-shot variant: workgroups per XCD-swizzle group
     int xpose_rows;        // transposed-gather kernel: source rows a streamed 128-px segment may cross on the direct path
 #ifdef OFL_EXPERIMENTS
     int ablate;            // OFL_C3_ABLATE (experiments build only): 1 = skip the gather, 2 = skip the stores, ...
@@ -510,6 +510,7 @@ __device__ __forceinline__ int wave_minmax(int v)
 // per pixel, bit-identical results; axis-aligned fields keep the direct path.
 constexpr int kXpRowF2 = 128 + 4;             // LDS row stride in float2 (padding spreads the 8 rows over the banks)
 constexpr int kXposeRows = 6;                 // source rows one streamed 128-px segment may cross before we transpose
+constexpr int kC3XcdRows = 1;                 // vertically adjacent tiles one XCD owns per dispatch group (1 = natural tile order)
 
 template <int QUANT, bool STATS>
 __device__ __forceinline__ void c3_sample_block(const C3Args &a, const float *__restrict__ fa, const uint8_t *__restrict__ ma,
@@ -586,7 +587,22 @@ void compose3_xpose_kernel(const C3Args a)
     static_assert(kC3LanesX == 32, "the transposed form assumes 128 x 8 tiles");
     __shared__ __attribute__((aligned(16))) float2 xp_v[8 * kXpRowF2];
     __shared__ __attribute__((aligned(16))) uint8_t xp_ok[8 * 128];
-    const int tile = blockIdx.x;
+    // Block -> tile.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), each with its own L2.
+    // In natural tile order the tile BELOW a tile is tiles_x blocks later and on another XCD, so the source rows the two
+    // share (bilinear halo; for a rotated sampling grid most of their cache lines) are fetched once per XCD.  With
+    // swz_group = R > 1 a group of 8 R consecutive blocks covers 8 tile columns x R tile rows and XCD x owns column x of
+    // it: R vertically adjacent tiles, dispatched 8 blocks apart, meet in ONE L2 -- while all XCDs still sweep the same
+    // window of memory (whole-field contiguous runs per XCD were measured slower).
+    int tile = blockIdx.x;
+    if (a.swz_group > 1) {
+        const int R = a.swz_group, per = 8 * R;
+        const int g = blockIdx.x / per, i = blockIdx.x - g * per;
+        const int tiles_y = a.tiles_per_field / a.tiles_x, n_gx = (a.tiles_x + 7) >> 3, n_gy = (tiles_y + R - 1) / R;
+        const int fld = g / (n_gx * n_gy), gg = g - fld * (n_gx * n_gy), gy = gg / n_gx, gx = gg - gy * n_gx;
+        const int ty = gy * R + (i >> 3), tx = gx * 8 + (i & 7);
+        if (tx >= a.tiles_x || ty >= tiles_y) return;
+        tile = fld * a.tiles_per_field + ty * a.tiles_x + tx;
+    }
     if (tile >= a.ntiles) return;
     C3Stat st = { 0.0f, 0.0f, 0.0f };
     const C3Stream in = c3_load_stream<kC3LanesX>(a, tile);
@@ -1448,6 +1464,10 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
         long long nt = (long long)tiles_x * tiles_y * batch;
         if (nt > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
         static const int xpose_rows = OFL_KNOB_INT("OFL_C3_XPOSE_ROWS", kXposeRows);
+        static const int xcd_rows = OFL_KNOB_INT("OFL_C3_XCD_ROWS", kC3XcdRows);       // tile rows one XCD owns per group (see the kernel)
+        const long long n_groups = (long long)batch * ((tiles_x + 7) / 8) * ((tiles_y + xcd_rows - 1) / xcd_rows);
+        const long long nblk = xcd_rows > 1 ? n_groups * 8 * xcd_rows : nt;
+        if (nblk > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3: too many tiles");
 #ifdef OFL_EXPERIMENTS
         // A/B variants: OFL_C3_VARIANT = 2 the same without the transposition, 0 persistent grid with stream prefetch,
         // 1 source tile staged in LDS; OFL_C3_ABLATE switches parts of the kernel off, OFL_C3_SWZ tries XCD-aware tile orders
@@ -1459,17 +1479,17 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
             tiles_x = (W + 4 * kLdsLX - 1) / (4 * kLdsLX); tiles_y = (H + 256 / kLdsLX - 1) / (256 / kLdsLX);
             nt = (long long)tiles_x * tiles_y * batch;
         }
-        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, swz, xpose_rows, ablate };
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, variant == 3 ? xcd_rows : swz, xpose_rows, ablate };
         int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr, use_lds);      // persistent variants: what the chip keeps resident
         if (grid > (int)nt) grid = (int)nt;
         if (grid >= 8) grid &= ~7;
 #define OFL_C3(Q, S) do { if (use_lds) hipLaunchKernelGGL((compose3_lds_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
                           else if (variant == 2) hipLaunchKernelGGL((compose3_oneshot_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); \
                           else if (variant == 0) hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
-                          else hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a); } while (0)
+                          else hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nblk), dim3(256), 0, s, a); } while (0)
 #else
-        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, 0, xpose_rows };
-#define OFL_C3(Q, S) hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nt), dim3(256), 0, s, a)
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, xcd_rows, xpose_rows };
+#define OFL_C3(Q, S) hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nblk), dim3(256), 0, s, a)
 #endif
         if (quant == OFL_QUANT_OPENCV) { if (stats) OFL_C3(OFL_QUANT_OPENCV, true); else OFL_C3(OFL_QUANT_OPENCV, false); }
         else                           { if (stats) OFL_C3(OFL_QUANT_EXACT, true);  else OFL_C3(OFL_QUANT_EXACT, false); }

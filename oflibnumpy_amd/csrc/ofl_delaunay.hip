@@ -484,6 +484,7 @@ void dl_big_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bstar
     const unsigned T = dl_big_size(head, cap), mask = T - 1;
     const Grid g = head->grid;
     const PosFn pos(flow, sign, W);
+    n_entries = bstart[(size_t)g.gx * g.gy];                   // the filled part of `sorted`
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n_entries; j += (size_t)gridDim.x * 256) {
         const unsigned c = sorted[j];
         if (c == 0xFFFFFFFFu) continue;
@@ -606,10 +607,10 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
 }
 
 // ------------------------------------------------------------------------------------------------ stars, clip pass (near)
-// One thread per point the cells and fans did not settle.  The list is compacted in BUCKET order (the order of `sorted`), not
-// in index order: 64 consecutive entries are neighbours in the plane, whatever the field does -- on a folded field (BASELINE
-// config 5) the sites of one source row lie hundreds of buckets apart -- so the ring searches of a wave read the same
-// candidates.  A star does not depend on the order in which stars are built.
+// One thread per point the cells and fans did not settle, in index order.  (Round 3 measured two spatially coherent
+// schedules for BASELINE config 5, whose source rows scatter over hundreds of buckets: one wave per 8 x 8 bucket tile -- half
+// empty waves, 24 -> 46 ms -- and a list compacted in bucket order -- no change: the pass is bound by the divergent clip
+// code of its 64 lanes, not by where the candidates come from.)
 __global__ __launch_bounds__(64)
 void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, const unsigned char *__restrict__ dup, int H, int W,
                          const DlHead *__restrict__ head, const unsigned *__restrict__ todo,
@@ -703,14 +704,15 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
 
 // compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx,
 // MODE 2 = points with deg == kDegFan -> todo_idx (what the cell pass left to the fan pass),
-// MODE 3 = entries j of `sorted` (src; aux = deg) whose point has deg == kDegTodo -> their POINT indices, in bucket order, for the clip pass
+// MODE 3 = points with deg == kDegTodo -> the clip pass's list (a list in BUCKET order -- entries of `sorted` -- was measured:
+// no faster on any field, BASELINE config 5 included, and its compaction costs 0.2 ms more at 4K: the gather of deg[sorted[j]])
 // MODE 1 also lists the ranks the wave pass finished beyond kMidRings coarse rings (aux = far_wide): they are not computed
 // again, but the workgroup pass searches the coarse grid only that far around a point, and a neighbour whose own cell
 // reaches farther would otherwise be missing from its candidates.
 template <int MODE>
 __device__ __forceinline__ bool flagged(const void *src, const unsigned char *aux, size_t i)
 {
-    if (MODE == 3) { const unsigned c = ((const unsigned *)src)[i]; return c != 0xFFFFFFFFu && aux[c] == kDegTodo; }
+    if (MODE == 3) return ((const unsigned char *)src)[i] == kDegTodo;
     return MODE == 0 ? ((const unsigned char *)src)[i] == kDegFar
          : MODE == 2 ? ((const unsigned char *)src)[i] == kDegFan : (((const unsigned *)src)[i] == kDegLeft || aux[i] != 0);
 }
@@ -745,7 +747,7 @@ void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__r
     for (int k = 0; k < 8; ++k)
         if (base + k < n && flagged<MODE>(src, aux, base + k)) {
             if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
-            list[at++] = MODE == 3 ? ((const unsigned *)src)[base + k] : (unsigned)(base + k);
+            list[at++] = (unsigned)(base + k);
         }
     if (blockIdx.x == last_block && threadIdx.x == 0) {
         unsigned cnt = offs[blockIdx.x] + total;
@@ -1820,7 +1822,6 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     static const double bucket_scale = OFL_KNOB_DOUBLE("OFL_DL_BUCKET", 1.0);      // development knob (experiments build only)
     hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W);
     OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
-    OFL_HIP(hipMemsetAsync(ws.sorted, 0xFF, n * 4, s));                  // entries past the last bucket stay blank
     hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup);
     OFL_HIP(hipGetLastError());
     OFL_TRY(scan_exclusive(ws.bstart, ws.bcap + 1, ws.scan_tmp, s));
@@ -1858,11 +1859,11 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     hipLaunchKernelGGL(dl_star_fan_kernel, dim3(std::min<unsigned>((unsigned)((n + kFanBlock - 1) / kFanBlock), 16384u)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.todo_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                        (const unsigned char *)ws.dup, ws.deg, ws.nbr);
-    // what cells and fans did not settle, in BUCKET order, for the clip pass (the unfilled tail of `sorted` is 0xFFFFFFFF)
+    // what cells and fans did not settle, in index order, for the clip pass
     static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
-    hipLaunchKernelGGL(dl_flag_count_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.sorted, (const unsigned char *)ws.deg, (const DlHead *)ws.head, n, fcnt);
+    hipLaunchKernelGGL(dl_flag_count_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_flag_write_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.sorted, (const unsigned char *)ws.deg, ws.head, n, (const unsigned *)fcnt,
+    hipLaunchKernelGGL(dl_flag_write_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
                        ws.far_idx, fblk - 1, (unsigned *)nullptr);           // (far_idx is free until the unfinished points are listed)
     hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,

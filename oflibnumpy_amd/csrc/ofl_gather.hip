@@ -1007,7 +1007,7 @@ __device__ __forceinline__ T run_elem(const uint32_t (&w)[4], int i)      // i i
 
 template <typename T, int CT, bool INSIDE>
 __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8_t *__restrict__ smask, int H, int W,
-                                          const Tap &tp, const int (&wi)[4], bool fixed_u8, int arith, int rule,
+                                          const Tap &tp, const int (&wi)[4], bool fixed_u8, bool sep, int arith, int rule,
                                           bool want_valid, T (&res)[CT], bool &ok)
 {
     bool     in[4];
@@ -1053,6 +1053,28 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
             } else load_run<kRB>(pr, run[r]);
         }
     }
+    // uint8 images with cv2's 15-bit fixed-point weights: w_k = 32 (32 - ay | ay) (32 - ax | ax), so
+    //   (sum v_k w_k + 2^14) >> 15  ==  ((32 - ay) h0 + ay h1 + 512) >> 10   with   h_r = (32 - ax) v_r0 + ax v_r1
+    // exactly (32 S + 16384 = 32 (S + 512)); the weights sum to 1024, so the result needs no clamp.  Per channel: one
+    // v_perm_b32 per row puts the two taps side by side, one v_dot4_u32_u8 blends them horizontally, one multiply-add
+    // vertically -- about half the integer work of the four-tap form (which stays for the un-snapped weights).
+    bool done_sep = false;
+    if constexpr (kRun && sizeof(T) == 1) {
+        if (fixed_u8 && sep) {
+            const uint32_t wx = (uint32_t)(32 - tp.ax) | ((uint32_t)tp.ax << 8);
+            const int wy0 = 32 - tp.ay, wy1 = tp.ay;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                constexpr uint32_t kZero = 0x0C0C0000u;                       // selector bytes 2, 3: constant 0
+                const uint32_t sel = kZero | (uint32_t)c | ((uint32_t)(CT + c) << 8);
+                const uint32_t t0 = __builtin_amdgcn_perm(run[0][1], run[0][0], sel), t1 = __builtin_amdgcn_perm(run[1][1], run[1][0], sel);
+                const uint32_t h0 = __builtin_amdgcn_udot4(t0, wx, 0u, false), h1 = __builtin_amdgcn_udot4(t1, wx, 0u, false);
+                res[c] = (T)((__umul24(h0, (uint32_t)wy0) + __umul24(h1, (uint32_t)wy1) + 512u) >> 10);
+            }
+            done_sep = true;
+        }
+    }
+    if (!done_sep) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         A v[4];
@@ -1073,6 +1095,7 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
                 res[c] = finish<T>(blend4((float)v[0], (float)v[1], (float)v[2], (float)v[3], tp), arith);
             }
         }
+    }
     }
     ok = false;
     if (want_valid) {
@@ -1099,7 +1122,10 @@ __device__ __forceinline__ void gather2_core(const T *__restrict__ src, const ui
     bool inside = true, outside = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float px = map_coord(gx[j], fu[j], sign), py = map_coord(y, fv[j], sign);
+        // float32(float64(grid) +- float64(flow)) of utils.py:231-235 as ONE float32 operation: exact for integer grid
+        // coordinates below 2^15 (proof at c3_pos; the float64 form costs a dozen half-rate instructions per pixel)
+        const float px = sign >= 0 ? __fadd_rn((float)gx[j], fu[j]) : __fsub_rn((float)gx[j], fu[j]);
+        const float py = sign >= 0 ? __fadd_rn((float)y, fv[j]) : __fsub_rn((float)y, fv[j]);
         tp[j] = (quant == OFL_QUANT_OPENCV) ? make_tap<OFL_QUANT_OPENCV>(px, py) : make_tap<OFL_QUANT_EXACT>(px, py);
         if (quant == OFL_QUANT_OPENCV) {
             wi[j][0] = __mul24(32 - tp[j].ay, 32 - tp[j].ax) * 32; wi[j][1] = __mul24(32 - tp[j].ay, tp[j].ax) * 32;
@@ -1127,11 +1153,11 @@ __device__ __forceinline__ void gather2_core(const T *__restrict__ src, const ui
     } else if (__all(inside)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (act4[j]) gather_px<T, CT, true>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
+            if (act4[j]) gather_px<T, CT, true>(src, smask, H, W, tp[j], wi[j], fixed_u8, quant == OFL_QUANT_OPENCV, arith, rule, want_valid, res[j], ok[j]);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (act4[j]) gather_px<T, CT, false>(src, smask, H, W, tp[j], wi[j], fixed_u8, arith, rule, want_valid, res[j], ok[j]);
+            if (act4[j]) gather_px<T, CT, false>(src, smask, H, W, tp[j], wi[j], fixed_u8, quant == OFL_QUANT_OPENCV, arith, rule, want_valid, res[j], ok[j]);
     }
 
 }

@@ -1643,9 +1643,41 @@ __device__ bool dl_locate(const DlWs &ws, unsigned far_base, const PosFn &pos, i
                 if (x < 0 || y < 0 || x >= W || y >= H) continue;
                 id = ws.owner[(size_t)y * W + x];
             }
-    if (id == kNoOwner) return false;
-    tr = dl_decode(id, far_base, ws);
-    if (!tr.ok) return false;
+    if (id == kNoOwner) {
+        // No owned node next to the position (it lies outside the image, or the hull does not cover the image there): seed
+        // the walk from the point set instead -- the first site in growing bucket rings around the position that has a star
+        // with two consecutive real neighbours.  A position inside the hull is reached from ANY triangle.
+        const Grid g = ws.head->grid;
+        const int bx = g.bx(qx), by = g.by(qy);
+        const int rmax = max(max(bx, g.gx - 1 - bx), max(by, g.gy - 1 - by));
+        bool seeded = false;
+        for (int r = 0; r <= rmax && r <= 512 && !seeded; ++r)
+            for (int row = by - r; row <= by + r && !seeded; ++row) {
+                if (row < 0 || row >= g.gy) continue;
+                const bool full = row == by - r || row == by + r;
+                for (int part = 0; part < (full ? 1 : 2) && !seeded; ++part) {
+                    int x0 = full ? bx - r : (part ? bx + r : bx - r), x1 = full ? bx + r : x0;
+                    if (!full && (x0 < 0 || x0 >= g.gx)) continue;
+                    x0 = max(x0, 0); x1 = min(x1, g.gx - 1);
+                    if (x1 < x0) continue;
+                    for (unsigned j = ws.bstart[(size_t)row * g.gx + x0]; j < ws.bstart[(size_t)row * g.gx + x1 + 1] && !seeded; ++j) {
+                        const unsigned sidx = ws.sorted[j];
+                        if (sidx == 0xFFFFFFFFu) continue;
+                        const StarRef ss = star_of(ws, sidx);
+                        for (unsigned k = 0; k < ss.d && !seeded; ++k) {
+                            const int n0 = star_at(ss, k), n1 = star_at(ss, k + 1 == ss.d ? 0 : k + 1);
+                            if (n0 < 0 || n1 < 0 || n0 == n1) continue;
+                            tr.i0 = sidx; tr.i1 = (unsigned)n0; tr.i2 = (unsigned)n1; tr.ok = true;
+                            seeded = true;
+                        }
+                    }
+                }
+            }
+        if (!seeded) return false;
+    } else {
+        tr = dl_decode(id, far_base, ws);
+        if (!tr.ok) return false;
+    }
     unsigned a = tr.i0, b = tr.i1, c = tr.i2;
     D2 pa = pt(pos, a), pb = pt(pos, b), pc = pt(pos, c);
     if (cross2(pa, pb, pc) < 0.0) { const unsigned t = b; b = c; c = t; const D2 tp = pb; pb = pc; pc = tp; }     // counter-clockwise

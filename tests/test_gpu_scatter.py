@@ -713,3 +713,21 @@ def test_integer_targets_valid_area_s(gpu, oracle):
         inner = of.Flow(vecs, 's').valid_target() & ~amb_all
         d = np.abs(got.astype(int) - want.astype(int)).max(-1)
         assert (d[inner] <= 1).all() and (d[inner] > 0).mean() < 1e-3
+
+
+def test_track_pts_t_positions_outside_the_image(gpu, oracle):
+    """track_pts(..., 't') interpolates on the points x - f (utils.py:610-615); a flow that carries them out of the image
+    leaves query positions that are inside their convex hull but next to no grid node the triangulation covers.  griddata
+    interpolates there, and so does the query pass: its walk is seeded from the point set when no owned node is near
+    (a non-affine field, so the Delaunay path with its visibility walk answers, not the certified mesh)."""
+    of, O = gpu, oracle
+    shape = (64, 80)
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float32)
+    vecs = np.stack([-100 + 0.8 * np.sin(xx / 9) * np.cos(yy / 7), 0.6 * np.cos(xx / 8) * np.sin(yy / 6)], -1).astype(np.float32)
+    rng = np.random.default_rng(5)
+    pts = np.stack([rng.uniform(2, 60, 40), rng.uniform(103, 176, 40)], 1)          # (row, col): columns 103 .. 176 of an 80-column image
+    pts = np.concatenate([pts, [[30.0, 40.0], [-5.0, 120.0], [30.0, 500.0]]])          # and three positions outside the hull
+    got = of.track_pts(vecs, 't', pts)
+    want = O.track_pts(vecs, 't', pts.copy())
+    assert np.abs(want[:40] - pts[:40]).max() > 50                                      # they are interpolated, not dropped
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-7)

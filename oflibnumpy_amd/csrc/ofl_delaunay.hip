@@ -117,8 +117,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 size_t scan_tmp_elems(size_t n)
 {
     size_t t = 0;
-    while (n > 1) { n = (n + kScanChunk - 1) / kScanChunk; t += n; }
-    return t + 16;
+    while (n > 8192) { n = (n + 8191) / 8192; t += (n + 63) / 64 * 64; }
+    return t + 64;
 }
 
 // device-side helpers -------------------------------------------------------------------------------------------
@@ -293,14 +293,23 @@ void dl_count_kernel(const float *__restrict__ flow, int sign, const uint8_t *__
     atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
 }
 
-// exclusive scan, level by level: reduce builds the block sums bottom-up, apply scans top-down in place
+// exclusive scan in three launches: sums of 8192-element chunks, ONE workgroup scans up to 8192 of those sums in place,
+// then every chunk is scanned with its offset (round 2 walked 2048-element levels: seven launches for the bucket counts of
+// a 4K field, five for every compaction -- a dozen scans per call made 42 tiny launches)
+constexpr int kScanBig = 8192;             // elements per block: 256 threads x 32
+
 __global__ __launch_bounds__(256)
 void dl_scan_reduce_kernel(const unsigned *__restrict__ in, size_t n, unsigned *__restrict__ sums)
 {
-    const size_t base = (size_t)blockIdx.x * kScanChunk;
+    const size_t base = (size_t)blockIdx.x * kScanBig + (size_t)threadIdx.x * 32;
     unsigned v = 0;
+    if (base + 32 <= n) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(in + base);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const size_t i = base + (size_t)threadIdx.x * 8 + k; if (i < n) v += in[i]; }
+        for (int k = 0; k < 8; ++k) { const uint4 t = q[k]; v += t.x + t.y + t.z + t.w; }
+    } else {
+        for (int k = 0; k < 32; ++k) if (base + k < n) v += in[base + k];
+    }
     unsigned total;
     (void)block_exscan(v, total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
@@ -309,12 +318,55 @@ void dl_scan_reduce_kernel(const unsigned *__restrict__ in, size_t n, unsigned *
 __global__ __launch_bounds__(256)
 void dl_scan_apply_kernel(unsigned *__restrict__ data, size_t n, const unsigned *__restrict__ offsets)
 {
-    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
+    const size_t base = (size_t)blockIdx.x * kScanBig + (size_t)threadIdx.x * 32;
+    unsigned e[32], v = 0;
+    const bool whole = base + 32 <= n;
+    if (whole) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(data + base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint4 t = q[k]; e[4 * k] = t.x; e[4 * k + 1] = t.y; e[4 * k + 2] = t.z; e[4 * k + 3] = t.w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) e[k] = base + k < n ? data[base + k] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v += e[k];
+    unsigned total;
+    unsigned run = block_exscan(v, total) + (offsets ? offsets[blockIdx.x] : 0u);
+    if (whole) {
+        uint4 *q = reinterpret_cast<uint4 *>(data + base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint4 t;
+            t.x = run; run += e[4 * k]; t.y = run; run += e[4 * k + 1]; t.z = run; run += e[4 * k + 2]; t.w = run; run += e[4 * k + 3];
+            q[k] = t;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { if (base + k < n) data[base + k] = run; run += e[k]; }
+    }
+}
+
+// one workgroup of 1024: in-place exclusive scan of up to 8192 values
+__global__ __launch_bounds__(1024)
+void dl_scan_small_kernel(unsigned *__restrict__ data, unsigned n)
+{
+    __shared__ unsigned s_w[16];
+    const unsigned base = threadIdx.x * 8;
     unsigned e[8], v = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { e[k] = base + k < n ? data[base + k] : 0u; v += e[k]; }
-    unsigned total;
-    unsigned run = block_exscan(v, total) + (offsets ? offsets[blockIdx.x] : 0u);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    unsigned run = inc - v;
+    for (int k = 0; k < w; ++k) run += s_w[k];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { if (base + k < n) data[base + k] = run; run += e[k]; }
 }
@@ -452,8 +504,8 @@ void dl_dedupe_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bs
 __device__ __forceinline__ unsigned dl_big_size(const DlHead *head, unsigned long long cap)
 {
     unsigned long long t = 1024;
-    while (t < 2ull * head->n_big) t <<= 1;
-    return (unsigned)(t < cap ? t : cap);          // (cap = pool entries >= 8 n > 4 n_big: never binding)
+    while (t < 2ull * head->n_big && 2 * t <= cap) t <<= 1;   // a power of two (cap = pool entries >= 8 n > 4 n_big: never binding)
+    return (unsigned)t;
 }
 
 __device__ __forceinline__ unsigned dl_pos_hash(const P2 &q)
@@ -1796,20 +1848,13 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
 
 int scan_exclusive(unsigned *data, size_t n, unsigned *tmp, hipStream_t s)
 {
-    // levels: data (n) -> sums of 2048-element chunks -> ... -> one value
-    std::vector<std::pair<unsigned *, size_t>> lv;
-    lv.push_back({ data, n });
-    unsigned *t = tmp;
-    while (lv.back().second > 1) {
-        const size_t m = (lv.back().second + kScanChunk - 1) / kScanChunk;
-        hipLaunchKernelGGL(dl_scan_reduce_kernel, dim3((unsigned)m), dim3(256), 0, s, (const unsigned *)lv.back().first, lv.back().second, t);
-        lv.push_back({ t, m });
-        t += m;
-    }
-    OFL_HIP(hipMemsetAsync(lv.back().first, 0, 4, s));          // exclusive prefix of the single top value
-    for (size_t k = lv.size() - 1; k-- > 0;) {
-        const size_t m = (lv[k].second + kScanChunk - 1) / kScanChunk;
-        hipLaunchKernelGGL(dl_scan_apply_kernel, dim3((unsigned)m), dim3(256), 0, s, lv[k].first, lv[k].second, (const unsigned *)lv[k + 1].first);
+    if (n <= (size_t)kScanBig) {
+        hipLaunchKernelGGL(dl_scan_small_kernel, dim3(1), dim3(1024), 0, s, data, (unsigned)n);
+    } else {
+        const size_t m = (n + kScanBig - 1) / kScanBig;                // chunk sums; tmp holds them (and the next level's, recursively)
+        hipLaunchKernelGGL(dl_scan_reduce_kernel, dim3((unsigned)m), dim3(256), 0, s, (const unsigned *)data, n, tmp);
+        OFL_TRY(scan_exclusive(tmp, m, tmp + (m + 63) / 64 * 64, s));
+        hipLaunchKernelGGL(dl_scan_apply_kernel, dim3((unsigned)m), dim3(256), 0, s, data, n, (const unsigned *)tmp);
     }
     OFL_HIP(hipGetLastError());
     return OFL_OK;

@@ -32,7 +32,7 @@ struct CertDev {                       // device record written by the certify k
 };
 static_assert(sizeof(CertDev) == 16 + 64 + 64, "CertDev layout");
 
-struct WalkCert { D2 c[4]; double delta; const uint32_t *diag; int diag_stride; };
+struct WalkCert { D2 c[4]; double inv_len[4]; double delta; const uint32_t *diag; int diag_stride; };     // inv_len[k]: 1 / |c[k + 1] - c[k]|
 
 __device__ __forceinline__ unsigned long long okey(double d)
 {
@@ -345,6 +345,22 @@ __device__ bool side_scan(const float *__restrict__ flow, int sign, int H, int W
     return true;
 }
 
+// signed distance (inward > 0) of a position from the straight line of hull side k
+__device__ __forceinline__ double side_dist(const WalkCert &wc, int k, double qx, double qy)
+{
+    return cross2(wc.c[k], wc.c[(k + 1) & 3], D2{ qx, qy }) * wc.inv_len[k];
+}
+
+// Beyond the noise band of a side: outside the convex hull, whatever the mesh looks like (the certificate bounds the border's
+// deviation from the four straight sides by delta).  Asked BEFORE the search: a node out there used to run the Newton
+// steps into a border cell and fourteen cell tests around it before the same four distances said "outside" -- on BASELINE
+// config 3 (scaling 0.9: a fifth of the frame is uncovered) that was the bulk of the kernel's work.
+__device__ __forceinline__ bool clearly_outside(const WalkCert &wc, double qx, double qy)
+{
+    const double lim = -2.0 * wc.delta - 1e-12;
+    return side_dist(wc, 0, qx, qy) < lim || side_dist(wc, 1, qx, qy) < lim || side_dist(wc, 2, qx, qy) < lim || side_dist(wc, 3, qx, qy) < lim;
+}
+
 // A position no mesh triangle covers is outside the convex hull -- unless it sits within the noise band of a border
 // side, where the hull of the (almost collinear) border points decides.
 __device__ bool hull_band_locate(const float *__restrict__ flow, int sign, int H, int W, const WalkCert &wc,
@@ -354,9 +370,7 @@ __device__ bool hull_band_locate(const float *__restrict__ flow, int sign, int H
     int near_mask = 0;
 #pragma unroll
     for (int side = 0; side < 4; ++side) {
-        const D2 A = wc.c[side], B = wc.c[(side + 1) & 3];
-        const double len = sqrt((B.x - A.x) * (B.x - A.x) + (B.y - A.y) * (B.y - A.y));
-        const double d = cross2(A, B, D2{ qx, qy }) / len;            // inward > 0
+        const double d = side_dist(wc, side, qx, qy);                 // inward > 0
         if (d < -2.0 * wc.delta - 1e-12) outside = true;
         else if (d <= 2.0 * wc.delta + 1e-12) near_mask |= 1 << side;
     }
@@ -391,8 +405,11 @@ void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ 
     const size_t o = (size_t)yl * W + x;
     Hit h;
     const int sign = SP;
-    bool found = walk_locate<SP, BITS>(flow, H, W, x, y, (double)x, (double)y, h, wc);
-    if (!found) found = hull_band_locate(flow, sign, H, W, wc, (double)x, (double)y, h, fail);
+    bool found = false;
+    if (!clearly_outside(wc, (double)x, (double)y)) {
+        found = walk_locate<SP, BITS>(flow, H, W, x, y, (double)x, (double)y, h, wc);
+        if (!found) found = hull_band_locate(flow, sign, H, W, wc, (double)x, (double)y, h, fail);
+    }
     if (found) {
         const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
         resolve_emit(vals, C, vmask, vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);
@@ -417,7 +434,7 @@ void scatter_walk_query_kernel(const float *__restrict__ flow, const float *__re
         else { const float2 q = ((const float2 *)query)[i]; qx = (double)q.x; qy = (double)q.y; }
         Hit h;
         bool found = false;
-        if (qx == qx && qy == qy) {
+        if (qx == qx && qy == qy && !clearly_outside(wc, qx, qy)) {
             const int nx = (int)fmin(fmax(rint(qx), 0.0), (double)(W - 1)), ny = (int)fmin(fmax(rint(qy), 0.0), (double)(H - 1));
             found = walk_locate<SP, false>(flow, H, W, nx, ny, qx, qy, h, wc);
             if (!found) found = hull_band_locate(flow, SP, H, W, wc, qx, qy, h, fail);
@@ -487,6 +504,10 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
     WalkCert wc;
     for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
     wc.delta = cert->border_dev;
+    for (int k = 0; k < 4; ++k) {
+        const double dx = wc.c[(k + 1) & 3].x - wc.c[k].x, dy = wc.c[(k + 1) & 3].y - wc.c[k].y;
+        wc.inv_len[k] = 1.0 / sqrt(dx * dx + dy * dy);
+    }
     wc.diag = cert->diag_bits; wc.diag_stride = (W + 31) / 32;
     const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
     // (a variant that took flow-valued targets straight from the corner loads was measured SLOWER -- 168 vs 157 us at 4K:
@@ -510,6 +531,10 @@ int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, 
     WalkCert wc;
     for (int k = 0; k < 4; ++k) { wc.c[k].x = cert->corner[k][0]; wc.c[k].y = cert->corner[k][1]; }
     wc.delta = cert->border_dev;
+    for (int k = 0; k < 4; ++k) {
+        const double dx = wc.c[(k + 1) & 3].x - wc.c[k].x, dy = wc.c[(k + 1) & 3].y - wc.c[k].y;
+        wc.inv_len[k] = 1.0 / sqrt(dx * dx + dy * dy);
+    }
     wc.diag = nullptr; wc.diag_stride = 0;
     if (n == 0) return OFL_OK;
     const size_t nb = (n + 255) / 256;

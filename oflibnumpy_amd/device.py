@@ -703,13 +703,15 @@ def grid_minus(vecs, out, h, w):
 _ws_cache = {}
 
 
-def _workspace(h, w, C):
-    key = (h, w)
+def _workspace(h, w, C, stream=None):
+    """Scatter workspace for fields of this shape -- one per (shape, stream): calls on different streams may overlap, and
+    each then needs bucket lists and an owner map of its own."""
+    key = (h, w, getattr(stream, "value", stream) or 0)
     ws = _ws_cache.get(key)
     if ws is None:
         n = ctypes.c_size_t(0)
         nat.check(_lib().ofl_scatter_workspace_bytes(h, w, C, ctypes.byref(n)))
-        if len(_ws_cache) > 4:
+        if len(_ws_cache) > 6:
             _ws_cache.clear()
         ws = _ws_cache[key] = DeviceBuffer(n.value)
     return ws
@@ -738,7 +740,7 @@ def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, v
         cert.certified = 0                                  # nodes were lost: this field takes the Delaunay path from now on
     if (cert is not None and not cert.certified and pmask is None) or (drops_points and pmask is not None):
         valid_rule |= nat.SCATTER_UNCERTIFIED          # the certificate pass has been run for this field: not again per call
-    ws = _workspace(h, w, C)
+    ws = _workspace(h, w, C, stream)
     info = (ctypes.c_uint64 * 3)()
     nat.check(_lib().ofl_scatter_linear_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),
                                             h, w, ptr(query), ptr(out), ptr(valid), valid_rule, ws.ptr, ws.nbytes,
@@ -748,7 +750,7 @@ def scatter_linear(flow, sign, pmask, vals, C, vmask, h, w, query, out, valid, v
 
 def scatter_linear_f64(flow, sign, pmask, vals, C, vmask, h, w, out, valid, valid_rule, point_precision=0, stream=None):
     """K3 with float64 values at the grid nodes (float64 targets of apply_flow 's', utils.py:253-258)."""
-    ws = _workspace(h, w, C)
+    ws = _workspace(h, w, C, stream)
     info = (ctypes.c_uint64 * 3)()
     ptr = lambda b: b.ptr if b is not None else None
     nat.check(_lib().ofl_scatter_linear_f64_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),
@@ -760,7 +762,7 @@ def scatter_rows(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, 
                  point_precision=0, stream=None):
     """K3 on one row band of a field split over several GPUs (SURVEY 8e, config 5 as loaded): all inputs are the
     replicated H x W arrays; only rows [row0, row0 + rows) of the result are produced."""
-    ws = _workspace(h, w, C)
+    ws = _workspace(h, w, C, stream)
     info = (ctypes.c_uint64 * 3)()
     ptr = lambda b: b.ptr if b is not None else None
     nat.check(_lib().ofl_scatter_rows_dev(flow.ptr, sign, point_precision, ptr(pmask), ptr(vals), C, ptr(vmask),

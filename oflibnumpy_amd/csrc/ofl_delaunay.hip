@@ -700,7 +700,8 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
             }
             return 0;
         };
-        const int rc = star_near(P, (int)p, pp, g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings, &rings_done, rescue);
+        // (a tighter bound -- reach beyond 1 .. 16 times the ring search's own radius -- was measured: no further gain)
+        const int rc = star_near(P, (int)p, pp, g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings, &rings_done, rescue, 4.0 * head->far_t2);
         bool ok = rc == 1;
         for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
         if (!ok) {
@@ -745,7 +746,7 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
     const int ns = min((int)row[1], kSlots - 4);
     PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kSlots, 0 };
     const int rc = star_near2(P, p, pos(p), row + 2, ns, (int)row[14], kRings, g, bstart, sorted, sorted_xy,
-                              kNear2Rings, g1, b1start, sorted1_pt, sorted1_xy, pos, kNear2Open);
+                              kNear2Rings, g1, b1start, sorted1_pt, sorted1_xy, pos, kNear2Open, 4.0 * head->far_t2);
     if (rc != 1) continue;
     for (int k = 0; k < P.n; ++k) row[k] = (unsigned)P.T(k);
     deg[p] = (unsigned char)P.n;

@@ -680,3 +680,32 @@ def test_diagonal_bit_plane_changes_nothing(gpu):
                 outs.append((out.to_host((h, w, 3), np.float32), valid.to_host((h, w), np.uint8)))
             np.testing.assert_array_equal(outs[0][0], outs[1][0])
             np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_random_collapses_against_scipy(gpu, oracle):
+    """Seeded sweep over fields in which rectangles of 2 .. 40 pixels a side collapse onto single positions -- some onto
+    the position of a background site (duplicates across sheets), some onto each other, the largest beyond the pairwise
+    dedupe (hash table): valid areas equal SciPy's bit for bit, values agree wherever its triangulation is unique."""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(77)
+    shape = (72, 96)
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float32)
+    for it in range(6):
+        vecs = np.zeros(shape + (2,), np.float32) if it % 2 == 0 else \
+            (of.from_transforms([['rotation', 40, 30, 5.0 * it]], list(shape), 's') + wobble(shape, 0.4, 0.3))
+        for _ in range(int(rng.integers(1, 4))):
+            hh, ww = int(rng.integers(2, 41)), int(rng.integers(2, 41))
+            y0, x0 = int(rng.integers(0, shape[0] - hh)), int(rng.integers(0, shape[1] - ww))
+            # even rounds: onto a lattice node (an exact duplicate of a background site when that one stays put)
+            ty, tx = (float(rng.integers(5, shape[0] - 5)), float(rng.integers(5, shape[1] - 5))) if it % 2 == 0 else \
+                     (float(rng.uniform(5, shape[0] - 5)), float(rng.uniform(5, shape[1] - 5)))
+            vecs[y0:y0 + hh, x0:x0 + ww, 0] = tx - xx[y0:y0 + hh, x0:x0 + ww]
+            vecs[y0:y0 + hh, x0:x0 + ww, 1] = ty - yy[y0:y0 + hh, x0:x0 + ww]
+        img = rng.random(shape + (2,), dtype=np.float32)
+        f = of.Flow(vecs, 's')
+        got, valid = f.apply(img, return_valid_area=True)
+        want, wvalid = O.OFlow(vecs, 's').apply(img, return_valid_area=True)
+        np.testing.assert_array_equal(valid, wvalid, err_msg="round {}".format(it))
+        amb, inside = nonunique_nodes(warped_points(vecs), shape)
+        bad = ~np.isclose(got, want, rtol=RTOL, atol=ATOL).all(-1)
+        assert not (bad & ~amb).any(), (it, int((bad & ~amb).sum()), np.argwhere(bad & ~amb)[:5].tolist())

@@ -259,6 +259,31 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
                          void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
 int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes);
 
+/* The same band with the STAR passes sharded too (SURVEY 8e, config 5 'ref s' -- a field the certificate refuses, whose
+ * Delaunay stars are most of the time): two calls per rank around ONE exchange.
+ *   1. ofl_scatter_slab_stars_dev: bins all sites (replicated inputs, as above), builds the stars of the sites within a
+ *      margin of the band's rows only, and writes the sites it could not finish -- rims of holes, hull sites: those of
+ *      the rank's own rows, the first / last band open-ended -- to `list` (device memory, list_bytes a multiple of 16):
+ *      uint32 { entries, error bits, 0, 0 } followed by one 64-byte record per site.  64 bytes per expected site; a
+ *      list that overflows is reported by step 2 on every rank (OFL_E_INVALID, err flag 32) -- retry with a larger one
+ *      or fall back to ofl_scatter_rows_dev.
+ *   2. all-gather the lists (ofl_comm_allgather: `list_bytes` per rank, in rank order or any other).
+ *   3. ofl_scatter_slab_finish_dev with the gathered buffer (`n_lists` lists of `list_bytes` each, this rank's among
+ *      them) and THE SAME workspace, untouched since step 1: every rank finishes all unfinished stars (they can reach
+ *      any band), rasterises and resolves its rows.  out_rows / valid_rows / valid_rule / info_host as above; the call
+ *      synchronises (it reads the error bits back: an error on one rank blanks every band).
+ * The concatenation of the bands equals ofl_scatter_linear_dev with OFL_SCATTER_UNCERTIFIED bit for bit.  A field whose
+ * mesh certifies needs none of this: ofl_scatter_certified_dev shards by rows without any exchange.
+ */
+int ofl_scatter_slab_stars_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask, int H, int W,
+                               int row0, int rows, uint32_t *list, size_t list_bytes,
+                               void *workspace, size_t workspace_bytes, void *stream);
+int ofl_scatter_slab_finish_dev(const float *flow, int sign, int point_precision, const float *vals, int C,
+                                const uint8_t *vmask, int H, int W, int row0, int rows,
+                                const uint32_t *lists, size_t list_bytes, int n_lists,
+                                float *out_rows, uint8_t *valid_rows, int valid_rule,
+                                void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream);
+
 /* Certificate of the warped grid as a triangulation (one pass over the flow, one 144-byte read-back; synchronises).
  * SciPy's griddata (utils.py:253) triangulates the points with Qhull; the cell-wise mesh of the warped grid IS that
  * Delaunay triangulation when no triangle is folded, every interior edge passes the local Delaunay test, no point is
@@ -348,14 +373,17 @@ int ofl_resize_flow_dev(const float *vecs, const uint8_t *mask, int H, int W, in
                         double scale_y, double scale_x, float mul_u, float mul_v,
                         float *out, uint8_t *mout, void *stream);
 
-/* ------------------------------------------------------------------ C1: shared-source broadcast (RCCL)
- * The only exchange step of the sharded workload: one broadcast of a shared source image / flow
- * from rank `root` to all ranks over xGMI.  The 128-byte unique id is created on rank 0 with
- * ofl_comm_unique_id and distributed by the launcher (torch.distributed store / gloo).
+/* ------------------------------------------------------------------ C1: the exchange steps (RCCL)
+ * Two exchange steps exist in the sharded workload: one broadcast of a shared source image / flow from rank `root`
+ * to all ranks over xGMI, and -- for one huge field warped with ref 's' in slab mode (above) -- one all-gather of the
+ * ranks' lists of unfinished sites (`bytes` from every rank into recv[rank * bytes ...], send may alias its own slot).
+ * The 128-byte unique id is created on rank 0 with ofl_comm_unique_id and distributed by the launcher
+ * (torch.distributed store / gloo).
  */
 int ofl_comm_unique_id(void *id128);
 int ofl_comm_init(const void *id128, int rank, int world);
 int ofl_comm_broadcast(void *dptr, size_t bytes, int root, void *stream);
+int ofl_comm_allgather(const void *send, void *recv, size_t bytes, void *stream);
 int ofl_comm_size(int *world);              /* ranks of the live communicator (ncclCommCount), 0 without one */
 int ofl_comm_destroy(void);
 

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ofl_axpy_dev": (_ci, [_vp, _vp, _vp, _vp, _cf, _cs, _vp, _vp, _vp]),
     "ofl_scatter_linear_f64_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_rows_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
+    "ofl_scatter_slab_stars_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _cs, _vp, _cs, _vp]),
+    "ofl_scatter_slab_finish_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _cs, _ci, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_linear_dev": (_ci, [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _cs, _vp, _vp]),
     "ofl_scatter_diag_bytes": (_ci, [_ci, _ci, ctypes.POINTER(_cs)]),
     "ofl_scatter_certify_dev": (_ci, [_vp, _ci, _ci, _vp, _ci, _ci, _vp, _cs, _vp, _vp, _vp]),
@@ -98,6 +100,7 @@ SIGNATURES = {
     "ofl_comm_unique_id": (_ci, [_vp]),
     "ofl_comm_init": (_ci, [_vp, _ci, _ci]),
     "ofl_comm_broadcast": (_ci, [_vp, _cs, _ci, _vp]),
+    "ofl_comm_allgather": (_ci, [_vp, _vp, _cs, _vp]),
     "ofl_comm_size": (_ci, [ctypes.POINTER(_ci)]),
     "ofl_comm_destroy": (_ci, []),
 }

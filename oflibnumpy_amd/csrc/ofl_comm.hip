@@ -1,6 +1,7 @@
-// ofl_comm.hip -- C1: the one exchange step of the sharded workload, a broadcast of a shared source
-// image / flow over xGMI with RCCL.  RCCL is bound lazily (dlopen) so that single-GPU users of
-// libofl_hip.so never pay for loading it; the launcher distributes the 128-byte unique id.
+// ofl_comm.hip -- C1: the exchange steps of the sharded workload over xGMI with RCCL: a broadcast of a shared source
+// image / flow, and the all-gather of the unfinished sites between the two halves of a slab-wise scatter.  RCCL is
+// bound lazily (dlopen) so that single-GPU users of libofl_hip.so never pay for loading it; the launcher distributes
+// the 128-byte unique id.
 #include "ofl_common.h"
 #include <dlfcn.h>
 
@@ -13,6 +14,7 @@ typedef void *nccl_comm_t;
 typedef int (*fn_get_uid)(nccl_uid_t *);
 typedef int (*fn_init_rank)(nccl_comm_t *, int, nccl_uid_t, int);
 typedef int (*fn_bcast)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_allgather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_destroy)(nccl_comm_t);
 typedef const char *(*fn_errstr)(int);
 typedef int (*fn_count)(nccl_comm_t, int *);
@@ -22,6 +24,7 @@ struct Rccl {
     fn_get_uid  get_uid = nullptr;
     fn_init_rank init_rank = nullptr;
     fn_bcast    bcast = nullptr;
+    fn_allgather allgather = nullptr;
     fn_destroy  destroy = nullptr;
     fn_errstr   errstr = nullptr;
     fn_count    count = nullptr;
@@ -41,10 +44,11 @@ int load_rccl()
     g.get_uid   = (fn_get_uid)dlsym(g.handle, "ncclGetUniqueId");
     g.init_rank = (fn_init_rank)dlsym(g.handle, "ncclCommInitRank");
     g.bcast     = (fn_bcast)dlsym(g.handle, "ncclBroadcast");
+    g.allgather = (fn_allgather)dlsym(g.handle, "ncclAllGather");
     g.destroy   = (fn_destroy)dlsym(g.handle, "ncclCommDestroy");
     g.errstr    = (fn_errstr)dlsym(g.handle, "ncclGetErrorString");
     g.count     = (fn_count)dlsym(g.handle, "ncclCommCount");
-    if (!g.get_uid || !g.init_rank || !g.bcast || !g.destroy)
+    if (!g.get_uid || !g.init_rank || !g.bcast || !g.allgather || !g.destroy)
         return fail(OFL_E_RCCL, "librccl lacks a required symbol");
     return OFL_OK;
 }
@@ -91,6 +95,17 @@ int ofl_comm_broadcast(void *dptr, size_t bytes, int root, void *stream)
     if (bytes == 0) return OFL_OK;
     int rc = g.bcast(dptr, dptr, bytes, /*ncclUint8*/ 1, root, g.comm, stream_of(stream));
     if (rc != 0) return rccl_fail(rc, "ncclBroadcast");
+    return OFL_OK;
+}
+
+int ofl_comm_allgather(const void *send, void *recv, size_t bytes, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!g.comm) return fail(OFL_E_INVALID, "ofl_comm_allgather: call ofl_comm_init first");
+    if (!send || !recv) return fail(OFL_E_INVALID, "ofl_comm_allgather: NULL pointer");
+    if (bytes == 0) return OFL_OK;
+    int rc = g.allgather(send, recv, bytes, /*ncclUint8*/ 1, g.comm, stream_of(stream));
+    if (rc != 0) return rccl_fail(rc, "ncclAllGather");
     return OFL_OK;
 }
 

@@ -27,6 +27,7 @@
 #include "ofl_scatter_dev.h"
 #include "ofl_delaunay_core.h"
 #include <algorithm>
+#include <limits>
 #include <stdlib.h>
 #include <vector>
 
@@ -65,6 +66,8 @@ constexpr unsigned kDedupeSmall = 256;    // buckets up to this size drop their 
 constexpr unsigned kMaxFar   = 1u << 20;  // unfinished stars ...
 constexpr unsigned kMaxLeft  = 1u << 18;  // ... and stars for the workgroup pass (quadratic in their number) before the call gives up
 constexpr unsigned kErrDegenerate = 16u;  // err bit: one of the three limits above -- Qhull, too, refuses such input ("initial simplex is flat")
+constexpr unsigned kErrSlabList = 32u;    // err bit: a rank's list of unfinished sites did not fit the buffer the caller gave it (slab mode)
+constexpr int      kSlabMargin = 2 * (kRings + 1) + 2;   // buckets around a row band within which the slab mode builds every star (see exact_stars)
 constexpr int      kScanChunk = 2048;    // elements per block of the scan kernels (256 threads x 8)
 
 struct DlHead {                           // device header of the exact path (256 bytes)
@@ -77,7 +80,8 @@ struct DlHead {                           // device header of the exact path (25
     double   far_t2;                                 // squared distance beyond which a cell vertex counts as "far" (well outside the data)
     unsigned n_big;                                  // sorted entries that live in buckets of more than kDedupeSmall entries
     unsigned live_huge;                              // distinct sites left in buckets of more than kMaxBucket entries
-    unsigned pad[10];
+    double   need_lo, need_hi;                       // slab mode: only sites with need_lo <= y <= need_hi get a star from cells / fans / clip (else -inf, +inf)
+    unsigned pad[6];
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
 
@@ -213,7 +217,7 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     }
 }
 
-__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale, int H, int W)
+__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale, int H, int W, int slab, int row0, int rows)
 {
     Grid g;
     g.ox = 0.0; g.oy = 0.0; g.s = 1.0; g.inv_s = 1.0; g.gx = 1; g.gy = 1;
@@ -250,6 +254,11 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
         head->far_t2 = t * t;
     } else head->far_t2 = 1.0;
     head->grid = g;
+    // slab mode: stars from cells / fans / clip only within kSlabMargin buckets of the band's rows (the first and the last
+    // band of a field are open-ended: sites warp beyond the frame)
+    const double inf = __longlong_as_double(0x7FF0000000000000ll), m = (double)kSlabMargin * g.s;
+    head->need_lo = (!slab || row0 <= 0) ? -inf : (double)row0 - m;
+    head->need_hi = (!slab || row0 + rows >= H) ? inf : (double)(row0 + rows - 1) + m;
     Grid g1 = g;                                     // coarse grid of the unfinished points: kMidScale fine buckets per cell
     g1.s = g.s * kMidScale; g1.inv_s = 1.0 / g1.s;
     g1.gx = (g.gx + kMidScale - 1) / kMidScale; g1.gy = (g.gy + kMidScale - 1) / kMidScale;
@@ -588,6 +597,10 @@ void dl_cell_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
         !(dup[ia] | dup[ia + 1] | dup[ia + W] | dup[ia + W + 1])) {
         const D2 a = point_of(flow, sign, W, x, y), b = point_of(flow, sign, W, x + 1, y);
         const D2 c = point_of(flow, sign, W, x + 1, y + 1), d = point_of(flow, sign, W, x, y + 1);
+        // (slab mode: a cell none of whose corners gets a star here is not looked at -- every site that does get one still
+        // finds all four of its cells verified, so its star comes out of the same pass as in a whole-field run)
+        const double lo = head->need_lo, hi = head->need_hi;
+        if (fmax(fmax(a.y, b.y), fmax(c.y, d.y)) >= lo && fmin(fmin(a.y, b.y), fmin(c.y, d.y)) <= hi)
         flag = cell_verify((int)ia, W, P2{ a.x, a.y }, P2{ b.x, b.y }, P2{ c.x, c.y }, P2{ d.x, d.y }, head->grid, bstart, sorted, sorted_xy,
                            PosFn(flow, sign, W), kFanSpan);
     }
@@ -595,7 +608,7 @@ void dl_cell_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
 }
 
 __global__ __launch_bounds__(256)
-void dl_site_cells_kernel(const uint8_t *__restrict__ pmask, int H, int W, const DlHead *__restrict__ head,
+void dl_site_cells_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W, const DlHead *__restrict__ head,
                           const unsigned char *__restrict__ dup, const unsigned char *__restrict__ cellflag,
                           unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
@@ -604,6 +617,10 @@ void dl_site_cells_kernel(const uint8_t *__restrict__ pmask, int H, int W, const
     if (!kept_pt(pmask, p) || dup[p]) { deg[p] = 0; return; }
     if (head->err & kErrDegenerate) { deg[p] = kDegTodo; return; }           // (no star pass runs on a refused point set)
     const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
+    if (head->need_lo > -1e300 || head->need_hi < 1e300) {   // slab mode: no star for a site outside the slab (degree 0: nothing is drawn from it, nothing looks it up)
+        const D2 q = point_of(flow, sign, W, x, y);
+        if (!(q.y >= head->need_lo && q.y <= head->need_hi)) { deg[p] = 0; return; }
+    }
     int n = 0;
     if (x > 0 && y > 0 && x < W - 1 && y < H - 1) {
         unsigned out[8];
@@ -1536,8 +1553,10 @@ void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int
 {
     // workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the field, so that the neighbour
     // rows a point looks up (the stars of the sites above and below it) are in ITS L2
+    // (a row band draws from the sites around its rows only -- often one contiguous stretch of indices, which that mapping
+    // would hand to a single XCD: 3.1 ms instead of 0.5 for an eighth of config 5 -- so bands keep the round-robin order)
     const unsigned nb = gridDim.x, per = (nb + 7) / 8;
-    const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const unsigned blk = ws.oy1 - ws.oy0 < H ? blockIdx.x : (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (blk >= nb) return;
     size_t p = (size_t)blk * 256 + threadIdx.x;
     if (p >= (size_t)H * W) return;
@@ -1796,6 +1815,59 @@ void dl_query_kernel(const float *__restrict__ flow, int sign, const float *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ slab mode: the exchange
+// BASELINE config 5 ('s' at 4320 x 7680) over several GPUs: rank r builds the cell / fan / clip stars of ITS slab only (the
+// bulk of the time), the ranks exchange the sites those passes left unfinished -- tens of thousands out of tens of millions --
+// and every rank finishes ALL of them, since the later passes search nothing but the unfinished sites beyond the fine rings
+// (a Delaunay neighbour of an unfinished site out there is itself unfinished) and a triangle of such a site can cross any
+// band.  List layout: word 0 = entries, word 1 = the rank's error bits, words 2 - 3 = 0, then one neighbour row (kSlots
+// words: seeds as the clip pass left them) per unfinished site with the site's index in slot 0 (which holds nothing yet).
+constexpr unsigned kSlabHead = 4;
+
+__global__ __launch_bounds__(256)
+void dl_slab_emit_kernel(const float *__restrict__ flow, int sign, int W, size_t n, const DlHead *__restrict__ head,
+                         const unsigned char *__restrict__ deg, const unsigned *__restrict__ nbr, double own_lo, double own_hi,
+                         unsigned *__restrict__ list, unsigned cap)
+{
+    const PosFn pos(flow, sign, W);
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (size_t)gridDim.x * 256) {
+        if (deg[p] != kDegFar) continue;
+        const P2 q = pos((int)p);
+        if (!(q.y >= own_lo && q.y < own_hi)) continue;             // another rank's to report (the bands tile the real line)
+        const unsigned slot = atomicAdd(&list[0], 1u);
+        if (slot >= cap) continue;                                  // (the reader sees entries > capacity)
+        const uint4 *src = reinterpret_cast<const uint4 *>(nbr + p * kSlots);
+        uint4 *dst = reinterpret_cast<uint4 *>(list + kSlabHead + (size_t)slot * kSlots);
+        uint4 r0 = src[0];
+        r0.x = (unsigned)p;
+        dst[0] = r0; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && head->err) atomicOr(&list[1], head->err);
+}
+
+__global__ __launch_bounds__(256)
+void dl_slab_absorb_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ lists, size_t stride_words, int n_lists, unsigned cap,
+                           size_t n, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
+{
+    for (int r = 0; r < n_lists; ++r) {
+        const unsigned *list = lists + (size_t)r * stride_words;
+        const unsigned total = list[0], cnt = total < cap ? total : cap;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned e = list[1] | (total > cap ? kErrSlabList : 0u);
+            if (e) atomicOr(&head->err, e);
+        }
+        for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(list + kSlabHead + (size_t)k * kSlots);
+            const uint4 r0 = src[0];
+            const size_t p = r0.x;
+            if (p >= n) { atomicOr(&head->err, kErrSlabList); continue; }     // not a list of this field
+            deg[p] = kDegFar;
+            uint4 *dst = reinterpret_cast<uint4 *>(nbr + p * kSlots);
+            dst[0] = r0; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
+    }
+}
+
 struct Sizes { size_t n, bcap, b1cap, pool_cap, big_cap; };
 
 Sizes sizes_for(int H, int W)
@@ -1876,19 +1948,30 @@ size_t exact_workspace_bytes(int H, int W)
 
 namespace {
 
-// Bins, stars and the owner map of rows [row0, row0 + rows).  Asynchronous unless the caller asks for the counts.
-int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows,
-                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s, DlWs &ws, unsigned &far_base_out,
-                  int &late_error)      // OFL_E_NOPOINTS / capacity errors known only after the fact: the owner map is complete (empty) all the same
+DlWs carve_band(void *workspace, int H, int W, int row0, int rows)
 {
-    late_error = OFL_OK;
+    DlWs ws = carve_exact(workspace, H, W);
+    ws.oy0 = row0; ws.oy1 = row0 + rows;
+    ws.owner -= (size_t)row0 * W;
+    return ws;
+}
+
+// Bins and the stars that cells, fans and the clip pass settle; what they leave is marked kDegFar with its seeds.
+// `slab`: only for the sites within kSlabMargin buckets of rows [row0, row0 + rows) -- every triangle that reaches those rows
+// has ALL its vertices there or is a triangle of an unfinished site: a finished star's neighbours lie within kRings + 1
+// buckets of its site per axis (clip pass: a cell is final only when twice its reach is covered by the rings searched; cells
+// and fans: circumcircles within kFanSpan buckets), so a triangle with one finished vertex spans at most 2 (kRings + 1) bucket
+// rows.  The copy of a triangle that is drawn is the one of its smallest-index vertex -- whose star is therefore built here
+// whenever the triangle matters, with the same neighbour order as in a whole-field run (the passes read the bins of ALL
+// sites either way): owner ids, and with them every tie on a shared edge, come out the same.
+int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows, bool slab,
+                void *workspace, size_t workspace_bytes, hipStream_t s, DlWs &ws)
+{
     const size_t n = (size_t)H * W;
     if (n >= (1ull << 27)) return fail(OFL_E_INVALID, "ofl_scatter_linear: the exact path takes fields below 2^27 pixels");
     if (workspace_bytes < ofl_sc::exact_workspace_bytes(H, W)) return fail(OFL_E_INVALID, "ofl_scatter_linear: workspace too small for the exact path");
-    ws = carve_exact(workspace, H, W);
-    ws.oy0 = row0; ws.oy1 = row0 + rows;
-    OFL_HIP(hipMemsetAsync(ws.owner, 0xFF, (size_t)rows * W * 4, s));
-    ws.owner -= (size_t)row0 * W;
+    ws = carve_band(workspace, H, W, row0, rows);
+    OFL_HIP(hipMemsetAsync(ws.owner + (size_t)row0 * W, 0xFF, (size_t)rows * W * 4, s));
     DlHead init;
     memset(&init, 0, sizeof(init));
     init.kx0 = init.ky0 = ~0ull;
@@ -1898,7 +1981,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
     const unsigned nblk = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 1024 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
     static const double bucket_scale = OFL_KNOB_DOUBLE("OFL_DL_BUCKET", 1.0);      // development knob (experiments build only)
-    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W);
+    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W, slab ? 1 : 0, row0, rows);
     OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
     hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup);
     OFL_HIP(hipGetLastError());
@@ -1927,7 +2010,7 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         hipLaunchKernelGGL(dl_cell_kernel, dim3((unsigned)((ctx * cty + 7) / 8 * 8)), dim3(256), 0, s, flow, sign_pp, pmask, H, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                            (const unsigned char *)ws.dup, ws.cellflag, ctx, ctx * cty);
-        hipLaunchKernelGGL(dl_site_cells_kernel, dim3(nblk), dim3(256), 0, s, pmask, H, W, (const DlHead *)ws.head,
+        hipLaunchKernelGGL(dl_site_cells_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
                            (const unsigned char *)ws.dup, (const unsigned char *)ws.cellflag, ws.deg, ws.nbr);
     }
     hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
@@ -1938,7 +2021,6 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        (const DlHead *)ws.head, (const unsigned *)ws.todo_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                        (const unsigned char *)ws.dup, ws.deg, ws.nbr);
     // what cells and fans did not settle, in index order, for the clip pass
-    static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
     hipLaunchKernelGGL(dl_flag_count_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
     hipLaunchKernelGGL(dl_flag_write_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
@@ -1947,6 +2029,21 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
                        (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
                        (const P2 *)ws.sorted_xy, ws.deg, ws.nbr);
     OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+// The unfinished sites in index order, their stars (second per-thread pass, wave pass, workgroup pass) and the owner map
+// of rows [row0, row0 + rows).  Asynchronous unless the caller asks for the counts.
+int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int rows, uint64_t *info_host, hipStream_t s, DlWs &ws,
+                 unsigned &far_base_out,
+                 int &late_error)      // OFL_E_NOPOINTS / capacity errors known only after the fact: the owner map is complete (empty) all the same
+{
+    late_error = OFL_OK;
+    const size_t n = (size_t)H * W;
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
+    unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
+    static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
     // unfinished points in index order
     hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
@@ -2025,9 +2122,19 @@ int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, i
         else if (h.err) late_error = fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
                                               "neighbours, 2 = neighbour pool, 4 = large-triangle list, 8 = unfinished stars beyond the "
                                               "triangle-id space, 16 = degenerate point set: thousands of coincident points or hundreds of "
-                                              "thousands of unbounded cells)", h.err, kFarCap);
+                                              "thousands of unbounded cells; 32 = a rank's list of unfinished sites exceeded its buffer)", h.err, kFarCap);
     }
     return OFL_OK;
+}
+
+// Bins, stars and the owner map of rows [row0, row0 + rows) in one go (every star of the field: one GPU, or replicated ranks).
+int exact_prepare(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows,
+                  void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s, DlWs &ws, unsigned &far_base_out,
+                  int &late_error)
+{
+    late_error = OFL_OK;
+    OFL_TRY(exact_stars(flow, sign_pp, pmask, H, W, row0, rows, false, workspace, workspace_bytes, s, ws));
+    return exact_finish(flow, sign_pp, H, W, row0, rows, info_host, s, ws, far_base_out, late_error);
 }
 
 
@@ -2069,6 +2176,53 @@ int exact_query(const float *flow, int sign_pp, const uint8_t *pmask, const floa
         hipLaunchKernelGGL(dl_query_kernel<true>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, query, n, out, valid, valid_rule, ws, far_base);
     else
         hipLaunchKernelGGL(dl_query_kernel<false>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, query, n, out, valid, valid_rule, ws, far_base);
+    OFL_HIP(hipGetLastError());
+    return late;
+}
+
+// slab mode, step 1: the stars of the slab around rows [row0, row0 + rows) and the list of the unfinished sites this rank
+// reports (those whose position lies in [row0, row0 + rows); the first band is open towards -inf, the last towards +inf)
+int exact_slab_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows,
+                     uint32_t *list, size_t list_bytes, void *workspace, size_t workspace_bytes, hipStream_t s)
+{
+    if (list_bytes < (kSlabHead + kSlots) * 4) return fail(OFL_E_INVALID, "ofl_scatter_slab_stars: list buffer too small");
+    DlWs ws;
+    OFL_TRY(exact_stars(flow, sign_pp, pmask, H, W, row0, rows, true, workspace, workspace_bytes, s, ws));
+    const size_t n = (size_t)H * W;
+    const size_t cap = std::min<size_t>((list_bytes / 4 - kSlabHead) / kSlots, 0xFFFFFFFFu);
+    const double inf = std::numeric_limits<double>::infinity();
+    OFL_HIP(hipMemsetAsync(list, 0, kSlabHead * 4, s));
+    hipLaunchKernelGGL(dl_slab_emit_kernel, dim3(std::min<unsigned>((unsigned)((n + 255) / 256), 4096u)), dim3(256), 0, s, flow, sign_pp, W, n,
+                       (const DlHead *)ws.head, (const unsigned char *)ws.deg, (const unsigned *)ws.nbr,
+                       row0 <= 0 ? -inf : (double)row0, row0 + rows >= H ? inf : (double)(row0 + rows), list, (unsigned)cap);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+// slab mode, step 2: the lists of ALL ranks (this rank's included; `n_lists` buffers of `stride_bytes` each, as an all-gather
+// leaves them) are merged into the star state step 1 left in `workspace`; then the unfinished stars, the owner map and the
+// result of the band, exactly as a whole-field call produces them.
+int exact_slab_finish(const float *flow, int sign_pp, const float *vals, int C, const uint8_t *vmask, int H, int W, int row0, int rows,
+                      const uint32_t *lists, size_t stride_bytes, int n_lists, float *out, uint8_t *valid, int valid_rule,
+                      void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s)
+{
+    if (workspace_bytes < exact_workspace_bytes(H, W)) return fail(OFL_E_INVALID, "ofl_scatter_slab_finish: workspace too small");
+    if (n_lists < 1 || stride_bytes % 16 || stride_bytes < (kSlabHead + kSlots) * 4)
+        return fail(OFL_E_INVALID, "ofl_scatter_slab_finish: bad list layout");
+    DlWs ws = carve_band(workspace, H, W, row0, rows);
+    const size_t n = (size_t)H * W;
+    const size_t cap = std::min<size_t>((stride_bytes / 4 - kSlabHead) / kSlots, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(dl_slab_absorb_kernel, dim3(256), dim3(256), 0, s, ws.head, lists, stride_bytes / 4, n_lists, (unsigned)cap, n, ws.deg, ws.nbr);
+    OFL_HIP(hipGetLastError());
+    unsigned far_base = 0;
+    int late = OFL_OK;
+    uint64_t info_local[3];
+    // (always read the counts back: an error bit another rank raised must blank this band too, and the exchange has
+    // synchronised the ranks a moment ago anyway)
+    OFL_TRY(exact_finish(flow, sign_pp, H, W, row0, rows, info_host ? info_host : info_local, s, ws, far_base, late));
+    const dim3 grid((W + 31) / 32, (rows + 7) / 8);
+    hipLaunchKernelGGL(dl_resolve_kernel<float>, grid, dim3(256), 0, s, flow, sign_pp, vals, C, vmask, H, W, row0, rows,
+                       out, valid, valid_rule, ws, far_base);
     OFL_HIP(hipGetLastError());
     return late;
 }

@@ -199,6 +199,35 @@ int ofl_scatter_rows_dev(const float *flow, int sign, int point_precision, const
                                     out_rows, valid_rows, valid_rule, workspace, workspace_bytes, info_host, stream_of(stream));
 }
 
+// One row band per rank with the star passes sharded as well (include/ofl.h): step 1, the exchange, step 2.
+int ofl_scatter_slab_stars_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask, int H, int W, int row0, int rows,
+                               uint32_t *list, size_t list_bytes, void *workspace, size_t workspace_bytes, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!flow || !list || !workspace) return fail(OFL_E_INVALID, "ofl_scatter_slab_stars: NULL pointer");
+    if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 27)) return fail(OFL_E_INVALID, "ofl_scatter_slab_stars: H*W must be in [1, 2^27)");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_scatter_slab_stars: sign must be +1 or -1");
+    if (point_precision != 0 && point_precision != 1) return fail(OFL_E_INVALID, "ofl_scatter_slab_stars: bad point_precision");
+    if (row0 < 0 || rows <= 0 || row0 + rows > H) return fail(OFL_E_INVALID, "ofl_scatter_slab_stars: rows [%d, %d) outside the %d-row grid", row0, row0 + rows, H);
+    if (list_bytes % 16) return fail(OFL_E_INVALID, "ofl_scatter_slab_stars: list_bytes must be a multiple of 16");
+    return exact_slab_stars(flow, point_precision ? 2 * sign : sign, pmask, H, W, row0, rows, list, list_bytes, workspace, workspace_bytes,
+                            stream_of(stream));
+}
+
+int ofl_scatter_slab_finish_dev(const float *flow, int sign, int point_precision, const float *vals, int C, const uint8_t *vmask,
+                                int H, int W, int row0, int rows, const uint32_t *lists, size_t list_bytes, int n_lists,
+                                float *out_rows, uint8_t *valid_rows, int valid_rule,
+                                void *workspace, size_t workspace_bytes, uint64_t *info_host, void *stream)
+{
+    OFL_TRY(need_device());
+    if (!lists) return fail(OFL_E_INVALID, "ofl_scatter_slab_finish: NULL pointer");
+    OFL_TRY(check_common("ofl_scatter_slab_finish", flow, sign, point_precision, C, vals, out_rows, valid_rows, valid_rule, H, W, workspace, workspace_bytes));
+    if ((long long)H * W >= (1ll << 27)) return fail(OFL_E_INVALID, "ofl_scatter_slab_finish: H*W must be below 2^27");
+    if (row0 < 0 || rows <= 0 || row0 + rows > H) return fail(OFL_E_INVALID, "ofl_scatter_slab_finish: rows [%d, %d) outside the %d-row grid", row0, row0 + rows, H);
+    return exact_slab_finish(flow, sign, vals, C, vmask, H, W, row0, rows, lists, list_bytes, n_lists, out_rows, valid_rows,
+                             valid_rule & ~OFL_SCATTER_UNCERTIFIED, workspace, workspace_bytes, info_host, stream_of(stream));
+}
+
 // Sparse queries (point tracking, utils.py:599-615): out[i][0..C) in float64, found[i] = 0 where griddata returns NaN.
 int ofl_scatter_query_dev(const float *flow, int sign, int point_precision, const uint8_t *pmask,
                           const float *vals, int C, int H, int W,

@@ -174,4 +174,11 @@ int exact_query(const float *flow, int sign_pp, const uint8_t *pmask, const floa
                 int H, int W, const void *query, size_t n, bool sparse, void *out, uint8_t *valid, int valid_rule,
                 void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s);
 
+// slab mode of the exact path (one row band per rank with ONE exchange of the unfinished sites in between: include/ofl.h)
+int exact_slab_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, int row0, int rows,
+                     uint32_t *list, size_t list_bytes, void *workspace, size_t workspace_bytes, hipStream_t s);
+int exact_slab_finish(const float *flow, int sign_pp, const float *vals, int C, const uint8_t *vmask, int H, int W, int row0, int rows,
+                      const uint32_t *lists, size_t stride_bytes, int n_lists, float *out, uint8_t *valid, int valid_rule,
+                      void *workspace, size_t workspace_bytes, uint64_t *info_host, hipStream_t s);
+
 }  // namespace ofl_sc

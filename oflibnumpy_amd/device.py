@@ -771,6 +771,59 @@ def scatter_rows(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, 
     return tuple(info)
 
 
+SLAB_LIST_HEAD = 16          # bytes before the first record of a slab list (entries, error bits, 0, 0)
+SLAB_RECORD = 64             # bytes per unfinished site
+
+
+def slab_list_bytes(entries):
+    return SLAB_LIST_HEAD + SLAB_RECORD * int(entries)
+
+
+def comm_allgather(send_ptr, recv, nbytes, stream=None):
+    """ncclAllGather of `nbytes` per rank over the live communicator (send may be the rank's own slot of recv)."""
+    nat.check(_lib().ofl_comm_allgather(send_ptr, recv.ptr, nbytes, stream))
+
+
+def scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, list_ptr, list_bytes, point_precision=0, stream=None):
+    """Step 1 of the slab-wise scatter (include/ofl.h, ofl_scatter_slab_stars_dev): bins, the stars around rows
+    [row0, row0 + rows) and -- at list_ptr (device) -- the unfinished sites of those rows.  The workspace of this
+    (shape, stream) keeps the star state for scatter_slab_finish: no other scatter call of that shape on that stream in
+    between."""
+    ws = _workspace(h, w, 0, stream)
+    nat.check(_lib().ofl_scatter_slab_stars_dev(flow.ptr, sign, point_precision, pmask.ptr if pmask is not None else None,
+                                                h, w, row0, rows, list_ptr, list_bytes, ws.ptr, ws.nbytes, stream))
+
+
+def scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, list_bytes, n_lists, out_rows, valid_rows,
+                        valid_rule=0, point_precision=0, stream=None):
+    """Step 2: the gathered lists of all ranks -> unfinished stars, owner map and result of the band."""
+    ws = _workspace(h, w, 0, stream)
+    info = (ctypes.c_uint64 * 3)()
+    ptr = lambda b: b.ptr if b is not None else None
+    nat.check(_lib().ofl_scatter_slab_finish_dev(flow.ptr, sign, point_precision, ptr(vals), C, ptr(vmask), h, w, row0, rows,
+                                                 lists.ptr, list_bytes, n_lists, ptr(out_rows), ptr(valid_rows), valid_rule,
+                                                 ws.ptr, ws.nbytes, info, stream))
+    return tuple(info)
+
+
+def scatter_slab(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, valid_rows, rank=0, world=1, valid_rule=0,
+                 point_precision=0, stream=None, entries=1 << 17, gather=comm_allgather):
+    """One row band of a ref-'s' warp whose mesh does not certify, with the star passes sharded over `world` ranks
+    (SURVEY 8e, config 5): step 1, ONE all-gather of `entries` 64-byte records per rank (8 MiB by default: config 5 at 8K
+    leaves 75 000 sites unfinished in all), step 2.  `gather(send_ptr, recv_buffer, nbytes, stream)` defaults to RCCL over
+    the live communicator.  Bands concatenate to scatter_linear's result bit for bit."""
+    if world <= 1 and (row0 != 0 or rows != h):
+        raise ValueError("scatter_slab: a band of a field needs the other ranks' lists")
+    nb = slab_list_bytes(entries)
+    lists = DeviceBuffer(nb * max(world, 1))
+    mine = lists.ptr + (rank if world > 1 else 0) * nb
+    scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, mine, nb, point_precision, stream)
+    if world > 1:
+        gather(mine, lists, nb, stream)
+    return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, nb, max(world, 1), out_rows, valid_rows,
+                               valid_rule, point_precision, stream)
+
+
 def scatter_host(flow, target, pmask, vmask=None):
     """apply_flow(flow, target, 's', mask) for host arrays (utils.py:237-258; `flow` may already be a DeviceBuffer
     holding the float32 vectors): target (H, W, C) of any numeric

@@ -259,6 +259,10 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
     const double inf = __longlong_as_double(0x7FF0000000000000ll), m = (double)kSlabMargin * g.s;
     head->need_lo = (!slab || row0 <= 0) ? -inf : (double)row0 - m;
     head->need_hi = (!slab || row0 + rows >= H) ? inf : (double)(row0 + rows - 1) + m;
+    // (sites beyond the grid are clamped into its border buckets: a star next to those may hold a neighbour that is "within
+    // the rings" by bucket number only -- a slab that comes this close to the border rows takes everything beyond them, too)
+    if (head->need_lo < g.oy + (double)(kRings + 2) * g.s) head->need_lo = -inf;
+    if (head->need_hi > g.oy + (double)(g.gy - kRings - 2) * g.s) head->need_hi = inf;
     Grid g1 = g;                                     // coarse grid of the unfinished points: kMidScale fine buckets per cell
     g1.s = g.s * kMidScale; g1.inv_s = 1.0 / g1.s;
     g1.gx = (g.gx + kMidScale - 1) / kMidScale; g1.gy = (g.gy + kMidScale - 1) / kMidScale;

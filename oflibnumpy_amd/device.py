@@ -809,18 +809,30 @@ def scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, lis
 def scatter_slab(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, valid_rows, rank=0, world=1, valid_rule=0,
                  point_precision=0, stream=None, entries=1 << 17, gather=comm_allgather):
     """One row band of a ref-'s' warp whose mesh does not certify, with the star passes sharded over `world` ranks
-    (SURVEY 8e, config 5): step 1, ONE all-gather of `entries` 64-byte records per rank (8 MiB by default: config 5 at 8K
-    leaves 75 000 sites unfinished in all), step 2.  `gather(send_ptr, recv_buffer, nbytes, stream)` defaults to RCCL over
-    the live communicator.  Bands concatenate to scatter_linear's result bit for bit."""
+    (SURVEY 8e, config 5): step 1 into a list of up to `entries` records, the exchange, step 2.  The exchange is two
+    all-gathers -- the 16-byte list heads first, then (one read-back of the counts later) only as many 64-byte records per
+    rank as the fullest list holds: config 5 at 8K leaves 75 000 sites unfinished in all, 1 MB per rank instead of the
+    8 MiB the buffers are sized for.  `gather(send_ptr, recv_buffer, nbytes, stream)` defaults to RCCL over the live
+    communicator (sharding.host_allgather(dist) goes through the host instead: rehearsals with ranks that share a GPU).
+    Bands concatenate to scatter_linear's result bit for bit."""
     if world <= 1 and (row0 != 0 or rows != h):
         raise ValueError("scatter_slab: a band of a field needs the other ranks' lists")
+    world = max(int(world), 1)
     nb = slab_list_bytes(entries)
-    lists = DeviceBuffer(nb * max(world, 1))
-    mine = lists.ptr + (rank if world > 1 else 0) * nb
-    scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, mine, nb, point_precision, stream)
-    if world > 1:
-        gather(mine, lists, nb, stream)
-    return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, nb, max(world, 1), out_rows, valid_rows,
+    mine = DeviceBuffer(nb)
+    scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, mine.ptr, nb, point_precision, stream)
+    if world == 1:
+        return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, mine, nb, 1, out_rows, valid_rows,
+                                   valid_rule, point_precision, stream)
+    heads = DeviceBuffer(SLAB_LIST_HEAD * world)
+    gather(mine.ptr, heads, SLAB_LIST_HEAD, stream)
+    counts = heads.to_host((world, SLAB_LIST_HEAD // 4), np.uint32, stream)[:, 0]
+    from .sharding import slab_payload_entries
+    m = slab_payload_entries(counts, entries)
+    nb2 = slab_list_bytes(m)
+    lists = DeviceBuffer(nb2 * world)
+    gather(mine.ptr, lists, nb2, stream)
+    return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, nb2, world, out_rows, valid_rows,
                                valid_rule, point_precision, stream)
 
 

@@ -39,6 +39,41 @@ def broadcast_bytes(dist, payload, src=0):
     return t.numpy()
 
 
+def allgather_bytes(dist, payload):
+    """uint8 arrays of equal length from every rank, in rank order (gloo)."""
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(payload, np.uint8).copy())
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return np.stack([p.numpy() for p in parts])
+
+
+def slab_payload_entries(counts, entries):
+    """Records per rank the second all-gather of a slab-wise scatter carries: as many as the fullest list holds (every rank
+    computes this from the same gathered heads), never more than the lists' capacity -- a rank whose list overflowed keeps
+    a count above it, which step 2 reports on every rank -- and at least one (the smallest list the C ABI accepts)."""
+    return max(1, min(int(max(counts)), int(entries)))
+
+
+def host_allgather(dist):
+    """An all-gather of device memory THROUGH THE HOST (download, gloo, upload) with the signature device.scatter_slab
+    expects of its `gather` hook: for rehearsals in which the ranks share one GPU -- RCCL refuses two ranks on a device.
+    Real multi-GPU runs use the default hook, ofl_comm_allgather."""
+    def gather(send_ptr, recv, nbytes, stream=None):
+        import numpy as np
+        from . import device as dev
+
+        class _At:                                  # (to_host needs nothing but the address)
+            ptr = send_ptr
+        from . import _native as nat
+        mine = dev.DeviceBuffer.to_host(_At, (nbytes,), np.uint8, stream)
+        every = np.ascontiguousarray(allgather_bytes(dist, mine))
+        nat.check(nat.load().ofl_upload(recv.ptr, every.ctypes.data, every.size, stream))
+        nat.check(nat.load().ofl_stream_sync(stream))                 # (`every` is a temporary)
+    return gather
+
+
 def max_over_ranks(dist, values):
     """Element-wise maximum of a list of floats over all ranks (timings are reported as the slowest rank's)."""
     import torch

@@ -1,0 +1,212 @@
+"""Slab-wise scatter (SURVEY 8e, config 5 with ref 's'): the star passes of the Delaunay path sharded over ranks with ONE
+exchange of the unfinished sites (include/ofl.h: ofl_scatter_slab_stars_dev, ofl_comm_allgather, ofl_scatter_slab_finish_dev).
+
+The bar is the one the replicated band entry (ofl_scatter_rows_dev) already meets: the bands of all ranks, concatenated,
+equal the whole-field result BIT FOR BIT -- values and validity -- for any number of ranks.  The ranks are rehearsed on the
+one GPU of the test box (tests/slab_util.py); the exchange between real ranks is ofl_comm_allgather, exercised here on a
+one-rank communicator.  What the whole-field result itself is worth against SciPy is the business of
+tests/test_gpu_scatter*.py.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+import pytest
+
+from slab_util import Slab, probe_values
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rotation_field(h, w):
+    import oflibnumpy_amd as of
+    return of.Flow.from_transforms([['rotation', w / 2, h / 2, -20], ['scaling', w / 3.84, h / 2.7, 0.9]], [h, w], 's').vecs
+
+
+def make_field(kind, h, w):
+    """(vectors, point mask or None): fields the certificate refuses, one per reason the star passes exist"""
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    m = None
+    if kind == "speckle":                       # 5 % of the sites dropped at random: fans and clips everywhere
+        v, m = rotation_field(h, w), rng.random((h, w)) > 0.05
+    elif kind == "hole":                        # a large hole: its rim goes through the wave pass, crosses several bands
+        v, m = rotation_field(h, w), np.ones((h, w), bool)
+        m[h // 5:h // 5 + h // 2, w // 4:w // 4 + w // 5] = False
+    elif kind == "stripes":                     # motion boundaries top to bottom: tears in every band
+        v = np.zeros((h, w, 2), np.float32)
+        v[..., 0] = (np.floor(xx / 32) % 2) * 9.0
+    elif kind == "object":                      # a block moving over a still background: folds and a tear
+        v = np.zeros((h, w, 2), np.float32)
+        v[h // 4:h // 4 * 3, w // 4:w // 4 * 3] = [13.0, -7.0]
+    elif kind == "sintel":                      # BASELINE config 5's field: lattice sites, duplicates, ragged right border
+        import oflibnumpy_amd as of
+        flo = of.load_sintel(os.path.join(GOLDEN, "sintel.flo"))
+        v = np.ascontiguousarray(np.tile(flo, (h // flo.shape[0], w // flo.shape[1], 1)))
+    elif kind == "vertical":                    # sites leave their source rows by tens of pixels: slabs are not index ranges
+        v = np.stack([3.0 * np.sin(yy / 17.0), 40.0 * np.sin(xx / 61.0) + 0.3 * yy], -1).astype(np.float32)
+    elif kind == "outliers":                    # garbage vectors far outside the bucket grid, next to the first and last band
+        v = (0.6 * rng.standard_normal((h, w, 2))).astype(np.float32)
+        v[0, 5] = [0.0, -9e4]; v[h - 1, 9] = [3.0, 7e4]; v[h // 2, 0] = [-6e4, 0.0]
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(v, np.float32), m
+
+
+def assert_bands_equal_full(sl, world, align=8):
+    h, w, C = sl.h, sl.w, sl.C
+    fo, fv, info = sl.full()
+    fo, fv = fo.to_host((h, w, C), np.float32), fv.to_host((h, w), np.uint8)
+    out, valid, lists, bands = sl.play(world, align)
+    counts, errs = sl.counts(lists, world)
+    assert not any(errs), errs
+    assert sum(counts) == info[1], (counts, info)            # the ranks' lists partition the unfinished sites
+    diff = (out.view(np.uint32) != fo.view(np.uint32)).any(-1) | (valid != fv)
+    assert not diff.any(), (int(diff.sum()), np.argwhere(diff)[:5].tolist(), bands)
+    return info, counts
+
+
+@pytest.mark.parametrize("kind", ["speckle", "hole", "stripes", "object", "sintel", "vertical", "outliers"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_slab_bands_equal_whole_field(gpu, kind, world):
+    h, w = (430, 760) if kind == "sintel" else (384, 512)
+    vecs, m = make_field(kind, h, w)
+    h, w = vecs.shape[:2]
+    sl = Slab(vecs, m, probe_values(h, w))
+    info, counts = assert_bands_equal_full(sl, world)
+    assert info[1] > 0                                       # every field leaves sites to the exchange
+
+
+def test_bands_thinner_than_the_slab_margin(gpu):
+    """96 rows over 8 and 12 ranks: every slab overlaps several bands (and with 13 ranks of 8-row tiles one band is empty)"""
+    vecs, m = make_field("speckle", 96, 160)
+    sl = Slab(vecs, m, probe_values(96, 160))
+    for world in (8, 12, 13):
+        assert_bands_equal_full(sl, world)
+    assert_bands_equal_full(sl, 5, align=1)                  # band edges off the 8-row tiles
+
+
+def test_float32_points_and_negated_field(gpu):
+    """the two other ways the entries are called: positions rounded to float32 (mode 2), sign -1 (flow_class.py:1398-1400)"""
+    vecs, m = make_field("speckle", 200, 320)
+    for sign, pp in ((1, 1), (-1, 0)):
+        sl = Slab(vecs, m, probe_values(200, 320), sign=sign, point_precision=pp)
+        assert_bands_equal_full(sl, 3)
+
+
+def test_list_overflow_blanks_every_band(gpu):
+    """a list buffer too small for a rank's unfinished sites: step 2 reports it ON EVERY RANK and returns an all-invalid band"""
+    vecs, m = make_field("hole", 256, 384)
+    sl = Slab(vecs, m, probe_values(256, 384), entries=64)
+    bands = sl.bands(2)
+    lists = sl.gather(bands)
+    counts, _ = sl.counts(lists, 2)
+    assert max(counts) > 64
+    scratch = gpu.device.DeviceBuffer(sl.nb)
+    for r0, r1 in bands:
+        sl.stars(r0, r1 - r0, scratch.ptr)
+        o, v = gpu.device.DeviceBuffer((r1 - r0) * 384 * 2 * 4), gpu.device.DeviceBuffer((r1 - r0) * 384)
+        rc, _ = sl.finish(r0, r1 - r0, lists, 2, o, v, check=False)
+        assert rc == gpu.native.E_INVALID
+        assert "32" in gpu.native.last_error()
+        assert not v.to_host((r1 - r0, 384), np.uint8).any()
+        assert not o.to_host((r1 - r0, 384, 2), np.float32).any()
+
+
+def test_argument_checks(gpu):
+    vecs, m = make_field("speckle", 64, 96)
+    sl = Slab(vecs, m, probe_values(64, 96))
+    lib, nat = sl.lib, sl.nat
+    lst = gpu.device.DeviceBuffer(sl.nb)
+    bad = [
+        lambda: lib.ofl_scatter_slab_stars_dev(None, 1, 0, None, 64, 96, 0, 64, lst.ptr, sl.nb, sl.ws.ptr, sl.ws.nbytes, None),
+        lambda: lib.ofl_scatter_slab_stars_dev(sl.flow.ptr, 1, 0, None, 64, 96, 60, 8, lst.ptr, sl.nb, sl.ws.ptr, sl.ws.nbytes, None),
+        lambda: lib.ofl_scatter_slab_stars_dev(sl.flow.ptr, 1, 0, None, 64, 96, 0, 64, lst.ptr, 24, sl.ws.ptr, sl.ws.nbytes, None),
+        lambda: lib.ofl_scatter_slab_stars_dev(sl.flow.ptr, 1, 0, None, 64, 96, 0, 64, lst.ptr, sl.nb, sl.ws.ptr, 4096, None),
+        lambda: lib.ofl_scatter_slab_stars_dev(sl.flow.ptr, 3, 0, None, 64, 96, 0, 64, lst.ptr, sl.nb, sl.ws.ptr, sl.ws.nbytes, None),
+        lambda: lib.ofl_scatter_slab_finish_dev(sl.flow.ptr, 1, 0, sl.vals.ptr, 2, None, 64, 96, 0, 64, None, sl.nb, 1, lst.ptr, lst.ptr, 0,
+                                                sl.ws.ptr, sl.ws.nbytes, None, None),
+        lambda: lib.ofl_scatter_slab_finish_dev(sl.flow.ptr, 1, 0, sl.vals.ptr, 2, None, 64, 96, 0, 64, lst.ptr, sl.nb, 0, lst.ptr, lst.ptr, 0,
+                                                sl.ws.ptr, sl.ws.nbytes, None, None),
+        lambda: lib.ofl_scatter_slab_finish_dev(sl.flow.ptr, 1, 0, sl.vals.ptr, 2, None, 64, 96, 0, 64, lst.ptr, sl.nb + 4, 1, lst.ptr, lst.ptr, 0,
+                                                sl.ws.ptr, sl.ws.nbytes, None, None),
+    ]
+    for call in bad:
+        assert call() == nat.E_INVALID
+
+
+def test_device_api_single_rank_and_allgather(gpu):
+    """device.scatter_slab on a one-rank communicator: the RCCL all-gather entry runs (in place, one rank), the result is the
+    whole-field one"""
+    from oflibnumpy_amd import device as dev
+    nat, lib = gpu.native, gpu.native.load()
+    h, w = 200, 320
+    vecs, m = make_field("speckle", h, w)
+    vals = probe_values(h, w)
+    sl = Slab(vecs, m, vals)
+    fo, fv, _ = sl.full()
+    fo, fv = fo.to_host((h, w, 2), np.float32), fv.to_host((h, w), np.uint8)
+    out, valid = dev.DeviceBuffer(h * w * 2 * 4), dev.DeviceBuffer(h * w)
+    info = dev.scatter_slab(sl.flow, 1, sl.pm, sl.vals, 2, None, h, w, 0, h, out, valid)
+    assert np.array_equal(out.to_host((h, w, 2), np.float32).view(np.uint32), fo.view(np.uint32))
+    assert np.array_equal(valid.to_host((h, w), np.uint8), fv)
+    assert info[1] > 0
+    with pytest.raises(ValueError):
+        dev.scatter_slab(sl.flow, 1, sl.pm, sl.vals, 2, None, h, w, 8, 64, out, valid)       # a band without the other ranks
+    uid = np.zeros(128, np.uint8)
+    nat.check(lib.ofl_comm_unique_id(uid.ctypes.data))
+    nat.check(lib.ofl_comm_init(uid.ctypes.data, 0, 1))
+    try:
+        calls = []
+
+        def gather(send, recv, nbytes, stream):
+            calls.append(nbytes)
+            dev.comm_allgather(send, recv, nbytes, stream)
+
+        # (world = 1 skips the exchange; play a "world" of one list through the gather hook by hand)
+        nb = dev.slab_list_bytes(1 << 12)
+        lists = dev.DeviceBuffer(nb)
+        dev.scatter_slab_stars(sl.flow, 1, sl.pm, h, w, 0, h, lists.ptr, nb)
+        before = lists.to_host((nb // 4,), np.uint32).copy()
+        gather(lists.ptr, lists, nb, None)
+        nat.check(lib.ofl_stream_sync(None))
+        assert np.array_equal(lists.to_host((nb // 4,), np.uint32), before) and calls == [nb]
+        dev.scatter_slab_finish(sl.flow, 1, sl.vals, 2, None, h, w, 0, h, lists, nb, 1, out, valid)
+        assert np.array_equal(out.to_host((h, w, 2), np.float32).view(np.uint32), fo.view(np.uint32))
+    finally:
+        nat.check(lib.ofl_comm_destroy())
+
+
+def test_config5_8k_slab_bands_and_time(gpu):
+    """BASELINE config 5 at full size, 8 ranks: bands == whole field bit for bit, and one rank's share (step 1 + step 2 of band
+    3) takes well under half of the whole-field time (measured 0.35; replicated stars: 0.91)."""
+    flo = gpu.load_sintel(os.path.join(GOLDEN, "sintel.flo"))
+    big = np.ascontiguousarray(np.tile(flo, (432, 384, 1)))
+    h, w = big.shape[:2]
+    assert (h, w) == (4320, 7680)
+    sl = Slab(big, None, probe_values(h, w))
+    info, counts = assert_bands_equal_full(sl, 8)
+    assert info[0] == h * w and 50_000 < info[1] < 100_000
+    bands = sl.bands(8)
+    lists = sl.gather(bands)
+    r0, r1 = bands[3]
+    o, v = gpu.device.DeviceBuffer((r1 - r0) * w * 2 * 4), gpu.device.DeviceBuffer((r1 - r0) * w)
+    scratch = gpu.device.DeviceBuffer(sl.nb)
+    lib = sl.lib
+
+    def ms(fn, iters=4):
+        fn()
+        sl.nat.check(lib.ofl_stream_sync(None))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        sl.nat.check(lib.ofl_stream_sync(None))
+        return (time.perf_counter() - t0) * 1e3 / iters
+
+    t_full = ms(lambda: sl.full())
+    t_band = ms(lambda: (sl.stars(r0, r1 - r0, scratch.ptr), sl.finish(r0, r1 - r0, lists, 8, o, v)))
+    print(f"config 5 's' at 8K: whole field {t_full:.2f} ms, band 3/8 slab-wise {t_band:.2f} ms ({t_band / t_full:.2f})")
+    assert t_band < 0.45 * t_full

@@ -48,8 +48,19 @@ WORKER = textwrap.dedent("""
     got = sharding.broadcast_bytes(dist, uid, 0)
     mine = list(sharding.shard(10, rank, world))
     t = sharding.max_over_ranks(dist, [1.0 + rank, 5.0 - rank])
+    # the exchange of a slab-wise scatter as device.scatter_slab runs it, on host buffers: heads first, then as many
+    # 64-byte records per rank as the fullest list holds
+    cap, count = 100, [3, 41][rank]
+    lst = np.zeros(4 + 16 * cap, np.uint32)
+    lst[0] = count
+    lst[4:4 + 16 * count] = np.arange(16 * count, dtype=np.uint32) + 1000 * rank
+    heads = sharding.allgather_bytes(dist, lst[:4].view(np.uint8)).view(np.uint32)
+    m = sharding.slab_payload_entries(heads[:, 0], cap)
+    lists = sharding.allgather_bytes(dist, lst[:4 + 16 * m].view(np.uint8)).view(np.uint32)
     dist.barrier()
-    print(json.dumps({{"rank": rank, "uid_sum": int(got.astype(int).sum()), "items": mine, "t": t}}), flush=True)
+    print(json.dumps({{"rank": rank, "uid_sum": int(got.astype(int).sum()), "items": mine, "t": t, "m": m,
+                      "counts": lists[:, 0].tolist(), "shape": list(lists.shape),
+                      "rec": [int(lists[0, 4 + 16 * 2]), int(lists[1, 4 + 16 * 40 + 15])]}}), flush=True)
     dist.destroy_process_group()
 """)
 
@@ -80,6 +91,10 @@ def test_two_ranks_over_gloo(tmp_path):
     assert [d["uid_sum"] for d in outs] == [want_sum, want_sum]
     assert outs[0]["items"] + outs[1]["items"] == list(range(10))
     assert outs[0]["t"] == outs[1]["t"] == [2.0, 5.0]
+    for d in outs:                                  # both ranks hold both lists, trimmed to the fuller one
+        assert d["m"] == 41 and d["counts"] == [3, 41] and d["shape"] == [2, 4 + 16 * 41]
+        assert d["rec"] == [32, 1000 + 16 * 40 + 15]
+    assert sharding.slab_payload_entries([0, 0], 64) == 1 and sharding.slab_payload_entries([5, 900], 64) == 64
 
 
 SPAWNED = textwrap.dedent("""

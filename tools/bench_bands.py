@@ -98,7 +98,20 @@ def main():
     t_t = run(lambda: dev.gather_rows(dimg, r0, rows, flow_rows, -1, want_valid=True), args.steps, args.warmup)
     t_s = run(lambda: dev.scatter_rows(flow_full, +1, None, dimg.buf, 3, None, h, w, r0, rows, out_s, valid_s),
               max(2, args.steps // 4), 1)
+    # the same band with the star passes sharded: step 1, the exchange of the unfinished sites, step 2 (include/ofl.h)
+    hook = dev.comm_allgather if (world > 1 and nat.device_count() >= world) else (sharding.host_allgather(dist) if world > 1 else None)
+    slab = (lambda: dev.scatter_slab(flow_full, +1, None, dimg.buf, 3, None, h, w, r0, rows, out_s, valid_s, rank, world, gather=hook)) \
+        if world > 1 else (lambda: dev.scatter_slab(flow_full, +1, None, dimg.buf, 3, None, h, w, 0, h, out_s, valid_s))
+    t_slab = run(slab, max(2, args.steps // 4), 1)
     ok = None
+    if args.check:
+        slab()
+        band_slab = out_s.to_host((rows, w, 3), np.float32).copy()
+        bvalid_slab = valid_s.to_host((rows, w), np.uint8).copy()
+        dev.scatter_rows(flow_full, +1, None, dimg.buf, 3, None, h, w, r0, rows, out_s, valid_s)
+        same = bool(np.array_equal(band_slab.view(np.uint32), out_s.to_host((rows, w, 3), np.float32).view(np.uint32)) and
+                    np.array_equal(bvalid_slab, valid_s.to_host((rows, w), np.uint8)))
+        slab_ok = (sharding.max_over_ranks(dist, [0.0 if same else 1.0])[0] == 0.0) if dist is not None else same
     if args.check and rank == 0:
         full, fvalid = dev.gather_bilinear(dimg, flow_full, (h, w), -1, want_valid=True)
         band, bvalid = dev.gather_rows(dimg, r0, rows, flow_rows, -1, want_valid=True)
@@ -112,6 +125,9 @@ def main():
                           "n_gpus": world, "rows_per_rank": rows, "scaling": "strong",
                           "ref_t_ms_per_field": round(t_t * 1e3, 4), "ref_t_fields_per_s": round(1 / t_t, 1),
                           "ref_s_ms_per_field": round(t_s * 1e3, 4), "ref_s_fields_per_s": round(1 / t_s, 1),
+                          "ref_s_slab_ms_per_field": round(t_slab * 1e3, 4), "ref_s_slab_fields_per_s": round(1 / t_slab, 1),
+                          "slab_exchange": "none (1 rank)" if world == 1 else ("RCCL all-gather" if hook is dev.comm_allgather else "through the host (gloo): rehearsal"),
+                          "slab_band_equals_replicated_band": slab_ok if args.check else None,
                           "exchange": note, "band_equals_full": ok}), flush=True)
     if dist is not None:
         nat.check(lib.ofl_comm_destroy())

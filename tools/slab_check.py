@@ -17,7 +17,9 @@ import numpy as np
 import oflibnumpy_amd as of
 from oflibnumpy_amd import device as dev
 from oflibnumpy_amd import _native as nat
-from oflibnumpy_amd.sharding import row_band
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from slab_util import Slab, probe_values
 
 
 def field(op, h, w):
@@ -49,68 +51,7 @@ def field(op, h, w):
     return np.ascontiguousarray(v, np.float32), m
 
 
-class Slab:
-    """The raw C ABI with explicit buffers (tests/test_gpu_slab.py uses this class too)."""
-
-    def __init__(self, vecs, pmask, vals, entries=1 << 17):
-        self.lib = nat.load()
-        self.h, self.w = vecs.shape[:2]
-        self.C = vals.shape[2]
-        self.flow = dev.DeviceBuffer.from_host(vecs)
-        self.pm = dev.DeviceBuffer.from_host(np.ascontiguousarray(pmask).view(np.uint8)) if pmask is not None else None
-        self.vals = dev.DeviceBuffer.from_host(np.ascontiguousarray(vals, np.float32))
-        n = ctypes.c_size_t(0)
-        nat.check(self.lib.ofl_scatter_workspace_bytes(self.h, self.w, self.C, ctypes.byref(n)))
-        self.ws = dev.DeviceBuffer(n.value)
-        self.nb = dev.slab_list_bytes(entries)
-
-    def ptr(self, b):
-        return b.ptr if b is not None else None
-
-    def full(self):
-        h, w, C = self.h, self.w, self.C
-        out, valid = dev.DeviceBuffer(h * w * C * 4), dev.DeviceBuffer(h * w)
-        info = (ctypes.c_uint64 * 3)()
-        nat.check(self.lib.ofl_scatter_linear_dev(self.flow.ptr, 1, 0, self.ptr(self.pm), self.vals.ptr, C, None, h, w, None,
-                                                  out.ptr, valid.ptr, nat.SCATTER_UNCERTIFIED, self.ws.ptr, self.ws.nbytes, info, None))
-        return out, valid, tuple(info)
-
-    def stars(self, row0, rows, list_ptr):
-        nat.check(self.lib.ofl_scatter_slab_stars_dev(self.flow.ptr, 1, 0, self.ptr(self.pm), self.h, self.w, row0, rows,
-                                                      list_ptr, self.nb, self.ws.ptr, self.ws.nbytes, None))
-
-    def finish(self, row0, rows, lists, n_lists, out, valid):
-        info = (ctypes.c_uint64 * 3)()
-        nat.check(self.lib.ofl_scatter_slab_finish_dev(self.flow.ptr, 1, 0, self.vals.ptr, self.C, None, self.h, self.w, row0, rows,
-                                                       lists.ptr, self.nb, n_lists, out.ptr, valid.ptr, 0,
-                                                       self.ws.ptr, self.ws.nbytes, info, None))
-        return tuple(info)
-
-    def play(self, world, align=8):
-        """all ranks in turn -> (out [H][W][C], valid [H][W]) assembled from the bands, the gathered lists"""
-        h, w, C = self.h, self.w, self.C
-        bands = [row_band(h, r, world, align) for r in range(world)]
-        lists = dev.DeviceBuffer(self.nb * world)
-        for r, (r0, r1) in enumerate(bands):
-            if r1 > r0:
-                self.stars(r0, r1 - r0, lists.ptr + r * self.nb)
-            else:
-                nat.check(self.lib.ofl_memset(lists.ptr + r * self.nb, 0, self.nb, None))
-        out = np.zeros((h, w, C), np.float32)
-        valid = np.zeros((h, w), np.uint8)
-        scratch = dev.DeviceBuffer(self.nb)
-        for r, (r0, r1) in enumerate(bands):
-            if r1 <= r0:
-                continue
-            self.stars(r0, r1 - r0, scratch.ptr)                 # this rank's star state back into the one workspace
-            o, v = dev.DeviceBuffer((r1 - r0) * w * C * 4), dev.DeviceBuffer((r1 - r0) * w)
-            self.finish(r0, r1 - r0, lists, world, o, v)
-            out[r0:r1] = o.to_host((r1 - r0, w, C), np.float32)
-            valid[r0:r1] = v.to_host((r1 - r0, w), np.uint8)
-        return out, valid, lists, bands
-
-
-def event_ms(fn, iters=5):
+def wall_ms(fn, iters=5):
     lib = nat.load()
     fn()
     nat.check(lib.ofl_stream_sync(None))
@@ -134,16 +75,14 @@ def main():
     h, w = args.size
     vecs, m = field(args.op, h, w)
     h, w = vecs.shape[:2]
-    yy, xx = np.mgrid[:h, :w].astype(np.float32)
-    vals = np.stack([np.sin(xx / 37.0) + yy / 500.0, np.cos(yy / 23.0) * xx / 700.0], -1).astype(np.float32)
-    sl = Slab(vecs, m, vals)
+    sl = Slab(vecs, m, probe_values(h, w))
     res = {"op": args.op, "shape": [h, w], "world": args.world}
     if not args.no_check:
         fo, fv, info = sl.full()
         fo = fo.to_host((h, w, 2), np.float32)
         fv = fv.to_host((h, w), np.uint8)
         out, valid, lists, bands = sl.play(args.world)
-        counts = [int(dev.DeviceBuffer.to_host(_View(lists.ptr + r * sl.nb), (4,), np.uint32)[0]) for r in range(args.world)]
+        counts = sl.counts(lists, args.world)[0]
         res.update({"kept_unfinished_left": list(map(int, info)), "unfinished_per_rank": counts,
                     "bands_equal_full": bool(np.array_equal(out.view(np.uint32), fo.view(np.uint32)) and np.array_equal(valid, fv)),
                     "valid_fraction": float(fv.mean())})
@@ -154,38 +93,22 @@ def main():
             res["differing_rows"] = [int(ys.min()), int(ys.max())]
             res["bands"] = bands
     else:
-        lists, bands = play_lists(sl, args.world)
+        bands = sl.bands(args.world)
+        lists = sl.gather(bands)
     r0, r1 = bands[args.band]
     o, v = dev.DeviceBuffer((r1 - r0) * w * 2 * 4), dev.DeviceBuffer((r1 - r0) * w)
     scratch = dev.DeviceBuffer(sl.nb)
     if args.profile:
-        t_ab = event_ms(lambda: (sl.stars(r0, r1 - r0, scratch.ptr), sl.finish(r0, r1 - r0, lists, args.world, o, v)))
+        t_ab = wall_ms(lambda: (sl.stars(r0, r1 - r0, scratch.ptr), sl.finish(r0, r1 - r0, lists, args.world, o, v)))
         print(json.dumps({"op": args.op, "band": [r0, r1], "slab_band_ms": round(t_ab, 3)}))
         return
-    t_full = event_ms(lambda: sl.full())
-    t_a = event_ms(lambda: sl.stars(r0, r1 - r0, scratch.ptr))
-    t_ab = event_ms(lambda: (sl.stars(r0, r1 - r0, scratch.ptr), sl.finish(r0, r1 - r0, lists, args.world, o, v)))
-    info = (ctypes.c_uint64 * 3)()
-    t_rows = event_ms(lambda: nat.check(sl.lib.ofl_scatter_rows_dev(sl.flow.ptr, 1, 0, sl.ptr(sl.pm), sl.vals.ptr, 2, None, h, w, r0, r1 - r0,
-                                                                    o.ptr, v.ptr, nat.SCATTER_UNCERTIFIED, sl.ws.ptr, sl.ws.nbytes, info, None)))
+    t_full = wall_ms(lambda: sl.full())
+    t_a = wall_ms(lambda: sl.stars(r0, r1 - r0, scratch.ptr))
+    t_ab = wall_ms(lambda: (sl.stars(r0, r1 - r0, scratch.ptr), sl.finish(r0, r1 - r0, lists, args.world, o, v)))
+    t_rows = wall_ms(lambda: sl.full(r0, r1 - r0))
     res.update({"band": [r0, r1], "full_ms": round(t_full, 3), "replicated_band_ms": round(t_rows, 3), "slab_step1_ms": round(t_a, 3),
                 "slab_band_ms": round(t_ab, 3), "slab_over_full": round(t_ab / t_full, 3)})
     print(json.dumps(res))
-
-
-class _View:
-    """a DeviceBuffer-like view for to_host"""
-
-    def __init__(self, ptr):
-        self.ptr = ptr
-
-
-def play_lists(sl, world):
-    bands = [row_band(sl.h, r, world, 8) for r in range(world)]
-    lists = dev.DeviceBuffer(sl.nb * world)
-    for r, (r0, r1) in enumerate(bands):
-        sl.stars(r0, r1 - r0, lists.ptr + r * sl.nb)
-    return lists, bands
 
 
 if __name__ == "__main__":

@@ -269,7 +269,9 @@ int ofl_scatter_workspace_bytes(int H, int W, int C, size_t *bytes);
  *      or fall back to ofl_scatter_rows_dev.
  *   2. all-gather the lists (ofl_comm_allgather: `list_bytes` per rank, in rank order or any other).
  *   3. ofl_scatter_slab_finish_dev with the gathered buffer (`n_lists` lists of `list_bytes` each, this rank's among
- *      them) and THE SAME workspace, untouched since step 1: every rank finishes all unfinished stars (they can reach
+ *      them) and THE SAME workspace, untouched since step 1 (checked: step 1 stamps its band into the workspace, a
+ *      workspace without that stamp -- no step 1, another band's, any other scatter call in between, a second step 2 --
+ *      is refused with OFL_E_INVALID before any kernel runs): every rank finishes all unfinished stars (they can reach
  *      any band), rasterises and resolves its rows.  out_rows / valid_rows / valid_rule / info_host as above; the call
  *      synchronises (it reads the error bits back: an error on one rank blanks every band).
  * The concatenation of the bands equals ofl_scatter_linear_dev with OFL_SCATTER_UNCERTIFIED bit for bit.  A field whose

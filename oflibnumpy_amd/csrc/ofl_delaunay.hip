@@ -66,7 +66,7 @@ constexpr unsigned kDedupeSmall = 256;    // buckets up to this size drop their 
 constexpr unsigned kMaxFar   = 1u << 20;  // unfinished stars ...
 constexpr unsigned kMaxLeft  = 1u << 18;  // ... and stars for the workgroup pass (quadratic in their number) before the call gives up
 constexpr unsigned kErrDegenerate = 16u;  // err bit: one of the three limits above -- Qhull, too, refuses such input ("initial simplex is flat")
-constexpr unsigned kErrSlabList = 32u;    // err bit: a rank's list of unfinished sites did not fit the buffer the caller gave it (slab mode)
+constexpr unsigned kErrSlabList = 32u;    // err bit (slab mode): a rank's list of unfinished sites did not fit the buffer the caller gave it, or is not a list of this field
 constexpr int      kSlabMargin = 2 * (kRings + 1) + 2;   // buckets around a row band within which the slab mode builds every star (see exact_stars)
 constexpr int      kScanChunk = 2048;    // elements per block of the scan kernels (256 threads x 8)
 
@@ -81,7 +81,8 @@ struct DlHead {                           // device header of the exact path (25
     unsigned n_big;                                  // sorted entries that live in buckets of more than kDedupeSmall entries
     unsigned live_huge;                              // distinct sites left in buckets of more than kMaxBucket entries
     double   need_lo, need_hi;                       // slab mode: only sites with need_lo <= y <= need_hi get a star from cells / fans / clip (else -inf, +inf)
-    unsigned pad[6];
+    unsigned slab_stamp;                             // slab mode: 1 + row0 * 65536 + rows of the band step 1 ran for (0: not a slab state)
+    unsigned pad[5];
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
 
@@ -217,6 +218,8 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     }
 }
 
+__host__ __device__ inline unsigned slab_stamp_of(int row0, int rows) { return 1u + (unsigned)row0 * 65536u + (unsigned)rows; }
+
 __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale, int H, int W, int slab, int row0, int rows)
 {
     Grid g;
@@ -263,6 +266,7 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
     // the rings" by bucket number only -- a slab that comes this close to the border rows takes everything beyond them, too)
     if (head->need_lo < g.oy + (double)(kRings + 2) * g.s) head->need_lo = -inf;
     if (head->need_hi > g.oy + (double)(g.gy - kRings - 2) * g.s) head->need_hi = inf;
+    head->slab_stamp = slab ? slab_stamp_of(row0, rows) : 0u;
     Grid g1 = g;                                     // coarse grid of the unfinished points: kMidScale fine buckets per cell
     g1.s = g.s * kMidScale; g1.inv_s = 1.0 / g1.s;
     g1.gx = (g.gx + kMidScale - 1) / kMidScale; g1.gy = (g.gy + kMidScale - 1) / kMidScale;
@@ -2126,7 +2130,7 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
         else if (h.err) late_error = fail(OFL_E_INVALID, "ofl_scatter_linear: exact path capacity exceeded (flags %u: 1 = star of more than %d "
                                               "neighbours, 2 = neighbour pool, 4 = large-triangle list, 8 = unfinished stars beyond the "
                                               "triangle-id space, 16 = degenerate point set: thousands of coincident points or hundreds of "
-                                              "thousands of unbounded cells; 32 = a rank's list of unfinished sites exceeded its buffer)", h.err, kFarCap);
+                                              "thousands of unbounded cells; 32 = slab mode: a rank's list of unfinished sites exceeded its buffer)", h.err, kFarCap);
     }
     return OFL_OK;
 }
@@ -2216,6 +2220,20 @@ int exact_slab_finish(const float *flow, int sign_pp, const float *vals, int C, 
     DlWs ws = carve_band(workspace, H, W, row0, rows);
     const size_t n = (size_t)H * W;
     const size_t cap = std::min<size_t>((stride_bytes / 4 - kSlabHead) / kSlots, 0xFFFFFFFFu);
+    {   // Is this the state step 1 left for THIS band?  Everything below trusts the lists and counts in the workspace: a
+        // foreign one must not reach a kernel.  (One 4-byte read-back; the call synchronises at its end anyway.  The stamp is
+        // cleared right away: a state is finished once.)
+        unsigned stamp = 0;
+        OFL_HIP(hipMemcpyAsync(&stamp, &ws.head->slab_stamp, 4, hipMemcpyDeviceToHost, s));
+        OFL_HIP(hipStreamSynchronize(s));
+        if (stamp != slab_stamp_of(row0, rows)) {
+            if (C > 0) OFL_HIP(hipMemsetAsync(out, 0, (size_t)rows * W * C * sizeof(float), s));
+            if (valid) OFL_HIP(hipMemsetAsync(valid, 0, (size_t)rows * W, s));
+            return fail(OFL_E_INVALID, "ofl_scatter_slab_finish: the workspace does not hold the state ofl_scatter_slab_stars_dev left for rows "
+                                       "[%d, %d) (another call used it in between, or step 1 ran for another band)", row0, row0 + rows);
+        }
+        OFL_HIP(hipMemsetAsync(&ws.head->slab_stamp, 0, 4, s));
+    }
     hipLaunchKernelGGL(dl_slab_absorb_kernel, dim3(256), dim3(256), 0, s, ws.head, lists, stride_bytes / 4, n_lists, (unsigned)cap, n, ws.deg, ws.nbr);
     OFL_HIP(hipGetLastError());
     unsigned far_base = 0;

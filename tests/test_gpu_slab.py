@@ -116,6 +116,36 @@ def test_list_overflow_blanks_every_band(gpu):
         assert not o.to_host((r1 - r0, 384, 2), np.float32).any()
 
 
+def test_step_2_refuses_a_workspace_that_is_not_its_step_1s(gpu):
+    """step 2 trusts the lists and counts in the workspace, so it checks the stamp step 1 left: no step 1, a step 1 for another
+    band, a whole-field call in between, or a second step 2 on the same state -> OFL_E_INVALID, outputs zeroed, no kernel runs"""
+    h, w = 128, 192
+    vecs, m = make_field("speckle", h, w)
+    sl = Slab(vecs, m, probe_values(h, w))
+    bands = sl.bands(2)
+    lists = sl.gather(bands)
+    (a0, a1), (b0, b1) = bands
+    o, v = gpu.device.DeviceBuffer((a1 - a0) * w * 2 * 4), gpu.device.DeviceBuffer((a1 - a0) * w)
+    scratch = gpu.device.DeviceBuffer(sl.nb)
+
+    def refused():
+        sl.nat.check(sl.lib.ofl_memset(o.ptr, 0x3F, o.nbytes, None))
+        sl.nat.check(sl.lib.ofl_memset(v.ptr, 1, v.nbytes, None))
+        rc, _ = sl.finish(a0, a1 - a0, lists, 2, o, v, check=False)
+        assert rc == gpu.native.E_INVALID and "workspace" in gpu.native.last_error()
+        assert not o.to_host((a1 - a0, w, 2), np.float32).any() and not v.to_host((a1 - a0, w), np.uint8).any()
+
+    sl.stars(b0, b1 - b0, scratch.ptr)                      # the OTHER band's state
+    refused()
+    sl.stars(a0, a1 - a0, scratch.ptr)
+    sl.full()                                               # a whole-field call on the same workspace in between
+    refused()
+    sl.stars(a0, a1 - a0, scratch.ptr)
+    rc, _ = sl.finish(a0, a1 - a0, lists, 2, o, v)
+    assert rc == 0 and v.to_host((a1 - a0, w), np.uint8).any()
+    refused()                                               # a state is finished once
+
+
 def test_argument_checks(gpu):
     vecs, m = make_field("speckle", 64, 96)
     sl = Slab(vecs, m, probe_values(64, 96))

@@ -82,7 +82,8 @@ struct DlHead {                           // device header of the exact path (25
     unsigned live_huge;                              // distinct sites left in buckets of more than kMaxBucket entries
     double   need_lo, need_hi;                       // slab mode: only sites with need_lo <= y <= need_hi get a star from cells / fans / clip (else -inf, +inf)
     unsigned slab_stamp;                             // slab mode: 1 + row0 * 65536 + rows of the band step 1 ran for (0: not a slab state)
-    unsigned pad[5];
+    unsigned skip_fans;                              // the mesh-cell pass settled (next to) nothing: the mesh is no guide to this triangulation
+    unsigned pad[4];
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
 
@@ -642,6 +643,30 @@ void dl_site_cells_kernel(const float *__restrict__ flow, int sign, const uint8_
     deg[p] = n > 0 ? (unsigned char)n : kDegFan;
 }
 
+// Is the mesh worth proposing fans from?  On a strongly sheared field (BASELINE config 5: every source row slides 1 .. 19 px
+// against the next, 42 % of the sites are duplicates) the Delaunay neighbours of a site have nothing to do with its grid
+// neighbours: the cell pass verifies NO cell and the fan pass would spend 0.84 ms at 8K to verify no fan.  4 096 sites are
+// sampled at a fixed stride: when at least 64 of them wait for the fan pass and fewer than 1 in 128 as many were settled by
+// the cells, the fan pass only relabels its list for the clip pass.  A speed decision only -- the clip pass computes the
+// same stars the fans would have verified.
+__global__ __launch_bounds__(1024)
+void dl_fan_decide_kernel(const unsigned char *__restrict__ deg, size_t n, DlHead *head)
+{
+    __shared__ unsigned s_fan, s_ok;
+    if (threadIdx.x == 0) { s_fan = 0; s_ok = 0; }
+    __syncthreads();
+    const size_t stride = n / 4096 + 1;
+    unsigned fan = 0, ok = 0;
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = ((size_t)threadIdx.x * 4 + k) * stride;
+        if (i < n) { const unsigned d = deg[i]; fan += d == kDegFan; ok += d >= 1 && d <= kSlots; }
+    }
+    if (fan) atomicAdd(&s_fan, fan);
+    if (ok) atomicAdd(&s_ok, ok);
+    __syncthreads();
+    if (threadIdx.x == 0) head->skip_fans = (s_fan >= 64 && s_ok * 128 < s_fan) ? 1u : 0u;
+}
+
 // ------------------------------------------------------------------------------------------------ stars, mesh-fan pass
 // One thread per point: a point whose eight grid neighbours are kept proposes the star of the cell-wise mesh and verifies
 // it against the sites under its circumcircles (ofl_dl::star_fan).  Verified stars are final; everything else is marked
@@ -654,6 +679,10 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
 {
     __shared__ P2 s_rel[8][kFanBlock];
     const unsigned n_fan = head->n_fan;                         // the sites the cell pass did not settle, in index order
+    if (head->skip_fans) {                                      // (dl_fan_decide_kernel)
+        for (unsigned i = blockIdx.x * kFanBlock + threadIdx.x; i < n_fan; i += gridDim.x * kFanBlock) deg[todo[i]] = kDegTodo;
+        return;
+    }
     for (unsigned i = blockIdx.x * kFanBlock + threadIdx.x; i < n_fan; i += gridDim.x * kFanBlock) {
         const size_t p = todo[i];
         const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
@@ -2021,6 +2050,7 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
         hipLaunchKernelGGL(dl_site_cells_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
                            (const unsigned char *)ws.dup, (const unsigned char *)ws.cellflag, ws.deg, ws.nbr);
     }
+    hipLaunchKernelGGL(dl_fan_decide_kernel, dim3(1), dim3(1024), 0, s, (const unsigned char *)ws.deg, n, ws.head);
     hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
     hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,

@@ -10,7 +10,7 @@ import numpy as np
 
 
 class Slab:
-    def __init__(self, vecs, pmask, vals, entries=1 << 17, sign=1, point_precision=0):
+    def __init__(self, vecs, pmask, vals, entries=1 << 17, sign=1, point_precision=0, vmask=None, valid_rule=0):
         from oflibnumpy_amd import _native as nat
         from oflibnumpy_amd import device as dev
         self.nat, self.dev, self.lib = nat, dev, nat.load()
@@ -20,6 +20,8 @@ class Slab:
         self.flow = dev.DeviceBuffer.from_host(np.ascontiguousarray(vecs, np.float32))
         self.pm = dev.DeviceBuffer.from_host(np.ascontiguousarray(pmask).astype(np.uint8)) if pmask is not None else None
         self.vals = dev.DeviceBuffer.from_host(np.ascontiguousarray(vals, np.float32))
+        self.vm = dev.DeviceBuffer.from_host(np.ascontiguousarray(vmask).astype(np.uint8)) if vmask is not None else None
+        self.rule = valid_rule
         n = ctypes.c_size_t(0)
         nat.check(self.lib.ofl_scatter_workspace_bytes(self.h, self.w, self.C, ctypes.byref(n)))
         self.ws = dev.DeviceBuffer(n.value)
@@ -34,8 +36,8 @@ class Slab:
         rows = h if rows is None else rows
         out, valid = self.dev.DeviceBuffer(rows * w * C * 4), self.dev.DeviceBuffer(rows * w)
         info = (ctypes.c_uint64 * 3)()
-        self.nat.check(self.lib.ofl_scatter_rows_dev(self.flow.ptr, self.sign, self.pp, self._p(self.pm), self.vals.ptr, C, None, h, w,
-                                                     row0, rows, out.ptr, valid.ptr, self.nat.SCATTER_UNCERTIFIED,
+        self.nat.check(self.lib.ofl_scatter_rows_dev(self.flow.ptr, self.sign, self.pp, self._p(self.pm), self.vals.ptr, C, self._p(self.vm), h, w,
+                                                     row0, rows, out.ptr, valid.ptr, self.rule | self.nat.SCATTER_UNCERTIFIED,
                                                      self.ws.ptr, self.ws.nbytes, info, None))
         return out, valid, tuple(info)
 
@@ -45,8 +47,8 @@ class Slab:
 
     def finish(self, row0, rows, lists, n_lists, out, valid, check=True):
         info = (ctypes.c_uint64 * 3)()
-        rc = self.lib.ofl_scatter_slab_finish_dev(self.flow.ptr, self.sign, self.pp, self.vals.ptr, self.C, None, self.h, self.w, row0, rows,
-                                                  lists.ptr, self.nb, n_lists, out.ptr, valid.ptr, 0,
+        rc = self.lib.ofl_scatter_slab_finish_dev(self.flow.ptr, self.sign, self.pp, self.vals.ptr, self.C, self._p(self.vm), self.h, self.w, row0, rows,
+                                                  lists.ptr, self.nb, n_lists, out.ptr, valid.ptr, self.rule,
                                                   self.ws.ptr, self.ws.nbytes, info, None)
         if check:
             self.nat.check(rc)

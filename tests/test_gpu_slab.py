@@ -97,6 +97,18 @@ def test_float32_points_and_negated_field(gpu):
         assert_bands_equal_full(sl, 3)
 
 
+def test_value_masks_and_valid_rules(gpu):
+    """the resolve step of a band is the whole-field one: a mask on the VALUES (Flow.apply's target mask, flow_class.py:643-668)
+    under the three validity rules, with and without the rounding of integer targets"""
+    h, w = 200, 320
+    vecs, m = make_field("speckle", h, w)
+    vm = np.random.default_rng(3).random((h, w)) > 0.2
+    vals = np.round(40.0 * probe_values(h, w))
+    for rule in (0, 1, 2, 2 | gpu.native.SCATTER_ROUND, gpu.native.SCATTER_NEGATE):
+        sl = Slab(vecs, m, vals, vmask=vm, valid_rule=rule)
+        assert_bands_equal_full(sl, 3)
+
+
 def test_list_overflow_blanks_every_band(gpu):
     """a list buffer too small for a rank's unfinished sites: step 2 reports it ON EVERY RANK and returns an all-invalid band"""
     vecs, m = make_field("hole", 256, 384)

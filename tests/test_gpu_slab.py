@@ -89,6 +89,31 @@ def test_bands_thinner_than_the_slab_margin(gpu):
     assert_bands_equal_full(sl, 5, align=1)                  # band edges off the 8-row tiles
 
 
+def test_randomised_fields_worlds_and_band_edges(gpu):
+    """seeded sweep: smooth fields with jumps, random point masks of every density, any number of ranks, band edges on and off
+    the 8-row tiles -- bands == whole field, bit for bit"""
+    rng = np.random.default_rng(2024)
+    for case in range(16):
+        h, w = int(rng.integers(24, 180)), int(rng.integers(40, 260))
+        yy, xx = np.mgrid[:h, :w].astype(np.float32)
+        amp = float(rng.choice([0.3, 2.0, 9.0]))
+        v = np.stack([amp * np.sin(xx / rng.uniform(5, 40) + yy / rng.uniform(7, 60)),
+                      amp * np.cos(yy / rng.uniform(5, 40) - xx / rng.uniform(9, 70))], -1).astype(np.float32)
+        if rng.random() < 0.5:                                  # a block that moves on its own: folds and tears
+            y0, x0 = int(rng.integers(0, h // 2)), int(rng.integers(0, w // 2))
+            v[y0:y0 + h // 3, x0:x0 + w // 3] += rng.uniform(-12, 12, 2).astype(np.float32)
+        if rng.random() < 0.3:
+            v = np.round(v)                                     # lattice sites, duplicates
+        keep = float(rng.choice([1.0, 0.97, 0.7, 0.3]))
+        m = None if keep == 1.0 else rng.random((h, w)) < keep
+        sl = Slab(v, m, probe_values(h, w), entries=1 << 15)
+        world, align = int(rng.integers(2, 10)), int(rng.choice([1, 8]))
+        try:
+            assert_bands_equal_full(sl, world, align)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {h} x {w}, amp {amp}, keep {keep}, world {world}, align {align}: {e}")
+
+
 def test_float32_points_and_negated_field(gpu):
     """the two other ways the entries are called: positions rounded to float32 (mode 2), sign -1 (flow_class.py:1398-1400)"""
     vecs, m = make_field("speckle", 200, 320)

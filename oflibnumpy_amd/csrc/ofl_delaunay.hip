@@ -81,7 +81,7 @@ struct DlHead {                           // device header of the exact path (25
     unsigned n_big;                                  // sorted entries that live in buckets of more than kDedupeSmall entries
     unsigned live_huge;                              // distinct sites left in buckets of more than kMaxBucket entries
     double   need_lo, need_hi;                       // slab mode: only sites with need_lo <= y <= need_hi get a star from cells / fans / clip (else -inf, +inf)
-    unsigned slab_stamp;                             // slab mode: 1 + row0 * 65536 + rows of the band step 1 ran for (0: not a slab state)
+    unsigned slab_stamp;                             // slab mode: slab_stamp_of(field, band) step 1 ran for (0: not a slab state)
     unsigned skip_fans;                              // the mesh-cell pass settled (next to) nothing: the mesh is no guide to this triangulation
     unsigned pad[4];
 };
@@ -219,7 +219,12 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     }
 }
 
-__host__ __device__ inline unsigned slab_stamp_of(int row0, int rows) { return 1u + (unsigned)row0 * 65536u + (unsigned)rows; }
+// what step 1 of the slab mode leaves in the header for step 2 to recognise: the band and the field it ran for (never 0)
+__host__ __device__ inline unsigned slab_stamp_of(int H, int W, int row0, int rows)
+{
+    const unsigned v = ((unsigned)row0 * 65536u + (unsigned)rows) ^ ((unsigned)H * 2654435761u) ^ ((unsigned)W * 40503u);
+    return v ? v : 1u;
+}
 
 __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale, int H, int W, int slab, int row0, int rows)
 {
@@ -267,7 +272,7 @@ __global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double b
     // the rings" by bucket number only -- a slab that comes this close to the border rows takes everything beyond them, too)
     if (head->need_lo < g.oy + (double)(kRings + 2) * g.s) head->need_lo = -inf;
     if (head->need_hi > g.oy + (double)(g.gy - kRings - 2) * g.s) head->need_hi = inf;
-    head->slab_stamp = slab ? slab_stamp_of(row0, rows) : 0u;
+    head->slab_stamp = slab ? slab_stamp_of(H, W, row0, rows) : 0u;
     Grid g1 = g;                                     // coarse grid of the unfinished points: kMidScale fine buckets per cell
     g1.s = g.s * kMidScale; g1.inv_s = 1.0 / g1.s;
     g1.gx = (g.gx + kMidScale - 1) / kMidScale; g1.gy = (g.gy + kMidScale - 1) / kMidScale;
@@ -1897,7 +1902,14 @@ void dl_slab_absorb_kernel(DlHead *__restrict__ head, const unsigned *__restrict
             const uint4 *src = reinterpret_cast<const uint4 *>(list + kSlabHead + (size_t)k * kSlots);
             const uint4 r0 = src[0];
             const size_t p = r0.x;
-            if (p >= n) { atomicOr(&head->err, kErrSlabList); continue; }     // not a list of this field
+            // not a list of this field?  (the later passes take positions from the seeds' site numbers: none may leave the field)
+            const uint4 r1 = src[1], r2 = src[2], r3 = src[3];
+            const unsigned sd[12] = { r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y };
+            const unsigned ns = r0.y < (unsigned)(kSlots - 4) ? r0.y : (unsigned)(kSlots - 4);
+            bool bad = p >= n;
+#pragma unroll
+            for (unsigned k2 = 0; k2 < (unsigned)(kSlots - 4); ++k2) bad = bad || (k2 < ns && sd[k2] >= n && sd[k2] < 0xFFFFFFFCu);      // (-1 .. -4: box sides)
+            if (bad) { atomicOr(&head->err, kErrSlabList); continue; }
             deg[p] = kDegFar;
             uint4 *dst = reinterpret_cast<uint4 *>(nbr + p * kSlots);
             dst[0] = r0; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
@@ -2256,7 +2268,7 @@ int exact_slab_finish(const float *flow, int sign_pp, const float *vals, int C, 
         unsigned stamp = 0;
         OFL_HIP(hipMemcpyAsync(&stamp, &ws.head->slab_stamp, 4, hipMemcpyDeviceToHost, s));
         OFL_HIP(hipStreamSynchronize(s));
-        if (stamp != slab_stamp_of(row0, rows)) {
+        if (stamp != slab_stamp_of(H, W, row0, rows)) {
             if (C > 0) OFL_HIP(hipMemsetAsync(out, 0, (size_t)rows * W * C * sizeof(float), s));
             if (valid) OFL_HIP(hipMemsetAsync(valid, 0, (size_t)rows * W, s));
             return fail(OFL_E_INVALID, "ofl_scatter_slab_finish: the workspace does not hold the state ofl_scatter_slab_stars_dev left for rows "

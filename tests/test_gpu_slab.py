@@ -153,6 +153,28 @@ def test_list_overflow_blanks_every_band(gpu):
         assert not o.to_host((r1 - r0, 384, 2), np.float32).any()
 
 
+def test_a_list_that_is_not_of_this_field_is_refused(gpu):
+    """the records carry site numbers the later passes take positions from: one that leaves the field (a list of another
+    field, a damaged transfer) raises flag 32 and blanks the band instead of reading out of bounds"""
+    h, w = 128, 192
+    vecs, m = make_field("hole", h, w)
+    sl = Slab(vecs, m, probe_values(h, w), entries=4096)
+    lists = sl.gather([(0, h)])
+    host = lists.to_host((sl.nb // 4,), np.uint32).copy()
+    assert host[0] > 8
+    for word, value in ((4 + 16 * 3 + 0, h * w + 5), (4 + 16 * 5 + 2, 0x7FFFFFFF)):      # a site index, a seed
+        bad = host.copy()
+        assert bad[4 + 16 * 5 + 1] >= 1                                                  # (record 5 has at least one seed)
+        bad[word] = value
+        dl = gpu.device.DeviceBuffer.from_host(bad)
+        scratch = gpu.device.DeviceBuffer(sl.nb)
+        sl.stars(0, h, scratch.ptr)
+        o, v = gpu.device.DeviceBuffer(h * w * 2 * 4), gpu.device.DeviceBuffer(h * w)
+        rc, _ = sl.finish(0, h, dl, 1, o, v, check=False)
+        assert rc == gpu.native.E_INVALID and "32" in gpu.native.last_error()
+        assert not v.to_host((h, w), np.uint8).any()
+
+
 def test_step_2_refuses_a_workspace_that_is_not_its_step_1s(gpu):
     """step 2 trusts the lists and counts in the workspace, so it checks the stamp step 1 left: no step 1, a step 1 for another
     band, a whole-field call in between, or a second step 2 on the same state -> OFL_E_INVALID, outputs zeroed, no kernel runs"""

@@ -127,6 +127,15 @@ class DeviceBuffer:
         return out
 
 
+class _BufferView:
+    """Part of a DeviceBuffer (an address and a length; the buffer itself stays with its owner)."""
+
+    __slots__ = ("ptr", "nbytes")
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, int(nbytes)
+
+
 class PinnedArray:
     """A NumPy view of page-locked host memory (ofl_host_alloc): transfers from / to it are asynchronous DMA."""
 
@@ -490,6 +499,84 @@ class DeviceFlow:
         scatter_linear(self.vecs, +1, pm, image.buf, C, vmask, h, w, None, out.buf, valid, 0,
                        cert=self.mesh_cert(+1) if pm is None else None, drops_points=pm is not None)
         return out, valid
+
+    def apply_image_rows(self, image, rank, world, target_mask=None, consider_mask=True, quant=nat.QUANT_OPENCV,
+                         gather=None, align=8):
+        """This rank's ROW BAND of apply_image when ONE field is split over `world` GPUs (BASELINE config 5):
+        flow, masks and image are the replicated H x W arrays, the result holds rows sharding.row_band(H, rank, world, align)
+        only -- (DeviceImage rows x W x C, valid rows x W, (row0, row1)); the bands of all ranks concatenate to
+        apply_image's result bit for bit.  't': one launch of the gather kernel on the band (nothing is exchanged).  's':
+        a field whose mesh certifies resolves its rows in one kernel (nothing is exchanged); any other field takes the
+        slab-wise Delaunay path with its one all-gather (`gather`: see scatter_slab; default RCCL)."""
+        from .sharding import row_band
+        h, w = self.shape
+        if image.shape[:2] != (h, w):
+            raise ValueError("image and flow need the same height and width")
+        r0, r1 = row_band(h, rank, world, align)
+        rows = r1 - r0
+        C = image.shape[2]
+        if rows <= 0:
+            return None, None, (r0, r1)
+        at = lambda buf, off, n: _BufferView(buf.ptr + off, n)
+        if self.ref == 't':
+            arith, rule = nat.ARITH_NATIVE, nat.RULE_EQ1
+            if image.dtype == np.uint8:
+                arith, rule = (nat.ARITH_NATIVE, nat.RULE_GE_HALF) if target_mask is not None else (nat.ARITH_FLOAT_RNE, nat.RULE_GT_HALF)
+            elif image.dtype == np.int16 or (image.dtype == np.uint16 and target_mask is not None):
+                rule = nat.RULE_GT_HALF
+            elif image.dtype == np.uint16:
+                raise TypeError("uint16 image with the default int8 mask needs an int32 remap, which cv2.remap does not provide")
+            if self.is_zero(thresholded=True, masked=False):        # identity short cut, utils.py:215-216
+                nb = rows * w * C * image.dtype.itemsize
+                dst = DeviceImage(DeviceBuffer(nb), (rows, w, C), image.dtype)
+                nat.check(_lib().ofl_copy_dev(dst.buf.ptr, image.buf.ptr + r0 * w * C * image.dtype.itemsize, nb, None))
+                valid = DeviceBuffer(rows * w)
+                if target_mask is None:
+                    nat.check(_lib().ofl_copy_dev(valid.ptr, self.mask.ptr + r0 * w, rows * w, None))
+                else:
+                    _mask_and(at(self.mask, r0 * w, rows * w), at(target_mask, r0 * w, rows * w), valid, rows * w)
+                return dst, valid, (r0, r1)
+            dst, valid = gather_rows(image, r0, rows, at(self.vecs, r0 * w * 8, rows * w * 8), -1, smask=target_mask,
+                                     fmask_rows=at(self.mask, r0 * w, rows * w), want_valid=True, quant=quant, arith=arith, rule=rule)
+            return dst, valid, (r0, r1)
+        if image.dtype != np.float32:
+            raise TypeError("'s'-reference warps of device images need float32 (got {})".format(image.dtype))
+        vmask = self.mask
+        if target_mask is not None:
+            vmask = DeviceBuffer(self.n_px)
+            _mask_and(target_mask, self.mask, vmask, self.n_px)                  # flow_class.py:643
+        if self.is_zero(thresholded=True, masked=False):
+            nb = rows * w * C * 4
+            dst = DeviceImage(DeviceBuffer(nb), (rows, w, C), np.float32)
+            nat.check(_lib().ofl_copy_dev(dst.buf.ptr, image.buf.ptr + r0 * w * C * 4, nb, None))
+            valid = DeviceBuffer(rows * w)
+            nat.check(_lib().ofl_copy_dev(valid.ptr, vmask.ptr + r0 * w, rows * w, None))
+            return dst, valid, (r0, r1)
+        out = DeviceImage(DeviceBuffer(rows * w * C * 4), (rows, w, C), np.float32)
+        valid = DeviceBuffer(rows * w)
+        pm = self._point_mask(consider_mask)
+        cert = self.mesh_cert(+1) if pm is None else None
+        if cert is not None and cert.certified and not getattr(cert, "_walk_checked", False):
+            # Does the walk kernel find every node of this certified mesh (scatter_linear)?  The answer must be the SAME on
+            # every rank -- a rank that went on alone to the slab-wise path would wait for the others in its all-gather --
+            # so each rank asks for the whole field once per certificate (validity only: 0.1 ms at 4K), not for its band.
+            cnt, scratch = DeviceBuffer.zeros(16), DeviceBuffer(self.n_px)
+            nat.check(_lib().ofl_scatter_certified_dev(self.vecs.ptr, +1, 0, None, 0, vmask.ptr, h, w, 0, h,
+                                                       None, scratch.ptr, 0, ctypes.byref(cert), cnt.ptr, None))
+            if int(cnt.to_host((1,), np.uint32)[0]) == 0:
+                cert._walk_checked = True
+            else:
+                cert.certified = 0
+        if cert is not None and cert.certified:
+            nat.check(_lib().ofl_scatter_certified_dev(self.vecs.ptr, +1, 0, image.buf.ptr, C, vmask.ptr, h, w, r0, rows,
+                                                       out.buf.ptr, valid.ptr, 0, ctypes.byref(cert), None, None))
+            return out, valid, (r0, r1)
+        if world <= 1:
+            scatter_linear(self.vecs, +1, pm, image.buf, C, vmask, h, w, None, out.buf, valid, nat.SCATTER_UNCERTIFIED)
+        else:
+            scatter_slab(self.vecs, +1, pm, image.buf, C, vmask, h, w, r0, rows, out.buf, valid, rank, world,
+                         gather=gather if gather is not None else comm_allgather)
+        return out, valid, (r0, r1)
 
     def resize(self, scale):
         """Flow.resize (flow_class.py:491-506) on HBM-resident data: one launch of the resize kernel."""

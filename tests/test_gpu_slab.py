@@ -299,3 +299,57 @@ def test_config5_8k_slab_bands_and_time(gpu):
     t_band = ms(lambda: (sl.stars(r0, r1 - r0, scratch.ptr), sl.finish(r0, r1 - r0, lists, 8, o, v)))
     print(f"config 5 's' at 8K: whole field {t_full:.2f} ms, band 3/8 slab-wise {t_band:.2f} ms ({t_band / t_full:.2f})")
     assert t_band < 0.45 * t_full
+
+
+def test_apply_image_rows_equals_apply_image(gpu):
+    """DeviceFlow.apply_image_rows, the user-level entry of SURVEY 8e: 't' (gather band), 's' on a certified mesh (walk kernel
+    on the band), 's' on a field the certificate refuses (slab-wise path; the other ranks are played by the `gather` hook on
+    a second stream, i.e. a second workspace) -- bands of all ranks == apply_image, bit for bit, values and valid area"""
+    from oflibnumpy_amd import device as dev
+    import oflibnumpy_amd as of
+    nat, lib = gpu.native, gpu.native.load()
+    h, w = 200, 320
+    rng = np.random.default_rng(5)
+    img = dev.DeviceImage.from_host(rng.random((h, w, 3), dtype=np.float32))
+    tmask = dev.DeviceBuffer.from_host((rng.random((h, w)) > 0.1).astype(np.uint8))
+    affine = of.Flow.from_transforms([['rotation', 120, 80, -15], ['scaling', 100, 60, 0.9]], (h, w), 's')
+    ragged, m = make_field("speckle", h, w)
+    sp = ctypes.c_void_p()
+    nat.check(lib.ofl_stream_create(ctypes.byref(sp)))
+    other = sp.value
+    try:
+        cases = [("t", dev.DeviceFlow.from_host(affine.vecs, 't', m), None),
+                 ("t + target mask", dev.DeviceFlow.from_host(ragged, 't'), tmask),
+                 ("s certified", dev.DeviceFlow.from_host(affine.vecs, 's'), tmask),
+                 ("s slab", dev.DeviceFlow.from_host(ragged, 's', m), None),
+                 ("s zero flow", dev.DeviceFlow.from_host(np.zeros((h, w, 2), np.float32), 's', m), tmask)]
+        for name, d, tm in cases:
+            full, fvalid = d.apply_image(img, target_mask=tm)
+            fo, fv = full.to_host(), fvalid.to_host((h, w), np.uint8)
+            for world in (1, 3):
+                got, gotv = np.zeros_like(fo), np.zeros_like(fv)
+                for rank in range(world):
+                    nb = dev.slab_list_bytes(1 << 17)
+                    played = {}
+
+                    def hook(send_ptr, recv, nbytes, stream, rank=rank, played=played):
+                        from oflibnumpy_amd.sharding import row_band
+                        if not played:                      # the other ranks' step 1, on their "own GPU" (stream = workspace)
+                            for r in range(world):
+                                if r == rank:
+                                    continue
+                                a, b = row_band(h, r, world)
+                                played[r] = dev.DeviceBuffer(nb)
+                                dev.scatter_slab_stars(d.vecs, +1, d._point_mask(True), h, w, a, b - a, played[r].ptr, nb, stream=other)
+                            nat.check(lib.ofl_stream_sync(other))
+                        for r in range(world):
+                            src = send_ptr if r == rank else played[r].ptr
+                            nat.check(lib.ofl_copy_dev(recv.ptr + r * nbytes, src, nbytes, stream))
+
+                    o, v, (r0, r1) = d.apply_image_rows(img, rank, world, target_mask=tm, gather=hook)
+                    got[r0:r1] = o.to_host()
+                    gotv[r0:r1] = v.to_host((r1 - r0, w), np.uint8)
+                    assert (name != "s slab" or world == 1) == (not played), name
+                assert np.array_equal(got.view(np.uint32), fo.view(np.uint32)) and np.array_equal(gotv, fv), (name, world)
+    finally:
+        nat.check(lib.ofl_stream_destroy(other))

@@ -871,20 +871,21 @@ def comm_allgather(send_ptr, recv, nbytes, stream=None):
     nat.check(_lib().ofl_comm_allgather(send_ptr, recv.ptr, nbytes, stream))
 
 
-def scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, list_ptr, list_bytes, point_precision=0, stream=None):
+def scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, list_ptr, list_bytes, point_precision=0, stream=None, ws=None):
     """Step 1 of the slab-wise scatter (include/ofl.h, ofl_scatter_slab_stars_dev): bins, the stars around rows
-    [row0, row0 + rows) and -- at list_ptr (device) -- the unfinished sites of those rows.  The workspace of this
-    (shape, stream) keeps the star state for scatter_slab_finish: no other scatter call of that shape on that stream in
-    between."""
-    ws = _workspace(h, w, 0, stream)
+    [row0, row0 + rows) and -- at list_ptr (device) -- the unfinished sites of those rows.  The workspace keeps the star
+    state for scatter_slab_finish: `ws` (a DeviceBuffer the caller holds on to across both steps, as scatter_slab does) or
+    the cached one of this (shape, stream) -- then no other scatter call of that shape on that stream in between, and
+    nothing that makes the cache drop it (step 2 refuses a workspace without step 1's stamp)."""
+    ws = ws if ws is not None else _workspace(h, w, 0, stream)
     nat.check(_lib().ofl_scatter_slab_stars_dev(flow.ptr, sign, point_precision, pmask.ptr if pmask is not None else None,
                                                 h, w, row0, rows, list_ptr, list_bytes, ws.ptr, ws.nbytes, stream))
 
 
 def scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, list_bytes, n_lists, out_rows, valid_rows,
-                        valid_rule=0, point_precision=0, stream=None):
+                        valid_rule=0, point_precision=0, stream=None, ws=None):
     """Step 2: the gathered lists of all ranks -> unfinished stars, owner map and result of the band."""
-    ws = _workspace(h, w, 0, stream)
+    ws = ws if ws is not None else _workspace(h, w, 0, stream)
     info = (ctypes.c_uint64 * 3)()
     ptr = lambda b: b.ptr if b is not None else None
     nat.check(_lib().ofl_scatter_slab_finish_dev(flow.ptr, sign, point_precision, ptr(vals), C, ptr(vmask), h, w, row0, rows,
@@ -907,10 +908,11 @@ def scatter_slab(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, 
     world = max(int(world), 1)
     nb = slab_list_bytes(entries)
     mine = DeviceBuffer(nb)
-    scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, mine.ptr, nb, point_precision, stream)
+    ws = _workspace(h, w, 0, stream)               # held across both steps: whatever the exchange does to the cache, step 2 finds step 1's state
+    scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, mine.ptr, nb, point_precision, stream, ws)
     if world == 1:
         return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, mine, nb, 1, out_rows, valid_rows,
-                                   valid_rule, point_precision, stream)
+                                   valid_rule, point_precision, stream, ws)
     heads = DeviceBuffer(SLAB_LIST_HEAD * world)
     gather(mine.ptr, heads, SLAB_LIST_HEAD, stream)
     counts = heads.to_host((world, SLAB_LIST_HEAD // 4), np.uint32, stream)[:, 0]
@@ -920,7 +922,7 @@ def scatter_slab(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, 
     lists = DeviceBuffer(nb2 * world)
     gather(mine.ptr, lists, nb2, stream)
     return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, nb2, world, out_rows, valid_rows,
-                               valid_rule, point_precision, stream)
+                               valid_rule, point_precision, stream, ws)
 
 
 def scatter_host(flow, target, pmask, vmask=None):

@@ -900,7 +900,7 @@ struct FarLds {
     double wmax[NT / 64], wfar[NT / 64];
     unsigned run_lo[64];       // candidate runs of the current step (ranges of a sorted list) ...
     int    run_pre[65];        // ... and the exclusive prefix of their lengths
-    int    n, a, ncut, status;
+    int    n, a, ncut, nstart, status;
     // Candidate rejection: a site can only cut a vertex v if it is closer than 2 |v| to the cell's site.  Vertices well
     // outside the data (|v|^2 > t2: the box vertices of an unbounded cell, the circumcentres of sliver triangles along a
     // straight border) would make that radius useless, so they are listed and tested one by one; reach2 covers the rest.
@@ -996,6 +996,28 @@ __device__ __noinline__ void far_refresh(FarLds<CAP, NT> &L)
     __syncthreads();
 }
 
+// Ties on coincident vertices can leave more than one run of cut vertices (ofl_dl::poly_cutmask): the first run that holds a
+// vertex cut beyond the margin is the one that goes -- the first run if none does.  L.cut holds vertex_cut_ex's 0 / 1 / 2,
+// L.a receives the start of the run; all threads, ends with a barrier.  (Not inlined: the workgroup pass sits at 121 VGPRs --
+// four waves per SIMD -- and this rare step must not take a register from its sweeps.)
+template <int CAP, int NT>
+__device__ __noinline__ void far_pick_run(FarLds<CAP, NT> &L)
+{
+    const int t = threadIdx.x, n = L.n;
+    __syncthreads();
+    if (t == 0) L.a = 0x7fffffff;
+    __syncthreads();
+    for (int k = t; k < n; k += NT)
+        if (L.cut[k] && !L.cut[k == 0 ? n - 1 : k - 1]) {
+            bool sure = false;
+            for (int m = k, c = 0; c < n && L.cut[m]; m = m + 1 == n ? 0 : m + 1, ++c) sure = sure || L.cut[m] == 2;
+            atomicMin(&L.a, (sure ? 0 : 1 << 24) | k);
+        }
+    __syncthreads();
+    if (t == 0) L.a &= 0xFFFFFF;
+    __syncthreads();
+}
+
 template <int CAP, int NT, class RelFn>
 __device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, RelFn rel)
 {
@@ -1004,17 +1026,23 @@ __device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, R
     const int t = threadIdx.x, n = L.n;
     const double h = 0.5 * (C.x * C.x + C.y * C.y);
     Poly P{ L.vx, L.vy, L.tag, 1, CAP, n };
-    if (t == 0) { L.a = 0x7fffffff; L.ncut = 0; }
+    if (t == 0) { L.a = 0x7fffffff; L.ncut = 0; L.nstart = 0; }
     __syncthreads();
     int mine = 0;
-    for (int k = t; k < n; k += NT) { const bool c = vertex_cut(P, k, n, C, ctag, ptag, h, rel); L.cut[k] = c ? 1 : 0; mine += c; }
+    bool weak = false;
+    for (int k = t; k < n; k += NT) {
+        const int c = vertex_cut_ex(P, k, n, C, ctag, ptag, h, rel);
+        L.cut[k] = (unsigned char)c; mine += c != 0; weak = weak || c == 1;
+    }
     if (mine) atomicAdd(&L.ncut, mine);
+    if (weak) L.nstart = 1;                            // (any vertex decided by the predicate or a tie rule: look at the runs below)
     __syncthreads();
     const int ncut = L.ncut;
     if (ncut == 0 || ncut == n) return;
     for (int k = t; k < n; k += NT)
         if (L.cut[k] && !L.cut[k == 0 ? n - 1 : k - 1]) atomicMin(&L.a, k);
     __syncthreads();
+    if (L.nstart) far_pick_run(L);                    // (rare: a vertex decided by the predicate or a tie rule)
     const int a = L.a;
     int len = 0;
     while (L.cut[(a + len) % n]) ++len;               // every thread walks the (short) run: uniform result

@@ -85,11 +85,15 @@ DL_HD void edge_line(int tag, RelFn rel, double &nx, double &ny, double &h)
 // breaks them for its square cells: of the two diagonals of the quadrilateral the one through the site with the
 // smallest index exists.  c cutting the vertex makes p - c an edge, so it cuts iff the smallest index is p's or c's;
 // seen from any of the four sites the same diagonal wins, so their stars agree.
+// vertex_cut_ex: 0 = not cut, 2 = cut by the test on the stored vertex (beyond its margin), 1 = cut by the in-circle predicate,
+// the index rule for exact ties or the re-derived vertex -- a decision taken vertex by vertex, so that coincident vertices
+// (four co-circular sites: a zero-length edge) may come out "cut, not cut, cut" around the polygon; poly_cutmask and
+// far_apply keep ONE run of cut vertices and prefer the one that holds a vertex of kind 2.
 template <class PolyX, class RelFn>
-DL_HD bool vertex_cut(const PolyX &P, int k, int n, const P2 &C, int ctag, int ptag, double h, RelFn rel)
+DL_HD int vertex_cut_ex(const PolyX &P, int k, int n, const P2 &C, int ctag, int ptag, double h, RelFn rel)
 {
     const int ta = P.T(k == 0 ? n - 1 : k - 1), tb = P.T(k);
-    if (ctag == ta || ctag == tb) return false;       // the candidate already carries an edge at this vertex
+    if (ctag == ta || ctag == tb) return 0;           // the candidate already carries an edge at this vertex
     if (sizeof(P.X(0)) == 4) {
         // float32 cells (the per-thread passes, which are bound by exactly these instructions): the first look in float32
         // as well -- the stored vertex is only good to 6e-8 anyway, and the margin below covers the rounding of three more
@@ -97,22 +101,22 @@ DL_HD bool vertex_cut(const PolyX &P, int k, int n, const P2 &C, int ctag, int p
         const float cx = (float)C.x, cy = (float)C.y, hf = (float)h;
         const float txf = (float)P.X(k) * cx, tyf = (float)P.Y(k) * cy, df = txf + tyf - hf;
         const float mf = 8e-6f * (fabsf(txf) + fabsf(tyf) + hf);
-        if (df > mf) return true;
-        if (df < -mf) return false;
+        if (df > mf) return 2;
+        if (df < -mf) return 0;
     }
     const double tx = (double)P.X(k) * C.x, ty = (double)P.Y(k) * C.y;
     const double d = tx + ty - h;
     const double m = PolyX::decide * (fabs(tx) + fabs(ty) + h);
-    if (d > m) return true;
-    if (d < -m) return false;
+    if (d > m) return 2;
+    if (d < -m) return 0;
     if (ta >= 0 && tb >= 0 && ta != tb) {
         const P2 A = rel(ta), B = rel(tb);
-        if ((A.x == C.x && A.y == C.y) || (B.x == C.x && B.y == C.y)) return false;     // a duplicate of an edge's site
+        if ((A.x == C.x && A.y == C.y) || (B.x == C.x && B.y == C.y)) return 0;         // a duplicate of an edge's site
         if (A.x * B.y - A.y * B.x != 0.0) {          // (p, a, b collinear: parallel bisectors, the vertex is a box vertex)
             const double ic = incircle_origin(A, B, C);
-            if (ic != 0.0) return ic > 0.0;
+            if (ic != 0.0) return ic > 0.0 ? 1 : 0;
             const int lo_pc = ptag < ctag ? ptag : ctag, lo_ab = ta < tb ? ta : tb;
-            return lo_pc < lo_ab;
+            return lo_pc < lo_ab ? 1 : 0;
         }
     }
     // a vertex on the box (unbounded cell): the stored coordinates (float32 in the per-thread pass, and ~1e9 in size)
@@ -124,10 +128,17 @@ DL_HD bool vertex_cut(const PolyX &P, int k, int n, const P2 &C, int ctag, int p
     const double det = ax * by - bx * ay;
     if (det != 0.0) {
         const double vx = (ah * by - bh * ay) / det, vy = (ax * bh - bx * ah) / det;
-        if (isfinite(vx) && isfinite(vy)) return vx * C.x + vy * C.y - h > 0.0;
+        if (isfinite(vx) && isfinite(vy)) return vx * C.x + vy * C.y - h > 0.0 ? 1 : 0;
     }
-    return d > 0.0;
+    return d > 0.0 ? 1 : 0;
 }
+
+template <class PolyX, class RelFn>
+DL_HD bool vertex_cut(const PolyX &P, int k, int n, const P2 &C, int ctag, int ptag, double h, RelFn rel)
+{
+    return vertex_cut_ex(P, k, n, C, ctag, ptag, h, rel) != 0;
+}
+
 
 // intersection of the edge line of `tag` with the bisector (C, h); falls back to the point of the segment u -> w
 // where the bisector's signed distance changes sign when the two lines are parallel to rounding
@@ -157,11 +168,31 @@ DL_HD unsigned long long poly_cutmask(const PolyX &P, const P2 &C, int ctag, int
 {
     const double h = 0.5 * (C.x * C.x + C.y * C.y);
     const int n = P.n;
-    unsigned long long cut = 0;
-    for (int k = 0; k < n; ++k)
-        if (vertex_cut(P, k, n, C, ctag, ptag, h, rel)) cut |= 1ull << k;
+    unsigned long long cut = 0, sure = 0;
+    for (int k = 0; k < n; ++k) {
+        const int c = vertex_cut_ex(P, k, n, C, ctag, ptag, h, rel);
+        if (c) cut |= 1ull << k;
+        if (c == 2) sure |= 1ull << k;
+    }
     const unsigned long long full = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    return cut == full ? 0ull : cut;
+    if (cut == 0ull || cut == full) return 0ull;
+    if (cut == sure) return cut;                      // no decision by predicate or tie rule: the run is what the plain test says
+    // A convex cell loses ONE run of vertices.  Ties decided vertex by vertex can flag a second one (a coincident pair of
+    // vertices on the bisector, one "cut", one not, next to the run that really goes): keep the first run that holds a
+    // vertex the plain test cut beyond its margin -- the first run if there is none.  (Removing the tie's run instead left
+    // the half-plane unapplied: the site was missing from the star, which then disagreed with its neighbours'.)
+    const unsigned long long prev = ((cut << 1) | (cut >> (n - 1))) & full;         // bit k = cut[k - 1]
+    const unsigned long long starts = cut & ~prev;
+    if ((starts & (starts - 1ull)) == 0ull) return cut;                               // one run
+    unsigned long long first = 0ull, chosen = 0ull;
+    for (int s = 0; s < n && !chosen; ++s) {
+        if (!((starts >> s) & 1ull)) continue;
+        unsigned long long run = 0ull;
+        for (int k = s, m = 0; m < n && ((cut >> k) & 1ull); k = k + 1 == n ? 0 : k + 1, ++m) run |= 1ull << k;
+        if (!first) first = run;
+        if (run & sure) chosen = run;
+    }
+    return chosen ? chosen : first;
 }
 
 // Removes the vertices of a non-empty `cut` mask (poly_cutmask) and closes the polygon with the candidate's edge.

@@ -19,10 +19,15 @@ int poly_clip_any(Poly &P, const P2 &C, int ctag, int ptag, RelFn rel, std::vect
     const int n = P.n;
     cut.assign(n, 0);
     int ncut = 0;
-    for (int k = 0; k < n; ++k) { cut[k] = vertex_cut(P, k, n, C, ctag, ptag, h, rel); ncut += cut[k]; }
+    for (int k = 0; k < n; ++k) { cut[k] = (char)vertex_cut_ex(P, k, n, C, ctag, ptag, h, rel); ncut += cut[k] != 0; }
     if (ncut == 0 || ncut == n) return 0;
-    int a = -1;
-    for (int k = 0; k < n; ++k) if (cut[k] && !cut[k == 0 ? n - 1 : k - 1]) { a = k; break; }
+    int a = -1, first = -1;                           // the first run with a vertex cut beyond the margin, else the first run (as far_apply)
+    for (int k = 0; k < n && a < 0; ++k)
+        if (cut[k] && !cut[k == 0 ? n - 1 : k - 1]) {
+            if (first < 0) first = k;
+            for (int m = k, c = 0; c < n && cut[m]; m = (m + 1) % n, ++c) if (cut[m] == 2) a = k;
+        }
+    if (a < 0) a = first;
     int L = 0;
     while (cut[(a + L) % n]) ++L;
     const int b = (a + L - 1) % n, ia = a == 0 ? n - 1 : a - 1, ib = (b + 1) % n;

@@ -1,0 +1,77 @@
+"""One random case of the scattered -> grid path against SciPy (tools/soak_scatter.py runs them by the thousand; the seeds that
+once failed are replayed by tests/test_gpu_scatter_exact.py::test_soak_regressions)."""
+import numpy as np
+
+
+def make_case(seed, hmax, wmax):
+    """-> h, w, kind, vecs float32 [h][w][2], point mask or None, sign, C, vals, value mask (all from the seed alone)"""
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(4, hmax)), int(rng.integers(4, wmax))
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    kind = int(rng.integers(0, 6))
+    amp = float(rng.uniform(0.1, 6))
+    vecs = np.stack([amp * np.sin(xx / rng.uniform(3, 40) + yy / rng.uniform(5, 50)) + rng.uniform(-0.2, 0.2) * yy,
+                     amp * np.cos(xx / rng.uniform(4, 35) - yy / rng.uniform(6, 45)) + rng.uniform(-0.2, 0.2) * xx], -1).astype(np.float32)
+    vecs += rng.uniform(-6, 6, 2).astype(np.float32)
+    if kind == 1:                                                   # isolated outliers: folds
+        vecs[rng.random((h, w)) < 0.03] += np.float32(rng.uniform(3, 15))
+    elif kind == 2:                                                 # a block moving on its own: tear + fold
+        y0, x0 = int(rng.integers(0, max(h // 2, 1))), int(rng.integers(0, max(w // 2, 1)))
+        vecs[y0:y0 + max(h // 3, 1), x0:x0 + max(w // 3, 1)] += rng.uniform(-10, 10, 2).astype(np.float32)
+    elif kind == 3:                                                 # integer vectors: lattice sites, duplicates, co-circular cells
+        vecs = np.round(vecs)
+    elif kind == 4:                                                 # a similarity: every cell close to co-circular
+        a, sc = rng.uniform(-0.6, 0.6), rng.uniform(0.7, 1.3)
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        vecs = np.stack([(sc * np.cos(a) - 1) * (xx - cx) - sc * np.sin(a) * (yy - cy),
+                         sc * np.sin(a) * (xx - cx) + (sc * np.cos(a) - 1) * (yy - cy)], -1).astype(np.float32)
+    pm = None
+    if rng.random() < 0.6:
+        pm = rng.random((h, w)) > rng.uniform(0, 0.5)
+        if rng.random() < 0.4 and h > 12 and w > 12:
+            pm[h // 4:h // 4 + h // 3, w // 5:w // 5 + w // 2] = False   # a hole
+        if pm.sum() < 8:
+            pm = None
+    sign = 1 if rng.random() < 0.7 else -1
+    C = int(rng.integers(1, 4))
+    vals = rng.random((h, w, C), dtype=np.float32)
+    vm = rng.random((h, w)) > 0.15
+    return h, w, kind, vecs, pm, sign, C, vals, vm
+
+
+def one_case(dev, O, nonunique_nodes, hull_band, seed, hmax, wmax):
+    h, w, kind, vecs, pm, sign, C, vals, vm = make_case(seed, hmax, wmax)
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    f, dv, dm = dev.DeviceBuffer.from_host(vecs), dev.DeviceBuffer.from_host(vals), dev.DeviceBuffer.from_host(vm.astype(np.uint8))
+    dpm = dev.DeviceBuffer.from_host(pm.astype(np.uint8)) if pm is not None else None
+    out, valid = dev.DeviceBuffer(h * w * C * 4), dev.DeviceBuffer(h * w)
+    try:
+        dev.scatter_linear(f, sign, dpm, dv, C, dm, h, w, None, out, valid, 0)
+    except (RuntimeError, ValueError) as e:
+        # a refused point set: SciPy must refuse it as well (QhullError) -- or it is a mismatch
+        try:
+            O.scatter_griddata(sign * vecs, np.concatenate([vals, vm[..., None].astype(np.float32)], -1), pm)
+        except Exception:
+            return 0, 0, None
+        return 0, 1, "refused by the library, accepted by SciPy: " + str(e)[:120]
+    got, gv = out.to_host((h, w, C), np.float32), valid.to_host((h, w), np.uint8).astype(bool)
+    try:
+        want = O.scatter_griddata(sign * vecs, np.concatenate([vals, vm[..., None].astype(np.float32)], -1), pm)
+    except Exception as e:
+        return 0, 1, "accepted by the library, refused by SciPy: " + str(e)[:120]
+    keep = np.ones((h, w), bool) if pm is None else pm
+    pts = np.stack([(xx + sign * vecs[..., 0].astype(np.float64)).ravel(), (yy + sign * vecs[..., 1].astype(np.float64)).ravel()], 1)[keep.ravel()]
+    amb, inside = nonunique_nodes(pts, (h, w))
+    try:
+        band = hull_band(pts, (h, w))
+    except Exception:
+        band = np.zeros((h, w), bool)
+    sel = ~amb & ~band
+    bad_v = (gv != (want[..., -1] == 1)) & sel
+    bad = ~np.isclose(got, want[..., :C], rtol=1e-4, atol=2e-5).all(-1) & sel
+    n_bad = int(bad_v.sum() + bad.sum())
+    msg = None
+    if n_bad:
+        msg = "kind {} {}x{} sign {} mask {}: {} validity, {} value nodes, first {}".format(
+            kind, h, w, sign, pm is not None, int(bad_v.sum()), int(bad.sum()), np.argwhere(bad_v | bad)[:3].tolist())
+    return int(sel.sum()), n_bad, msg

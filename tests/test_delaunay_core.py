@@ -162,3 +162,24 @@ def test_far_pass_handles_unbounded_and_large_cells(core):
     ours = {tuple(sorted(t)) for t in tri.tolist()}
     ref = {tuple(sorted(s)) for s in Delaunay(pts).simplices.tolist()}
     assert ref <= ours and len(ours - ref) == 0
+
+
+def test_tie_on_coincident_vertices_keeps_the_real_run(core):
+    """Soak seed 1000020 (tests/scatter_soak_util.py): a similarity-transformed lattice under a random point mask.  The
+    bisector of a neighbour passes exactly through two coincident vertices of the growing cell (four co-circular sites); the
+    tie rule flags one of them and not the other, and the clip must still remove the run of vertices the half-plane really
+    cuts off -- it used to remove the one-vertex run of the tie, the neighbour was never applied, and the star of site 6936
+    lacked its south-east neighbour 7020 (the triangle SciPy has there: 6936, 6937, 7020)."""
+    from scatter_soak_util import make_case
+    h, w, kind, vecs, pm, sign, C, vals, vm = make_case(1000020, 160, 240)
+    assert (h, w, kind, sign) == (125, 83, 4, 1) and pm is not None
+    yy, xx = np.mgrid[:h, :w]
+    pts_all = np.stack([(xx + vecs[..., 0].astype(np.float64)).ravel(), (yy + vecs[..., 1].astype(np.float64)).ravel()], 1)
+    tri, info = stars_grid(core, pts_all, pm, h, w)
+    star = [tuple(int(v) for v in t[1:]) for t in tri if t[0] == 6936]
+    assert (6937, 7020) in star and (7020, 7102) in star, star
+    idx = np.flatnonzero(pm.ravel())
+    d = Delaunay(pts_all[idx])
+    want = {tuple(sorted(int(idx[v]) for v in t)) for t, u in zip(d.simplices, unique_simplices(pts_all[idx], d.simplices)) if u}
+    got = {tuple(sorted(int(v) for v in t)) for t in tri}
+    assert not (want - got), sorted(want - got)[:5]

@@ -69,6 +69,28 @@ DL_HD double incircle_origin(const P2 &a, const P2 &b, const P2 &c)
     return o > 0.0 ? -det3 : (o < 0.0 ? det3 : 0.0);
 }
 
+// The same question for the clip's near-tie branch, with "on the circle as far as float64 can tell" made explicit: 0 when the
+// determinant is within 4e-15 of the sum of its absolute terms (Shewchuk's static filter for this expression is 1.1e-15).  The
+// four sites of such a question take part in four stars, each asking from its own point of view with coordinates relative to
+// ITS site, and the stars only fit together if all four answer alike.  Sites that are co-circular in exact arithmetic (every
+// cell of a similarity transform whose float32 rounding repeats from row to row) came out as + 3.6e-15 from one site and as
+// - 0.0 from another: one star took the site in, its neighbour's did not, and their triangles overlapped (soak seed 3000265).
+// With the filter every site calls such a set a TIE and vertex_cut_ex's index rule -- which is globally consistent: among
+// co-circular sites the diagonals through the smallest index exist -- decides for all of them.  (Evaluating the determinant
+// once per SET of sites -- indices sorted, coordinates relative to the smallest one, so that everybody gets the same bits --
+// was built as well: four more position loads in a branch that similarity fields and lattices take all the time, + 5 - 9 %
+// on every Delaunay-path case; what it adds over the filter is the set of determinants within rounding of the THRESHOLD.)
+DL_HD double incircle_origin_filtered(const P2 &a, const P2 &b, const P2 &c)
+{
+    const double a2 = a.x * a.x + a.y * a.y, b2 = b.x * b.x + b.y * b.y, c2 = c.x * c.x + c.y * c.y;
+    const double det3 = a.x * (b.y * c2 - b2 * c.y) - a.y * (b.x * c2 - b2 * c.x) + a2 * (b.x * c.y - b.y * c.x);
+    const double perm = fabs(a.x) * (fabs(b.y) * c2 + b2 * fabs(c.y)) + fabs(a.y) * (fabs(b.x) * c2 + b2 * fabs(c.x))
+                      + a2 * (fabs(b.x * c.y) + fabs(b.y * c.x));
+    if (!(fabs(det3) > 4e-15 * perm)) return 0.0;
+    const double o = a.x * b.y - a.y * b.x;
+    return o > 0.0 ? -det3 : (o < 0.0 ? det3 : 0.0);
+}
+
 // line n . v = h carrying the edges of `tag`
 template <class RelFn>
 DL_HD void edge_line(int tag, RelFn rel, double &nx, double &ny, double &h)
@@ -113,7 +135,7 @@ DL_HD int vertex_cut_ex(const PolyX &P, int k, int n, const P2 &C, int ctag, int
         const P2 A = rel(ta), B = rel(tb);
         if ((A.x == C.x && A.y == C.y) || (B.x == C.x && B.y == C.y)) return 0;         // a duplicate of an edge's site
         if (A.x * B.y - A.y * B.x != 0.0) {          // (p, a, b collinear: parallel bisectors, the vertex is a box vertex)
-            const double ic = incircle_origin(A, B, C);
+            const double ic = incircle_origin_filtered(A, B, C);
             if (ic != 0.0) return ic > 0.0 ? 1 : 0;
             const int lo_pc = ptag < ctag ? ptag : ctag, lo_ab = ta < tb ? ta : tb;
             return lo_pc < lo_ab ? 1 : 0;

@@ -61,7 +61,8 @@ def one_case(dev, O, nonunique_nodes, hull_band, seed, hmax, wmax):
         return 0, 1, "accepted by the library, refused by SciPy: " + str(e)[:120]
     keep = np.ones((h, w), bool) if pm is None else pm
     pts = np.stack([(xx + sign * vecs[..., 0].astype(np.float64)).ravel(), (yy + sign * vecs[..., 1].astype(np.float64)).ravel()], 1)[keep.ravel()]
-    amb, inside = nonunique_nodes(pts, (h, w))
+    # (Qhull's own roundoff grows with the coordinates: what counts as "the fourth site lies on the circle" scales with them)
+    amb, inside = nonunique_nodes(pts, (h, w), tol=max(1e-9, 2.5e-11 * float(np.abs(pts).max())))
     try:
         band = hull_band(pts, (h, w))
     except Exception:

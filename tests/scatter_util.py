@@ -9,17 +9,20 @@ def warped_points(vecs, keep=None, sign=1):
     return p if keep is None else p[np.asarray(keep, bool).ravel()]
 
 
-def nonunique_nodes(points, shape, queries=None):
+def nonunique_nodes(points, shape, queries=None, tol=1e-9):
     """Grid nodes whose covering simplex of SciPy's own triangulation is NOT uniquely Delaunay (a fourth site within
-    1e-9 of its circumcircle, or a duplicated site): Qhull's choice among the co-circular alternatives is arbitrary
+    `tol` (relative) of its circumcircle, or a duplicated site): Qhull's choice among the co-circular alternatives is arbitrary
     there, and non-affine data (image values, speckled masks) can tell the alternatives apart.  Everywhere else the
     Delaunay triangulation -- and with it griddata's result -- is unique.  `queries` (N x 2, (x, y), N = H * W): scattered
-    query positions instead of the grid nodes (mode 2 / 't', flow_class.py:1407).  Returns (ambiguous, inside_hull)."""
+    query positions instead of the grid nodes (mode 2 / 't', flow_class.py:1407).  Returns (ambiguous, inside_hull).
+    (Qhull merges facets that are coplanar within ITS roundoff, which grows with the coordinates: on a 248 x 411
+    similarity field it splits a cell whose fourth corner is 1.1e-9 px OUTSIDE the circle along the other diagonal -- and
+    along the right one when x and y are swapped; tools/soak_scatter.py therefore scales `tol` with the field.)"""
     from scipy.spatial import Delaunay
     from test_delaunay_core import unique_simplices
     upts, inv, counts = np.unique(points, axis=0, return_inverse=True, return_counts=True)
     d = Delaunay(upts)
-    uniq = unique_simplices(upts, d.simplices)
+    uniq = unique_simplices(upts, d.simplices, tol)
     dup_vertex = (counts[d.simplices] > 1).any(1)
     yy, xx = np.mgrid[:shape[0], :shape[1]]
     q = np.stack([xx.ravel(), yy.ravel()], 1).astype(np.float64) if queries is None else np.asarray(queries, np.float64)

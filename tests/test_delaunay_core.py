@@ -183,3 +183,26 @@ def test_tie_on_coincident_vertices_keeps_the_real_run(core):
     want = {tuple(sorted(int(idx[v]) for v in t)) for t, u in zip(d.simplices, unique_simplices(pts_all[idx], d.simplices)) if u}
     got = {tuple(sorted(int(v) for v in t)) for t in tri}
     assert not (want - got), sorted(want - got)[:5]
+
+
+def test_exactly_cocircular_sites_are_a_tie_for_every_star(core):
+    """Soak seed 3000265: a similarity field whose float32 rounding leaves FIVE sites exactly co-circular (in the rationals) and
+    a sixth 1e-5 off.  The in-circle determinant of four of them, evaluated relative to the asking site, is + 3.6e-15 from one
+    site and - 0.0 from another; unfiltered, one star inserted the candidate at the wrong end of a run of coincident vertices
+    (its neighbours were no longer in angular order) and the triangles of four stars overlapped on a unique simplex.  With the
+    filter (ofl_dl::incircle_origin_filtered) everybody calls it a tie and the index rule decides."""
+    from scatter_soak_util import make_case
+    h, w, kind, vecs, pm, sign, C, vals, vm = make_case(3000265, 320, 420)
+    assert (h, w, kind, sign) == (317, 166, 4, -1) and pm is not None
+    yy, xx = np.mgrid[:h, :w]
+    pts_all = np.stack([(xx + sign * vecs[..., 0].astype(np.float64)).ravel(), (yy + sign * vecs[..., 1].astype(np.float64)).ravel()], 1)
+    tri, info = stars_grid(core, pts_all, pm, h, w)
+    star = [int(t[1]) for t in tri if t[0] == 20407]
+    ang = np.unwrap(np.arctan2(*(pts_all[star] - pts_all[20407]).T[::-1]))
+    assert (np.diff(ang) > -1e-9).all() or (np.diff(ang) < 1e-9).all(), star       # neighbours in angular order
+    idx = np.flatnonzero(pm.ravel())
+    d = Delaunay(pts_all[idx])
+    want = {tuple(sorted(int(idx[v]) for v in t)) for t, u in zip(d.simplices, unique_simplices(pts_all[idx], d.simplices, 1e-8)) if u}
+    got = {tuple(sorted(int(v) for v in t)) for t in tri}
+    assert (20407, 20410, 20574) in want and not (want - got), sorted(want - got)[:5]
+

@@ -55,6 +55,7 @@ constexpr unsigned kDegLeft  = 0xFFFFFFFFu;   // far_deg marker: not finished by
 constexpr unsigned kFarK     = 4096;     // triangle-id stride of a far point (>= kFarCap)
 constexpr unsigned kNoOwner  = 0xFFFFFFFFu;
 constexpr int      kSmallArea = 1024;
+constexpr int      kLocateRings = 2;     // bucket rings dl_locate_brute searches when the visibility walk got stuck
 constexpr unsigned char kDegFar = 0xFF;
 constexpr unsigned char kDegTodo = 0xFE;  // not settled by the mesh-fan pass: the clip pass builds this star
 constexpr unsigned char kDegFan = 0xFD;   // not settled by the mesh-cell pass: the fan pass looks at this site
@@ -1768,6 +1769,59 @@ __device__ __forceinline__ StarRef star_of(const DlWs &ws, unsigned u)
 
 __device__ __forceinline__ int star_at(const StarRef &s, unsigned k) { return s.small ? (int)s.small[k] : s.far[k]; }
 
+// Last resort of dl_locate: the stars of the sites in the bucket rings around the position, triangle by triangle.  The walk
+// below needs stars that AGREE along its way (the edge it leaves through must be listed by the star it enters); where four
+// sites are co-circular they need not -- on an integer-valued field that is every cell -- and a walk that meets such a pair
+// used to give up: 0.17 % of the positions of mode 2 't' on such fields came back "outside" although SciPy finds them inside
+// (tools/soak_scatter.py --mode query).  Whatever the stars disagree on, their triangles together cover the hull, and none
+// spans an unbounded gap: a position that lies in no triangle of any site within `rings` buckets IS outside (or in a triangle
+// larger than that: rims of holes -- the walk finds those, they are not what it stumbles over).
+__device__ bool dl_locate_brute(const DlWs &ws, const PosFn &pos, double qx, double qy, int rings, TriRef &tr, double &c0, double &c1, double &c2)
+{
+    const Grid g = ws.head->grid;
+    const int bx = g.bx(qx), by = g.by(qy);
+    const D2 q{ qx, qy };
+    for (int r = 0; r <= rings; ++r)
+        for (int row = by - r; row <= by + r; ++row) {
+            if (row < 0 || row >= g.gy) continue;
+            const bool full = row == by - r || row == by + r;
+            for (int part = 0; part < (full ? 1 : 2); ++part) {
+                int x0 = full ? bx - r : (part ? bx + r : bx - r), x1 = full ? bx + r : x0;
+                if (!full && (x0 < 0 || x0 >= g.gx)) continue;
+                x0 = max(x0, 0); x1 = min(x1, g.gx - 1);
+                if (x1 < x0) continue;
+                for (unsigned j = ws.bstart[(size_t)row * g.gx + x0]; j < ws.bstart[(size_t)row * g.gx + x1 + 1]; ++j) {
+                    const unsigned sidx = ws.sorted[j];
+                    if (sidx == 0xFFFFFFFFu) continue;
+                    const StarRef ss = star_of(ws, sidx);
+                    if (ss.d < 2) continue;
+                    const D2 pa = pt(pos, sidx);
+                    int n0 = star_at(ss, ss.d - 1);
+                    D2 p0 = n0 >= 0 ? pt(pos, (unsigned)n0) : D2{ 0.0, 0.0 };
+                    for (unsigned k = 0; k < ss.d; ++k) {
+                        const int n1 = star_at(ss, k);
+                        const D2 p1 = n1 >= 0 ? pt(pos, (unsigned)n1) : D2{ 0.0, 0.0 };
+                        if (n0 >= 0 && n1 >= 0 && n0 != n1) {
+                            const double det = cross2(pa, p0, p1);
+                            if (det != 0.0) {
+                                const double sg = det > 0.0 ? 1.0 : -1.0, tol = kEps * fabs(det);
+                                const double wa = sg * cross2(p0, p1, q), wb = sg * cross2(p1, pa, q), wc = sg * cross2(pa, p0, q);
+                                if (wa >= -tol && wb >= -tol && wc >= -tol) {
+                                    tr.i0 = sidx; tr.i1 = (unsigned)n0; tr.i2 = (unsigned)n1; tr.ok = true;
+                                    canonical3(tr.i0, tr.i1, tr.i2);
+                                    (void)bary(pt(pos, tr.i0), pt(pos, tr.i1), pt(pos, tr.i2), qx, qy, c0, c1, c2);
+                                    return true;
+                                }
+                            }
+                        }
+                        n0 = n1; p0 = p1;
+                    }
+                }
+            }
+        }
+    return false;
+}
+
 // The triangle of the triangulation that contains (qx, qy): a visibility walk from the owner triangle of the grid node
 // next to the position.  Stepping over the edge u -> v of the counter-clockwise triangle (u, v, w) leads to the triangle
 // (u, x, v) with x the neighbour BEFORE v in u's star; a gap there means the position is outside the convex hull.
@@ -1818,7 +1872,7 @@ __device__ bool dl_locate(const DlWs &ws, unsigned far_base, const PosFn &pos, i
         if (!seeded) return false;
     } else {
         tr = dl_decode(id, far_base, ws);
-        if (!tr.ok) return false;
+        if (!tr.ok) return dl_locate_brute(ws, pos, qx, qy, kLocateRings, tr, c0, c1, c2);
     }
     unsigned a = tr.i0, b = tr.i1, c = tr.i2;
     D2 pa = pt(pos, a), pb = pt(pos, b), pc = pt(pos, c);
@@ -1826,7 +1880,7 @@ __device__ bool dl_locate(const DlWs &ws, unsigned far_base, const PosFn &pos, i
     for (int step = 0; step < 16384; ++step) {
         // edge functions of q (positive inside)
         const double det = cross2(pa, pb, pc);
-        if (!(det > 0.0)) return false;
+        if (!(det > 0.0)) return dl_locate_brute(ws, pos, qx, qy, kLocateRings, tr, c0, c1, c2);
         const double wa = cross2(pb, pc, D2{ qx, qy }), wb = cross2(pc, pa, D2{ qx, qy }), wc = cross2(pa, pb, D2{ qx, qy });
         const double tol = kEps * det;
         if (wa >= -tol && wb >= -tol && wc >= -tol) {
@@ -1842,17 +1896,46 @@ __device__ bool dl_locate(const DlWs &ws, unsigned far_base, const PosFn &pos, i
         if (wa <= wb && wa <= wc) { u = b; v = c; pu = pb; pv = pc; }
         else if (wb <= wc)        { u = c; v = a; pu = pc; pv = pa; }
         else                      { u = a; v = b; pu = pa; pv = pb; }
-        const StarRef su = star_of(ws, u);
-        if (su.d == 0) return false;
-        unsigned k = 0;
-        while (k < su.d && star_at(su, k) != (int)v) ++k;
-        if (k == su.d) return false;                                   // stars disagree here (co-circular sites): give up
-        const int x = star_at(su, k == 0 ? su.d - 1 : k - 1);
-        if (x < 0) return false;                                       // an unbounded gap: outside the convex hull
+        // the triangle on the other side of u -> v: the neighbour BEFORE v in u's star -- or, where u's star does not list v
+        // (stars that disagree on a co-circular cell), the neighbour AFTER u in v's star, which is the same site when both do
+        int x = -2;                                         // -2: neither star lists the edge, -1: an unbounded gap
+        {
+            const StarRef su = star_of(ws, u);
+            unsigned k = 0;
+            while (k < su.d && star_at(su, k) != (int)v) ++k;
+            if (k < su.d) x = star_at(su, k == 0 ? su.d - 1 : k - 1);
+        }
+        if (x == -2) {
+            const StarRef sv = star_of(ws, v);
+            unsigned k = 0;
+            while (k < sv.d && star_at(sv, k) != (int)u) ++k;
+            if (k < sv.d) x = star_at(sv, k + 1 == sv.d ? 0 : k + 1);
+        }
+        if (x == -1) return false;                                     // an unbounded gap: outside the convex hull
+        D2 px = x >= 0 ? pt(pos, (unsigned)x) : D2{ 0.0, 0.0 };
+        if (x < 0 || !(cross2(pu, px, pv) > 0.0)) {
+            // Neither star lists the edge, or the order of a star is no guide here (hull stars of lattice fields repeat a
+            // neighbour around a collinear run: a, b, a): choose the apex GEOMETRICALLY -- among the neighbours of u and of v
+            // that lie on the far side of u -> v, the one whose circle through u and v holds none of the others.
+            int best = -1;
+            D2 pbest{ 0.0, 0.0 };
+            for (int side = 0; side < 2; ++side) {
+                const StarRef sn = star_of(ws, side ? v : u);
+                for (unsigned k = 0; k < sn.d; ++k) {
+                    const int n = star_at(sn, k);
+                    if (n < 0 || n == (int)u || n == (int)v || n == best) continue;
+                    const D2 pn = pt(pos, (unsigned)n);
+                    if (!(cross2(pu, pn, pv) > 0.0)) continue;
+                    if (best < 0 || incircle(pu, pbest, pv, pn) > 0.0) { best = n; pbest = pn; }
+                }
+            }
+            if (best < 0) return dl_locate_brute(ws, pos, qx, qy, kLocateRings, tr, c0, c1, c2);
+            x = best; px = pbest;
+        }
         // new triangle (u, x, v), counter-clockwise
-        a = u; pa = pu; b = (unsigned)x; pb = pt(pos, (unsigned)x); c = v; pc = pv;
+        a = u; pa = pu; b = (unsigned)x; pb = px; c = v; pc = pv;
     }
-    return false;
+    return dl_locate_brute(ws, pos, qx, qy, kLocateRings, tr, c0, c1, c2);
 }
 
 template <bool SPARSE>

@@ -76,3 +76,47 @@ def one_case(dev, O, nonunique_nodes, hull_band, seed, hmax, wmax):
         msg = "kind {} {}x{} sign {} mask {}: {} validity, {} value nodes, first {}".format(
             kind, h, w, sign, pm is not None, int(bad_v.sum()), int(bad.sum()), np.argwhere(bad_v | bad)[:3].tolist())
     return int(sel.sum()), n_bad, msg
+
+
+def one_query_case(dev, O, nonunique_nodes, hull_band, seed, hmax, wmax):
+    """combine_with mode 2, ref 't' (flow_class.py:1398-1410): f1 resampled from the float32 points x - f1 onto the positions
+    x - f3 -- scattered QUERY positions, every point kept, the mask a value channel, validity = interpolated mask > 0.99.
+    The product's DeviceFlow._resample_to against the oracle's _mode2_t_resample (SciPy griddata at the same positions)."""
+    h, w, kind, f1, pm, sign, C, vals, vm = make_case(seed, hmax, wmax)
+    rng = np.random.default_rng(seed + 7_000_000_000)
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    amp = float(rng.uniform(0.1, 5))
+    f3 = np.stack([amp * np.cos(xx / rng.uniform(4, 40) + yy / rng.uniform(6, 50)) + rng.uniform(-3, 3),
+                   amp * np.sin(yy / rng.uniform(4, 40) - xx / rng.uniform(6, 50)) + rng.uniform(-3, 3)], -1).astype(np.float32)
+    m1 = vm if pm is None else pm
+    try:
+        got = dev.DeviceFlow.from_host(f1, 't', m1)._resample_to(dev.DeviceFlow.from_host(f3, 't'))
+        gv, gm = got.to_host()
+    except (RuntimeError, ValueError) as e:
+        try:
+            O._mode2_t_resample(O.OFlow(f1, 't', m1), O.OFlow(f3, 't'))
+        except Exception:
+            return 0, 0, None
+        return 0, 1, "refused by the library, accepted by SciPy: " + str(e)[:120]
+    try:
+        want = O._mode2_t_resample(O.OFlow(f1, 't', m1), O.OFlow(f3, 't'))
+    except Exception as e:
+        return 0, 1, "accepted by the library, refused by SciPy: " + str(e)[:120]
+    # the points and the positions as the reference builds them: float32 arrays (flow_class.py:1398-1406)
+    c1 = np.copy(-f1); c1[:, :, 0] += np.arange(w); c1[:, :, 1] += np.arange(h)[:, None]
+    c3 = np.copy(-f3); c3[:, :, 0] += np.arange(w); c3[:, :, 1] += np.arange(h)[:, None]
+    pts, q = c1.reshape(-1, 2).astype(np.float64), c3.reshape(-1, 2).astype(np.float64)
+    amb, inside = nonunique_nodes(pts, (h, w), queries=q, tol=max(1e-9, 2.5e-11 * float(np.abs(pts).max())))
+    try:
+        band = hull_band(pts, (h, w), queries=q)
+    except Exception:
+        band = np.zeros((h, w), bool)
+    sel = ~amb & ~band
+    bad = ~np.isclose(gv, want.vecs, rtol=1e-4, atol=2e-5).all(-1) & sel
+    bad_m = (gm != want.mask) & sel
+    n_bad = int(bad.sum() + bad_m.sum())
+    msg = None
+    if n_bad:
+        msg = "query kind {} {}x{}: {} mask, {} value positions, first {}".format(kind, h, w, int(bad_m.sum()), int(bad.sum()),
+                                                                                   np.argwhere(bad | bad_m)[:3].tolist())
+    return int(sel.sum()), n_bad, msg

@@ -733,3 +733,21 @@ def test_soak_regressions(gpu, oracle):
         total += n
     assert total > 150_000
 
+
+def test_query_soak_regressions(gpu, oracle):
+    """combine_with mode 2 / ref 't' on integer-valued fields (tools/soak_scatter.py --mode query): every cell is co-circular, so
+    stars legitimately disagree on diagonals, and hull stars repeat a neighbour around collinear runs (a, b, a).  The
+    visibility walk of the query path needs the edge it leaves through listed by the star it enters: it used to give up there
+    and returned "outside" for 0.17 % of the positions SciPy finds inside -- up to long hull slivers 0.02 px wide.  Now: the
+    other endpoint's star, then a geometric choice of the apex among both endpoints' neighbours, then the triangles of all
+    sites within two bucket rings (dl_locate, dl_locate_brute): 0 of 5.2 M positions off."""
+    from oflibnumpy_amd import device as dev
+    from scatter_soak_util import one_query_case
+    from scatter_util import nonunique_nodes, hull_band
+    total = 0
+    for seed in (5000011, 5000017, 5000022, 5000030, 5000043, 5000078):
+        n, bad, msg = one_query_case(dev, oracle, nonunique_nodes, hull_band, seed, 160, 240)
+        assert bad == 0, msg
+        total += n
+    assert total > 20_000
+

@@ -25,6 +25,22 @@ def make_case(seed, hmax, wmax):
         cx, cy = rng.uniform(0, w), rng.uniform(0, h)
         vecs = np.stack([(sc * np.cos(a) - 1) * (xx - cx) - sc * np.sin(a) * (yy - cy),
                          sc * np.sin(a) * (xx - cx) + (sc * np.cos(a) - 1) * (yy - cy)], -1).astype(np.float32)
+    elif kind == 5:                                                 # lattices of other makes (the regression seeds are kinds 3 and 4)
+        sub = int(rng.integers(0, 3))
+        if sub == 0:                                                # BASELINE config 5's make: rows that slide against each other
+            px, py = int(rng.integers(3, 24)), int(rng.integers(2, 12))
+            vecs = np.stack([((xx % px) * (yy % py)).astype(np.float32) * np.float32(rng.choice([1.0, 0.5, 0.25])), np.zeros((h, w), np.float32)], -1)
+        elif sub == 1:                                              # a translation: every cell an exact square
+            vecs = np.broadcast_to(rng.uniform(-7, 7, 2).astype(np.float32), (h, w, 2)).copy()
+            if rng.random() < 0.5:
+                y0, x0 = int(rng.integers(0, max(h // 2, 1))), int(rng.integers(0, max(w // 2, 1)))
+                vecs[y0:y0 + max(h // 3, 1), x0:x0 + max(w // 3, 1)] += np.round(rng.uniform(-9, 9, 2)).astype(np.float32)
+        else:                                                       # piecewise constant integer vectors: sheets that fold and tear
+            by, bx = int(rng.integers(3, 20)), int(rng.integers(3, 20))
+            gy, gx = (yy // by).astype(int), (xx // bx).astype(int)
+            tab = np.round(rng.uniform(-6, 6, (gy.max() + 1, gx.max() + 1, 2))).astype(np.float32)
+            vecs = tab[gy, gx]
+        vecs = np.ascontiguousarray(vecs, np.float32)
     pm = None
     if rng.random() < 0.6:
         pm = rng.random((h, w)) > rng.uniform(0, 0.5)

@@ -589,6 +589,9 @@ void dl_big_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bstar
     }
 }
 
+// every how-manieth grid cell dl_fan_decide_kernel looks at (about 4 096 of them)
+__host__ __device__ inline size_t fan_sample_stride(size_t n) { return n / 4096 + 1; }
+
 // ------------------------------------------------------------------------------------------------ stars, mesh-cell pass
 // One thread per grid cell: both triangles of an intact, convex, positively oriented cell are verified ONCE against the
 // sites under their circumcircles (ofl_dl::cell_verify) instead of three times from their three vertices; then one thread
@@ -614,8 +617,9 @@ void dl_cell_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
         const D2 c = point_of(flow, sign, W, x + 1, y + 1), d = point_of(flow, sign, W, x, y + 1);
         // (slab mode: a cell none of whose corners gets a star here is not looked at -- every site that does get one still
         // finds all four of its cells verified, so its star comes out of the same pass as in a whole-field run)
+        // (... except the cells dl_fan_decide_kernel samples: its decision must not depend on the slab)
         const double lo = head->need_lo, hi = head->need_hi;
-        if (fmax(fmax(a.y, b.y), fmax(c.y, d.y)) >= lo && fmin(fmin(a.y, b.y), fmin(c.y, d.y)) <= hi)
+        if ((fmax(fmax(a.y, b.y), fmax(c.y, d.y)) >= lo && fmin(fmin(a.y, b.y), fmin(c.y, d.y)) <= hi) || ia % fan_sample_stride((size_t)H * W) == 0)
         flag = cell_verify((int)ia, W, P2{ a.x, a.y }, P2{ b.x, b.y }, P2{ c.x, c.y }, P2{ d.x, d.y }, head->grid, bstart, sorted, sorted_xy,
                            PosFn(flow, sign, W), kFanSpan);
     }
@@ -651,26 +655,33 @@ void dl_site_cells_kernel(const float *__restrict__ flow, int sign, const uint8_
 
 // Is the mesh worth proposing fans from?  On a strongly sheared field (BASELINE config 5: every source row slides 1 .. 19 px
 // against the next, 42 % of the sites are duplicates) the Delaunay neighbours of a site have nothing to do with its grid
-// neighbours: the cell pass verifies NO cell and the fan pass would spend 0.84 ms at 8K to verify no fan.  4 096 sites are
-// sampled at a fixed stride: when at least 64 of them wait for the fan pass and fewer than 1 in 128 as many were settled by
-// the cells, the fan pass only relabels its list for the clip pass.  A speed decision only -- the clip pass computes the
-// same stars the fans would have verified.
+// neighbours: the cell pass verifies NO cell and the fan pass would spend 0.84 ms at 8K to verify no fan.  Every
+// fan_sample_stride-th grid cell is a SAMPLE (the cell pass verifies those whatever the slab, so that the ranks of a slab-wise
+// call and a whole-field call decide alike -- which pass settles a site shows in the order of its neighbours, hence in triangle
+// ids and ties): when at least 64 samples have four kept corners and fewer than 1 in 128 of those were verified, the fan pass
+// only relabels its list for the clip pass.  A speed decision only -- the clip pass computes the same stars the fans would
+// have verified.
 __global__ __launch_bounds__(1024)
-void dl_fan_decide_kernel(const unsigned char *__restrict__ deg, size_t n, DlHead *head)
+void dl_fan_decide_kernel(const uint8_t *__restrict__ pmask, const unsigned char *__restrict__ dup, const unsigned char *__restrict__ cellflag,
+                          int H, int W, DlHead *head)
 {
-    __shared__ unsigned s_fan, s_ok;
-    if (threadIdx.x == 0) { s_fan = 0; s_ok = 0; }
+    __shared__ unsigned s_all, s_ok;
+    if (threadIdx.x == 0) { s_all = 0; s_ok = 0; }
     __syncthreads();
-    const size_t stride = n / 4096 + 1;
-    unsigned fan = 0, ok = 0;
-    for (int k = 0; k < 4; ++k) {
-        const size_t i = ((size_t)threadIdx.x * 4 + k) * stride;
-        if (i < n) { const unsigned d = deg[i]; fan += d == kDegFan; ok += d >= 1 && d <= kSlots; }
+    const size_t n = (size_t)H * W, stride = fan_sample_stride(n);
+    unsigned all = 0, ok = 0;
+    for (size_t i = (size_t)threadIdx.x * stride; i < n; i += 1024 * stride) {
+        const int y = (int)(i / (unsigned)W), x = (int)(i - (size_t)y * W);
+        if (x >= W - 1 || y >= H - 1) continue;
+        if (!(kept_pt(pmask, i) && kept_pt(pmask, i + 1) && kept_pt(pmask, i + W) && kept_pt(pmask, i + W + 1))) continue;
+        if (dup[i] | dup[i + 1] | dup[i + W] | dup[i + W + 1]) continue;
+        ++all;
+        ok += cellflag[i] != 0;
     }
-    if (fan) atomicAdd(&s_fan, fan);
+    if (all) atomicAdd(&s_all, all);
     if (ok) atomicAdd(&s_ok, ok);
     __syncthreads();
-    if (threadIdx.x == 0) head->skip_fans = (s_fan >= 64 && s_ok * 128 < s_fan) ? 1u : 0u;
+    if (threadIdx.x == 0) head->skip_fans = (s_all >= 64 && s_ok * 128 < s_all) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------ stars, mesh-fan pass
@@ -2173,7 +2184,7 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
         hipLaunchKernelGGL(dl_site_cells_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
                            (const unsigned char *)ws.dup, (const unsigned char *)ws.cellflag, ws.deg, ws.nbr);
     }
-    hipLaunchKernelGGL(dl_fan_decide_kernel, dim3(1), dim3(1024), 0, s, (const unsigned char *)ws.deg, n, ws.head);
+    hipLaunchKernelGGL(dl_fan_decide_kernel, dim3(1), dim3(1024), 0, s, pmask, (const unsigned char *)ws.dup, (const unsigned char *)ws.cellflag, H, W, ws.head);
     hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
     OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
     hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,

@@ -41,6 +41,16 @@ def main():
         except (RuntimeError, ValueError):
             seed += 1
             continue                                                 # (a point set the whole-field call refuses: nothing to compare)
+        # the whole-field call is deterministic, and the replicated-stars bands (ofl_scatter_rows_dev) tile it as well
+        fo2, fv2, _ = sl.full()
+        if not (np.array_equal(fo2.to_host((h, w, 2), np.float32).view(np.uint32), fo.view(np.uint32)) and np.array_equal(fv2.to_host((h, w), np.uint8), fv)):
+            bad += 1; msgs.append("seed {}: kind {} {}x{}: two whole-field calls differ".format(seed, kind, h, w))
+        for r0, r1 in sl.bands(world, align)[:3]:
+            if r1 > r0:
+                bo, bv, _ = sl.full(r0, r1 - r0)
+                if not (np.array_equal(bo.to_host((r1 - r0, w, 2), np.float32).view(np.uint32), fo[r0:r1].view(np.uint32)) and
+                        np.array_equal(bv.to_host((r1 - r0, w), np.uint8), fv[r0:r1])):
+                    bad += 1; msgs.append("seed {}: kind {} {}x{}: replicated band [{}, {}) differs from the whole field".format(seed, kind, h, w, r0, r1))
         out, valid, lists, bands = sl.play(world, align)
         counts, errs = sl.counts(lists, world)
         d = (out.view(np.uint32) != fo.view(np.uint32)).any(-1) | (valid != fv)

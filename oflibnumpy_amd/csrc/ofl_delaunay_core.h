@@ -439,7 +439,7 @@ DL_HD int star_fan(int p, int W, const P2 &pp, unsigned kept8, PosFn pos, SlotPo
     // diagonals: cell 0 (a = p, b = E, c = SE, d = S), cell 1 (a = W, b = p, c = S, d = SW),
     //            cell 2 (a = NW, b = N, c = p, d = W), cell 3 (a = N, b = NE, c = E, d = p)
     auto ac = [](const P2 &A, const P2 &B, const P2 &C, const P2 &D) {
-        return incircle_origin(P2{ B.x - A.x, B.y - A.y }, P2{ D.x - A.x, D.y - A.y }, P2{ C.x - A.x, C.y - A.y }) >= 0.0;
+        return incircle_origin_filtered(P2{ B.x - A.x, B.y - A.y }, P2{ D.x - A.x, D.y - A.y }, P2{ C.x - A.x, C.y - A.y }) >= 0.0;
     };
     bool whole[4];                                               // cell c has all its corners
 #ifdef __HIPCC__
@@ -597,7 +597,7 @@ DL_HD int cell_verify(int ia, int W, const P2 &A, const P2 &B, const P2 &C, cons
 {
     auto cross = [](const P2 &o, const P2 &u, const P2 &v) { return (u.x - o.x) * (v.y - o.y) - (u.y - o.y) * (v.x - o.x); };
     if (!(cross(A, B, C) > 0.0 && cross(A, C, D) > 0.0 && cross(B, C, D) > 0.0 && cross(B, D, A) > 0.0)) return 0;
-    const bool ac = incircle_origin(P2{ B.x - A.x, B.y - A.y }, P2{ D.x - A.x, D.y - A.y }, P2{ C.x - A.x, C.y - A.y }) >= 0.0;
+    const bool ac = incircle_origin_filtered(P2{ B.x - A.x, B.y - A.y }, P2{ D.x - A.x, D.y - A.y }, P2{ C.x - A.x, C.y - A.y }) >= 0.0;
     const P2 O = ac ? A : B;                                      // the vertex both triangles share
     // triangle t = (O, U[t], V[t]), counter-clockwise: (a, b, c), (a, c, d)  or  (b, c, d), (b, d, a)
     const P2 q0 = ac ? B : C, q1 = ac ? C : D, q2 = ac ? D : A;

@@ -35,6 +35,20 @@ __device__ __forceinline__ double incircle(const D2 &a, const D2 &b, const D2 &c
     return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx);
 }
 
+// incircle with "on the circle as far as float64 can tell" made explicit: 0 within 4e-15 of the sum of the absolute terms
+// (Shewchuk's static filter for this expression is 1.1e-15).  Every place that decides a diagonal -- here, the mesh-cell and
+// mesh-fan passes and the clip pass of the Delaunay path (ofl_dl::incircle_origin_filtered) -- evaluates a DIFFERENT
+// expression of the same four sites; for sites that are co-circular in exact arithmetic (similarity transforms, lattices)
+// their results are rounding noise of either sign, and only "all call it a tie, the index rule decides" makes them agree.
+__device__ __forceinline__ double incircle_filtered(const D2 &a, const D2 &b, const D2 &c, const D2 &d)
+{
+    const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    const double a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+    const double det = ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx);
+    const double perm = fabs(ax) * (fabs(by) * c2 + b2 * fabs(cy)) + fabs(ay) * (fabs(bx) * c2 + b2 * fabs(cx)) + a2 * (fabs(bx * cy) + fabs(by * cx));
+    return fabs(det) > 4e-15 * perm ? det : 0.0;
+}
+
 // Which diagonal splits the warped cell a=P(x,y), b=P(x+1,y), c=P(x+1,y+1), d=P(x,y+1):
 // returns 0 for a-c, 1 for b-d.
 __device__ __forceinline__ int pick_diagonal(const D2 &a, const D2 &b, const D2 &c, const D2 &d)
@@ -46,7 +60,7 @@ __device__ __forceinline__ int pick_diagonal(const D2 &a, const D2 &b, const D2 
     if (ac_ok && !bd_ok) return 0;
     if (bd_ok && !ac_ok) return 1;
     if (!ac_ok && !bd_ok) return 0;                 // folded cell: the reference is arbitrary here too
-    double ic = incircle(a, b, c, d);               // convex cell: Delaunay criterion
+    double ic = incircle_filtered(a, b, c, d);      // convex cell: Delaunay criterion (a tie keeps a-c: a is the cell's smallest index)
     if (o_abc < 0) ic = -ic;
     return ic > 0 ? 1 : 0;                          // d inside circle(a, b, c) -> a-c is illegal
 }

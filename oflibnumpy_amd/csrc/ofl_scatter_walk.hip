@@ -218,7 +218,7 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
     // convex, positive cell
     int diag;
     if (BITS) diag = (int)((wc.diag[(size_t)cy * wc.diag_stride + (cx >> 5)] >> (cx & 31)) & 1u);
-    else      diag = incircle(pa, pb, pc, pd) > 0 ? 1 : 0;
+    else      diag = incircle_filtered(pa, pb, pc, pd) > 0 ? 1 : 0;
     // triangle 0 = (a, b, c) or (b, c, d); its vertex-1 coordinate w1 vanishes on the cell's diagonal, so w1 also tells
     // on which side of the diagonal the position lies: the second triangle is only evaluated when it can matter
     int t = 0;

@@ -136,3 +136,66 @@ def one_query_case(dev, O, nonunique_nodes, hull_band, seed, hmax, wmax):
         msg = "query kind {} {}x{}: {} mask, {} value positions, first {}".format(kind, h, w, int(bad_m.sum()), int(bad.sum()),
                                                                                    np.argwhere(bad | bad_m)[:3].tolist())
     return int(sel.sum()), n_bad, msg
+
+
+def one_track_case(of, O, seed, hmax, wmax):
+    """track_pts (utils.py:547-622) through the packaged mirror against the oracle: random points (inside, on and outside the
+    image; float64, float32 and integer), both references, s_exact_mode, int_out.  's' bilinear samples must agree to float
+    rounding (1e-5 px), the Delaunay forms ('t', s_exact_mode) to 1e-4 relative wherever the covering simplex is unique."""
+    from scipy.spatial import Delaunay
+    from test_delaunay_core import unique_simplices
+    h, w, kind, vecs, pm, sign, C, vals, vm = make_case(seed, hmax, wmax)
+    rng = np.random.default_rng(seed + 11_000_000_000)
+    n = int(rng.integers(1, 400))
+    pts = np.stack([rng.uniform(-3, h + 2, n), rng.uniform(-3, w + 2, n)], 1)
+    ref = 's' if rng.random() < 0.5 else 't'
+    exact = bool(rng.random() < 0.5)
+    int_out = bool(rng.random() < 0.3)
+    dt = rng.choice(['f8', 'f4', 'i'])
+    if dt == 'i':
+        pts = np.stack([rng.integers(0, h, n), rng.integers(0, w, n)], 1).astype(np.int64)
+    else:
+        if ref == 's' and not exact:                           # bilinear_interpolation indexes the image: positions must lie inside it
+            pts = np.stack([rng.uniform(0, h - 1, n), rng.uniform(0, w - 1, n)], 1)
+        pts = pts.astype(dt)
+    try:
+        want = O.track_pts(vecs, ref, pts.copy(), int_out, exact)
+    except Exception:
+        return 0, 0, None                                      # (the reference's own arithmetic refuses the case: nothing to compare)
+    try:
+        got = of.track_pts(vecs, ref, pts.copy(), int_out, exact)
+    except Exception as e:
+        return 0, 1, "track {} {} {}x{} exact {}: product raised {}".format(ref, dt, h, w, exact, str(e)[:100])
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    sel = np.ones(n, bool)
+    if (ref == 't' or (exact and dt != 'i')) and not O.is_zero_flow(vecs, True):
+        # the Delaunay forms: exempt positions whose covering simplex is not unique, and those within 1e-5 px of the hull border
+        yy, xx = np.mgrid[:h, :w]
+        src = np.stack([yy.ravel(), xx.ravel()], 1).astype(np.float64)
+        P = src - vecs[..., ::-1].reshape(-1, 2).astype(np.float64) if ref == 't' else src
+        up, counts = np.unique(P, axis=0, return_counts=True)
+        try:
+            d = Delaunay(up)
+        except Exception:
+            return 0, 0, None
+        q = pts.astype(np.float64)
+        s_ = d.find_simplex(q)
+        uniq = unique_simplices(up, d.simplices, max(1e-9, 2.5e-11 * float(np.abs(up).max())))
+        sel = (s_ >= 0)
+        sel[s_ >= 0] = uniq[s_[s_ >= 0]] & ~(counts[d.simplices[s_[s_ >= 0]]] > 1).any(1)
+        from scipy.spatial import ConvexHull
+        hull = ConvexHull(up)
+        dist = (q @ hull.equations[:, :2].T + hull.equations[:, 2]).max(1)
+        sel &= np.abs(dist) > 1e-5
+        sel |= (s_ < 0) & (dist > 1e-5)                        # clearly outside: both must say so (0)
+    tol = 0.51 if int_out else None
+    if int_out:
+        bad = (np.abs(got - want) > 1).any(1) & sel            # (a rounding boundary may fall either way)
+    else:
+        bad = ~np.isclose(got, want, rtol=1e-4, atol=1e-4 if (ref == 's' and not exact) else 2e-4).all(1) & sel
+    msg = None
+    if bad.any():
+        i = int(np.flatnonzero(bad)[0])
+        msg = "track ref {} pts {} exact {} int_out {} {}x{} kind {}: {} of {} points, first {} got {} want {}".format(
+            ref, dt, exact, int_out, h, w, kind, int(bad.sum()), n, pts[i].tolist(), got[i].tolist(), want[i].tolist())
+    return int(sel.sum()), int(bad.sum()), msg

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
-from scatter_soak_util import one_case, one_query_case
+from scatter_soak_util import one_case, one_query_case, one_track_case
 
 
 def main():
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max", type=int, nargs=2, default=[160, 240])
-    ap.add_argument("--mode", default="grid", choices=["grid", "query"], help="grid nodes (apply 's', invert, ...) or scattered query positions (mode 2 't')")
+    ap.add_argument("--mode", default="grid", choices=["grid", "query", "track"], help="grid nodes (apply 's', invert, ...) or scattered query positions (mode 2 't')")
     args = ap.parse_args()
     import oflibnumpy_amd as of
     from oflibnumpy_amd import device as dev
@@ -38,12 +38,15 @@ def main():
     t0, cases, nodes, bad, msgs = time.time(), 0, 0, 0, []
     seed = args.seed * 1_000_000
     while time.time() - t0 < args.seconds:
-        n, b, msg = (one_case if args.mode == "grid" else one_query_case)(dev, O, nonunique_nodes, hull_band, seed, args.max[0], args.max[1])
+        if args.mode == "track":
+            n, b, msg = one_track_case(of, O, seed, args.max[0], args.max[1])
+        else:
+            n, b, msg = (one_case if args.mode == "grid" else one_query_case)(dev, O, nonunique_nodes, hull_band, seed, args.max[0], args.max[1])
         cases += 1; nodes += n; bad += b
         if msg:
             msgs.append("seed {}: {}".format(seed, msg))
         seed += 1
-    print(json.dumps({"soak": "scatter path vs SciPy" + (" (query positions)" if args.mode == "query" else ""), "seed_base": args.seed * 1_000_000, "cases": cases, "nodes_compared": nodes,
+    print(json.dumps({"soak": "scatter path vs SciPy" + (" (query positions)" if args.mode == "query" else " (track_pts)" if args.mode == "track" else ""), "seed_base": args.seed * 1_000_000, "cases": cases, "nodes_compared": nodes,
                       "mismatching_nodes_or_cases": bad, "details": msgs[:20]}))
 
 

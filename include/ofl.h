@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OFL_ABI_VERSION 3
+#define OFL_ABI_VERSION 4
 
 /* status codes */
 enum {

@@ -9,6 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFL_LIB") or os.path.join(_HERE, "libofl_hip.so")   # OFL_LIB: A/B builds only
+ABI_VERSION = 4          # OFL_ABI_VERSION of the include/ofl.h these prototypes were written for
 
 # enums of include/ofl.h
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_NOPOINTS, E_RCCL = 0, -1, -2, -3, -4, -5, -6
@@ -124,6 +125,12 @@ def load():
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(lib, name)      # AttributeError if the ABI lacks a declared symbol
                     fn.restype, fn.argtypes = res, args
+                got = lib.ofl_abi_version()
+                if got != ABI_VERSION:
+                    # a stale build (the .so files are git-ignored and travel with the snapshot; OFL_LIB may point at an old
+                    # experiments build): same symbol names, shifted arguments -- refuse rather than call it
+                    raise ImportError("{} has ABI version {}, these bindings need {}: rebuild it with "
+                                      "`python -m oflibnumpy_amd.build_native --force --experiments`".format(LIB_PATH, got, ABI_VERSION))
                 _lib = lib
     return _lib
 

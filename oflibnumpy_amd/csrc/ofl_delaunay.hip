@@ -28,6 +28,7 @@
 #include "ofl_delaunay_core.h"
 #include <algorithm>
 #include <limits>
+#include <stddef.h>
 #include <stdlib.h>
 #include <vector>
 
@@ -87,6 +88,7 @@ struct DlHead {                           // device header of the exact path (25
     unsigned pad[4];
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
+static_assert(offsetof(DlHead, slab_stamp) == ofl_sc::kSlabStampAt, "ofl_scatter_dev.h: kSlabStampAt");
 
 struct DlWs {
     DlHead   *head;

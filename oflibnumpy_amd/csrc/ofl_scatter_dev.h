@@ -7,6 +7,10 @@
 namespace ofl_sc {
 
 constexpr double   kEps       = 100.0 * 2.220446049250313e-16;   // scipy _qhull: eps = 100 * DBL_EPSILON
+// Byte offset, in the first 256 bytes of a scatter workspace, of the stamp step 1 of the slab-wise scatter leaves for step 2
+// (ofl_delaunay.hip: DlHead::slab_stamp, static_assert there).  The certificate pass writes its own 144-byte record over the
+// front of the same header: it clears the stamp, so that a slab state it has trampled on is refused by step 2.
+constexpr size_t   kSlabStampAt = 184;
 
 struct D2 { double x, y; };
 

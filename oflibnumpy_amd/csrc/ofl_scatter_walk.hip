@@ -470,6 +470,8 @@ int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, in
     for (int k = 0; k < 4; ++k) { init.dev_min[k] = ~0ull; init.dev_max[k] = 0ull; }
     CertDev *dev = (CertDev *)scratch128;
     OFL_HIP(hipMemcpyAsync(dev, &init, sizeof(init), hipMemcpyHostToDevice, s));
+    static_assert(sizeof(CertDev) <= kSlabStampAt, "the certificate record must end before the slab stamp");
+    OFL_HIP(hipMemsetAsync((char *)scratch128 + kSlabStampAt, 0, 4, s));          // (callers give at least 256 bytes) a slab state in this workspace is void now
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);
     hipLaunchKernelGGL(scatter_certify_kernel, grid, block, 0, s, flow, sign_pp, pmask, H, W, dev, diag_bits, (W + 31) / 32);
     cert->diag_bits = diag_bits;

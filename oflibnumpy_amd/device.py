@@ -515,10 +515,10 @@ class DeviceFlow:
         r0, r1 = row_band(h, rank, world, align)
         rows = r1 - r0
         C = image.shape[2]
-        if rows <= 0:
-            return None, None, (r0, r1)
         at = lambda buf, off, n: _BufferView(buf.ptr + off, n)
         if self.ref == 't':
+            if rows <= 0:                       # more ranks than 8-row tiles: nothing to compute, and 't' exchanges nothing
+                return None, None, (r0, r1)
             arith, rule = nat.ARITH_NATIVE, nat.RULE_EQ1
             if image.dtype == np.uint8:
                 arith, rule = (nat.ARITH_NATIVE, nat.RULE_GE_HALF) if target_mask is not None else (nat.ARITH_FLOAT_RNE, nat.RULE_GT_HALF)
@@ -546,14 +546,18 @@ class DeviceFlow:
             vmask = DeviceBuffer(self.n_px)
             _mask_and(target_mask, self.mask, vmask, self.n_px)                  # flow_class.py:643
         if self.is_zero(thresholded=True, masked=False):
+            if rows <= 0:
+                return None, None, (r0, r1)
             nb = rows * w * C * 4
             dst = DeviceImage(DeviceBuffer(nb), (rows, w, C), np.float32)
             nat.check(_lib().ofl_copy_dev(dst.buf.ptr, image.buf.ptr + r0 * w * C * 4, nb, None))
             valid = DeviceBuffer(rows * w)
             nat.check(_lib().ofl_copy_dev(valid.ptr, vmask.ptr + r0 * w, rows * w, None))
             return dst, valid, (r0, r1)
-        out = DeviceImage(DeviceBuffer(rows * w * C * 4), (rows, w, C), np.float32)
-        valid = DeviceBuffer(rows * w)
+        # (a rank with an EMPTY band -- more ranks than 8-row tiles -- still walks through the path decision below: the
+        # slab-wise path has two all-gathers that every rank of `world` must join, scatter_slab with rows == 0)
+        out = DeviceImage(DeviceBuffer(max(rows, 0) * w * C * 4), (max(rows, 0), w, C), np.float32)
+        valid = DeviceBuffer(max(rows, 0) * w)
         pm = self._point_mask(consider_mask)
         cert = self.mesh_cert(+1) if pm is None else None
         if cert is not None and cert.certified and not getattr(cert, "_walk_checked", False):
@@ -568,6 +572,8 @@ class DeviceFlow:
             else:
                 cert.certified = 0
         if cert is not None and cert.certified:
+            if rows <= 0:
+                return None, None, (r0, r1)
             nat.check(_lib().ofl_scatter_certified_dev(self.vecs.ptr, +1, 0, image.buf.ptr, C, vmask.ptr, h, w, r0, rows,
                                                        out.buf.ptr, valid.ptr, 0, ctypes.byref(cert), None, None))
             return out, valid, (r0, r1)
@@ -576,6 +582,8 @@ class DeviceFlow:
         else:
             scatter_slab(self.vecs, +1, pm, image.buf, C, vmask, h, w, r0, rows, out.buf, valid, rank, world,
                          gather=gather if gather is not None else comm_allgather)
+            if rows <= 0:
+                return None, None, (r0, r1)
         return out, valid, (r0, r1)
 
     def resize(self, scale):
@@ -894,35 +902,82 @@ def scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, lis
     return tuple(info)
 
 
+SLAB_ERR_LIST = 32           # error bit of a list head: the rank's unfinished sites did not fit its list (kErrSlabList)
+
+
+def _slab_timeout():
+    import os
+    return float(os.environ.get("OFL_SLAB_TIMEOUT", "120"))
+
+
 def scatter_slab(flow, sign, pmask, vals, C, vmask, h, w, row0, rows, out_rows, valid_rows, rank=0, world=1, valid_rule=0,
-                 point_precision=0, stream=None, entries=1 << 17, gather=comm_allgather):
+                 point_precision=0, stream=None, entries=1 << 17, gather=comm_allgather, timeout=None):
     """One row band of a ref-'s' warp whose mesh does not certify, with the star passes sharded over `world` ranks
     (SURVEY 8e, config 5): step 1 into a list of up to `entries` records, the exchange, step 2.  The exchange is two
     all-gathers -- the 16-byte list heads first, then (one read-back of the counts later) only as many 64-byte records per
     rank as the fullest list holds: config 5 at 8K leaves 75 000 sites unfinished in all, 1 MB per rank instead of the
     8 MiB the buffers are sized for.  `gather(send_ptr, recv_buffer, nbytes, stream)` defaults to RCCL over the live
     communicator (sharding.host_allgather(dist) goes through the host instead: rehearsals with ranks that share a GPU).
-    Bands concatenate to scatter_linear's result bit for bit."""
+    Bands concatenate to scatter_linear's result bit for bit.
+
+    Every rank of `world` MUST call this, whatever its band: a rank with an EMPTY band (rows == 0: more ranks than 8-row
+    tiles) skips both steps but takes part in both gathers with an empty list; a rank whose step 1 fails joins them with an
+    error head and raises afterwards, so that its peers fail with it instead of waiting for it.  When some rank's list
+    overflowed (`entries` too small: large holes, hull sites of an 8K field) every rank sees the same counts in the gathered
+    heads and all of them repeat the exchange ONCE with lists sized for the fullest.  Each gather -- and the read-back that
+    waits for it -- is bounded by `timeout` seconds (default: OFL_SLAB_TIMEOUT, 120): a rank left alone in the collective
+    ends its process with exit code 3 (sharding.bounded_call) instead of hanging for ever."""
     if world <= 1 and (row0 != 0 or rows != h):
         raise ValueError("scatter_slab: a band of a field needs the other ranks' lists")
+    from .sharding import slab_payload_entries, bounded_call
     world = max(int(world), 1)
-    nb = slab_list_bytes(entries)
-    mine = DeviceBuffer(nb)
+    timeout = _slab_timeout() if timeout is None else timeout
     ws = _workspace(h, w, 0, stream)               # held across both steps: whatever the exchange does to the cache, step 2 finds step 1's state
-    scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, mine.ptr, nb, point_precision, stream, ws)
-    if world == 1:
-        return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, mine, nb, 1, out_rows, valid_rows,
+    for attempt in range(2):
+        nb = slab_list_bytes(entries)
+        mine = DeviceBuffer(nb)
+        failed = None
+        if rows > 0:
+            try:
+                scatter_slab_stars(flow, sign, pmask, h, w, row0, rows, mine.ptr, nb, point_precision, stream, ws)
+            except nat.NativeError as e:            # the peers are on their way into the gathers: join them, then raise
+                failed = e
+        if rows <= 0 or failed is not None:
+            head = np.array([0, SLAB_ERR_LIST if failed is not None else 0, 0, 0], np.uint32)
+            nat.check(_lib().ofl_upload(mine.ptr, head.ctypes.data, SLAB_LIST_HEAD, stream))
+            nat.check(_lib().ofl_stream_sync(stream))
+        if world == 1:
+            if failed is not None:
+                raise failed
+            return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, mine, nb, 1, out_rows, valid_rows,
+                                       valid_rule, point_precision, stream, ws)
+        heads = DeviceBuffer(SLAB_LIST_HEAD * world)
+
+        def exchange_heads():
+            gather(mine.ptr, heads, SLAB_LIST_HEAD, stream)
+            return heads.to_host((world, SLAB_LIST_HEAD // 4), np.uint32, stream)
+        hw = bounded_call(exchange_heads, timeout, "the all-gather of the slab list heads")
+        counts, errs = hw[:, 0], hw[:, 1]
+        if attempt == 0 and int(counts.max()) > entries and not errs.any():
+            # some rank's list overflowed; every rank reads the same heads and takes this branch together
+            entries = int(counts.max()) + 1024
+            continue
+        m = slab_payload_entries(counts, entries)
+        nb2 = slab_list_bytes(m)
+        lists = DeviceBuffer(nb2 * world)
+
+        def exchange_lists():
+            gather(mine.ptr, lists, nb2, stream)
+            nat.check(_lib().ofl_stream_sync(stream))
+        bounded_call(exchange_lists, timeout, "the all-gather of the slab lists")
+        if failed is not None:
+            raise failed
+        if rows <= 0:
+            return (0, 0, 0)
+        # (error bits in a peer's head -- a refused point set, a step 1 that failed there -- reach step 2 with the lists: it
+        # blanks this band and raises here as well, include/ofl.h)
+        return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, nb2, world, out_rows, valid_rows,
                                    valid_rule, point_precision, stream, ws)
-    heads = DeviceBuffer(SLAB_LIST_HEAD * world)
-    gather(mine.ptr, heads, SLAB_LIST_HEAD, stream)
-    counts = heads.to_host((world, SLAB_LIST_HEAD // 4), np.uint32, stream)[:, 0]
-    from .sharding import slab_payload_entries
-    m = slab_payload_entries(counts, entries)
-    nb2 = slab_list_bytes(m)
-    lists = DeviceBuffer(nb2 * world)
-    gather(mine.ptr, lists, nb2, stream)
-    return scatter_slab_finish(flow, sign, vals, C, vmask, h, w, row0, rows, lists, nb2, world, out_rows, valid_rows,
-                               valid_rule, point_precision, stream, ws)
 
 
 def scatter_host(flow, target, pmask, vmask=None):

@@ -74,6 +74,40 @@ def host_allgather(dist):
     return gather
 
 
+def bounded_call(fn, timeout, what, exit_code=3):
+    """Run fn() -- a collective, or the synchronisation behind one -- with a bound on the wait.  A rank whose peers never
+    arrive (one of them took another code path, or died) would otherwise sit in the collective for ever; after `timeout`
+    seconds this rank says so on stderr and the PROCESS exits with `exit_code` (os._exit from the waiting thread's parent:
+    neither the communicator nor the process group can be torn down while a rank is inside them; nothing is re-exec'ed).
+    Its peers -- stuck in the same collective -- run into the same bound, so every rank of the job ends non-zero.
+    timeout None or <= 0: no bound.  Returns fn's result; an exception raised by fn is re-raised here."""
+    if timeout is None or timeout <= 0:
+        return fn()
+    import os
+    import sys
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:      # noqa: BLE001 - handed to the caller
+            box["error"] = e
+
+    worker = threading.Thread(target=run, daemon=True)
+    worker.start()
+    worker.join(timeout)
+    if worker.is_alive():
+        sys.stderr.write("rank {}: {} did not complete within {:.0f} s -- a peer never joined it; leaving with exit code {}\n".format(
+            os.environ.get("RANK", "0"), what, timeout, exit_code))
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(exit_code)
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
 def max_over_ranks(dist, values):
     """Element-wise maximum of a list of floats over all ranks (timings are reported as the slowest rank's)."""
     import torch
@@ -89,7 +123,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(script, argv, world, timeout=900.0, env=None, grace=10.0):
+def spawn_ranks(script, argv, world, timeout=None, env=None, grace=10.0):
     """Self-launch: run `script argv` once per rank as FRESH child processes (subprocess, never os.exec*) with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them, relay rank 0's
     stdout to ours and return the worst child exit code.  The caller must not have touched the GPU: the parent stays a
@@ -97,7 +131,9 @@ def spawn_ranks(script, argv, world, timeout=900.0, env=None, grace=10.0):
 
     Every child is polled: the first rank that exits with an error takes the others down after `grace` seconds (a rank
     that died at start-up would otherwise leave its peers in the rendezvous until torch's own timeout, tens of minutes),
-    and `timeout` seconds bound the whole launch (exit code 124, as timeout(1))."""
+    and `timeout` seconds bound the whole launch (exit code 124, as timeout(1)).  timeout=None: the environment variable
+    OFL_SPAWN_TIMEOUT (seconds) if set, else no bound -- soaks and cold builds in the children may legitimately run long;
+    bench.py and tools/bench_bands.py pass their own finite bound."""
     import os
     import subprocess
     import sys
@@ -105,6 +141,8 @@ def spawn_ranks(script, argv, world, timeout=900.0, env=None, grace=10.0):
     import time
     if world < 1:
         raise ValueError("world must be >= 1")
+    if timeout is None and os.environ.get("OFL_SPAWN_TIMEOUT"):
+        timeout = float(os.environ["OFL_SPAWN_TIMEOUT"])
     base = dict(os.environ if env is None else env)
     base.setdefault("MASTER_ADDR", "127.0.0.1")
     base.setdefault("MASTER_PORT", str(free_port()))

@@ -353,3 +353,115 @@ def test_apply_image_rows_equals_apply_image(gpu):
                 assert np.array_equal(got.view(np.uint32), fo.view(np.uint32)) and np.array_equal(gotv, fv), (name, world)
     finally:
         nat.check(lib.ofl_stream_destroy(other))
+
+
+def _play_apply_image_rows(dev, nat, lib, d, img, tm, h, w, world, other, entries=1 << 17, peers_entries=1 << 17):
+    """every rank of `world` through DeviceFlow.apply_image_rows; the peers' step 1 runs inside the gather hook on a second
+    stream (a second workspace).  Returns the assembled image / valid area and the number of hook calls per rank."""
+    from oflibnumpy_amd.sharding import row_band
+    got, gotv, calls = None, None, []
+    for rank in range(world):
+        played, n_calls = {}, [0]
+
+        def hook(send_ptr, recv, nbytes, stream, rank=rank, played=played, n_calls=n_calls):
+            n_calls[0] += 1
+            if not played:
+                nb = dev.slab_list_bytes(peers_entries)
+                for r in range(world):
+                    if r == rank:
+                        continue
+                    a, b = row_band(h, r, world)
+                    played[r] = dev.DeviceBuffer(nb)
+                    if b > a:
+                        dev.scatter_slab_stars(d.vecs, +1, d._point_mask(True), h, w, a, b - a, played[r].ptr, nb, stream=other)
+                    else:                               # a peer with an empty band sends an empty list
+                        nat.check(lib.ofl_memset(played[r].ptr, 0, nb, other))
+                nat.check(lib.ofl_stream_sync(other))
+            for r in range(world):
+                src = send_ptr if r == rank else played[r].ptr
+                nat.check(lib.ofl_copy_dev(recv.ptr + r * nbytes, src, nbytes, stream))
+
+        if entries != 1 << 17:                          # (apply_image_rows has no `entries`: go one level down)
+            r0, r1 = row_band(h, rank, world)
+            o = dev.DeviceImage(dev.DeviceBuffer(max(r1 - r0, 0) * w * 3 * 4), (max(r1 - r0, 0), w, 3), np.float32)
+            v = dev.DeviceBuffer(max(r1 - r0, 0) * w)
+            dev.scatter_slab(d.vecs, +1, d._point_mask(True), img.buf, 3, d.mask, h, w, r0, r1 - r0, o.buf, v, rank, world,
+                             entries=entries, gather=hook)
+        else:
+            o, v, (r0, r1) = d.apply_image_rows(img, rank, world, target_mask=tm, gather=hook)
+        calls.append(n_calls[0])
+        if r1 > r0:
+            if got is None:
+                got, gotv = np.zeros((h, w, 3), np.float32), np.zeros((h, w), np.uint8)
+            got[r0:r1] = o.to_host()
+            gotv[r0:r1] = v.to_host((r1 - r0, w), np.uint8)
+        else:
+            assert o is None or o.shape[0] == 0
+    return got, gotv, calls
+
+
+def test_more_ranks_than_row_tiles(gpu):
+    """H = 40 over 8 ranks: five 8-row tiles, three ranks with EMPTY bands.  On the slab-wise path those ranks must still join
+    both all-gathers (they used to return before the exchange and leave the others waiting in ncclAllGather for ever); on the
+    other paths nothing is exchanged.  Bands of the non-empty ranks == apply_image."""
+    from oflibnumpy_amd import device as dev
+    import oflibnumpy_amd as of
+    nat, lib = gpu.native, gpu.native.load()
+    h, w, world = 40, 96, 8
+    rng = np.random.default_rng(9)
+    img = dev.DeviceImage.from_host(rng.random((h, w, 3), dtype=np.float32))
+    ragged = (0.8 * rng.standard_normal((h, w, 2))).astype(np.float32)
+    m = rng.random((h, w)) > 0.06
+    affine = of.Flow.from_transforms([['rotation', 40, 20, -10]], (h, w), 's')
+    sp = ctypes.c_void_p()
+    nat.check(lib.ofl_stream_create(ctypes.byref(sp)))
+    try:
+        for name, d, want_calls in (("s slab", dev.DeviceFlow.from_host(ragged, 's', m), 2),
+                                    ("s certified", dev.DeviceFlow.from_host(affine.vecs, 's'), 0),
+                                    ("t", dev.DeviceFlow.from_host(ragged, 't', m), 0)):
+            full, fvalid = d.apply_image(img)
+            got, gotv, calls = _play_apply_image_rows(dev, nat, lib, d, img, None, h, w, world, sp.value)
+            assert calls == [want_calls] * world, (name, calls)          # EVERY rank joined both gathers -- or none did
+            assert np.array_equal(got.view(np.uint32), full.to_host().view(np.uint32)), name
+            assert np.array_equal(gotv, fvalid.to_host((h, w), np.uint8)), name
+    finally:
+        nat.check(lib.ofl_stream_destroy(sp.value))
+
+
+def test_scatter_slab_retries_once_when_a_list_overflows(gpu):
+    """`entries` too small for this rank's unfinished sites: the gathered heads tell every rank so, and all of them repeat the
+    exchange with lists sized for the fullest (4 gathers instead of 2) -- same result as the whole-field call"""
+    from oflibnumpy_amd import device as dev
+    nat, lib = gpu.native, gpu.native.load()
+    h, w, world = 256, 384, 2
+    vecs, m = make_field("hole", h, w)
+    d = dev.DeviceFlow.from_host(vecs, 's', m)
+    d.stats()
+    img = dev.DeviceImage.from_host(np.random.default_rng(2).random((h, w, 3), dtype=np.float32))
+    full, fvalid = d.apply_image(img)
+    sp = ctypes.c_void_p()
+    nat.check(lib.ofl_stream_create(ctypes.byref(sp)))
+    try:
+        got, gotv, calls = _play_apply_image_rows(dev, nat, lib, d, img, None, h, w, world, sp.value, entries=64)
+        assert calls == [4, 4], calls
+        assert np.array_equal(got.view(np.uint32), full.to_host().view(np.uint32))
+        assert np.array_equal(gotv, fvalid.to_host((h, w), np.uint8))
+    finally:
+        nat.check(lib.ofl_stream_destroy(sp.value))
+
+
+def test_a_certificate_pass_voids_a_slab_state(gpu):
+    """ofl_scatter_certify_dev writes its record over the front of the workspace header: a slab state left there by step 1 is
+    void afterwards (the stamp is cleared) and step 2 refuses it instead of running on a trampled grid"""
+    from oflibnumpy_amd import device as dev
+    nat, lib = gpu.native, gpu.native.load()
+    h, w = 128, 192
+    vecs, m = make_field("speckle", h, w)
+    sl = Slab(vecs, m, probe_values(h, w))
+    lst = dev.DeviceBuffer(sl.nb)
+    sl.stars(0, h, lst.ptr)
+    cert = nat.MeshCert()
+    nat.check(lib.ofl_scatter_certify_dev(sl.flow.ptr, 1, 0, sl.pm.ptr, h, w, sl.ws.ptr, sl.ws.nbytes, ctypes.byref(cert), None, None))
+    o, v = dev.DeviceBuffer(h * w * 2 * 4), dev.DeviceBuffer(h * w)
+    rc, _ = sl.finish(0, h, lst, 1, o, v, check=False)
+    assert rc == nat.E_INVALID and "does not hold the state" in nat.last_error()

@@ -28,7 +28,7 @@ def test_abi_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libofl_hip.so does not export " + s
     assert set(syms) == set(nat.SIGNATURES), "ctypes table and include/ofl.h disagree"
-    assert nat.load().ofl_abi_version() == 3
+    assert nat.load().ofl_abi_version() == nat.ABI_VERSION == 4
 
 
 def test_shipped_library_is_lean():

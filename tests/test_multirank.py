@@ -162,6 +162,45 @@ def test_self_spawn_does_not_hang_on_a_dead_or_stuck_rank(tmp_path):
         assert "rank0 waits" in p.stdout           # what rank 0 printed before it was stopped is still relayed
 
 
+ALONE = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, {root!r})
+    if "WORLD_SIZE" not in os.environ:
+        from oflibnumpy_amd import sharding
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), [], 2, timeout=120, grace=2))
+    import numpy as np
+    import torch.distributed as dist
+    from oflibnumpy_amd import sharding
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    fd = os.dup(1); os.dup2(2, 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    os.dup2(fd, 1)
+    if rank == 1:
+        time.sleep(60)              # took another code path: never joins the gather of the slab list heads
+        sys.exit(0)
+    sharding.bounded_call(lambda: sharding.allgather_bytes(dist, np.zeros(16, np.uint8)), 3.0, "the all-gather of the slab list heads")
+    print("not reached", flush=True)
+""")
+
+
+def test_a_rank_alone_in_the_slab_exchange_leaves_with_an_error(tmp_path):
+    """device.scatter_slab bounds its two all-gathers with sharding.bounded_call: a rank whose peer never joins does not hang --
+    the process ends with exit code 3 (and takes the job down through the launcher), nothing is re-exec'ed"""
+    import time
+    assert sharding.bounded_call(lambda: 41 + 1, 5.0, "x") == 42 and sharding.bounded_call(lambda: 7, None, "x") == 7
+    with pytest.raises(KeyError):
+        sharding.bounded_call(lambda: {}["missing"], 5.0, "x")
+    script = tmp_path / "stuck.py"
+    script.write_text(ALONE.format(root=ROOT))
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=100,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert p.returncode == 3, (p.returncode, p.stderr[-1500:])
+    assert time.monotonic() - t0 < 45
+    assert "did not complete within 3 s" in p.stderr and "not reached" not in p.stdout
+
+
 def test_bench_launcher_mode_is_reached_before_the_engine_loads():
     """bench.py / tools/bench_bands.py with --gpus N > 1 and no WORLD_SIZE must hand over to spawn_ranks before
     loading the native library / selecting a device (the parent never touches the GPU)."""

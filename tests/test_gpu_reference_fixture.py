@@ -89,7 +89,7 @@ def test_reference_image_gpu_vs_oracle(gpu, oracle, smudge):
             np.testing.assert_array_equal(got, want)
             np.testing.assert_array_equal(gv, wv)
     crop = np.ascontiguousarray(smudge[160:352, 128:384])
-    for tr in ([['rotation', 127.5, 95.5, -30]], [['scaling', 100, 60, 0.9], ['translation', 3.25, -2.5]]):
+    for tr in ([['rotation', 127.5, 95.5, -30]], [['rotation', 100, 60, 17], ['scaling', 100, 60, 0.9]]):
         f = of.Flow.from_transforms(tr, crop.shape[:2], 's')
         o = O.OFlow(f.vecs, 's', f.mask)
         got, gv = f.apply(crop, return_valid_area=True)

@@ -353,10 +353,12 @@ def collect(iters=12, sections=("config2", "config3", "config4", "delaunay", "co
         try:
             gen = fn(iters, bands=False) if name == "config5" else fn(iters)
             for e in gen:
+                # (compact: the driver keeps the TAIL of stdout, and this rides in the one JSON line; the verbose entry -- op,
+                # shape, note -- goes to stderr, and tools/bench_ops.py prints it when run on its own)
                 out[e["key"]] = {"ms": e["device_ms"], "algorithmic_bytes": e["algorithmic_bytes"], "frac": e["frac_of_8TBps"],
-                                 "kernel": e["kernel"], "rotating_sets": e["rotating_sets"], "shape": e["shape"], "note": e["note"]}
+                                 "kernel": e["kernel"].split(" (")[0], "sets": e["rotating_sets"]}
                 if log:
-                    log("{}: {} ms, {} of 8 TB/s".format(e["key"], e["device_ms"], e["frac_of_8TBps"]))
+                    log(json.dumps(e))
         finally:
             dev.empty_cache()
     if skipped:

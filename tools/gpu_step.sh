@@ -1,0 +1,28 @@
+#!/bin/bash
+# one gpurun call of the round: tools/gpu_step.sh <tag> <step> [<step> ...]   (steps are joined with &&: a failed or killed step ends the call)
+#   tests            the whole -m gpu suite                     -> gpurun_out/<tag>_tests.log
+#   tests:<expr>     pytest -k <expr>
+#   bench            python bench.py --steps 20 --warmup 5      -> gpurun_out/<tag>_bench.json (+ .err)
+#   bench2           the same with --gpus 2 on the one GPU (rehearsal of the N > 1 path; ranks share the card)
+#   cases[:ops]      per-kernel breakdown of the Delaunay-path cases (tools/prof_cases.sh)
+#   ops[:only]       tools/bench_ops.py [--only ...]            -> gpurun_out/<tag>_ops.jsonl
+set -o pipefail
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
+cd $ROOT
+for STEP in "$@"; do
+  echo "== step $STEP ($(date +%T))"
+  case $STEP in
+    tests)   timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.log 2>&1 || { tail -40 gpurun_out/${TAG}_tests.log; exit 1; }; tail -3 gpurun_out/${TAG}_tests.log ;;
+    tests:*) timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "${STEP#tests:}" > gpurun_out/${TAG}_tests.log 2>&1 || { tail -40 gpurun_out/${TAG}_tests.log; exit 1; }; tail -3 gpurun_out/${TAG}_tests.log ;;
+    bench)   timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { tail -20 gpurun_out/${TAG}_bench.err; exit 1; }; wc -c gpurun_out/${TAG}_bench.json; cut -c1-600 gpurun_out/${TAG}_bench.json ;;
+    bench2)  timeout -k 10 600 python bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench2.json 2> gpurun_out/${TAG}_bench2.err || { tail -20 gpurun_out/${TAG}_bench2.err; exit 1; }; cut -c1-300 gpurun_out/${TAG}_bench2.json; grep -o '"strong".*' gpurun_out/${TAG}_bench2.json | cut -c1-900 ;;
+    cases)   bash tools/prof_cases.sh $TAG object stripes speckle wobble hole config5 || exit 1 ;;
+    cases:*) bash tools/prof_cases.sh $TAG $(echo "${STEP#cases:}" | tr ',' ' ') || exit 1 ;;
+    ops)     timeout -k 10 600 python tools/bench_ops.py > gpurun_out/${TAG}_ops.jsonl 2> gpurun_out/${TAG}_ops.err || { tail -20 gpurun_out/${TAG}_ops.err; exit 1; }; cut -c1-200 gpurun_out/${TAG}_ops.jsonl ;;
+    ops:*)   timeout -k 10 600 python tools/bench_ops.py --only "${STEP#ops:}" > gpurun_out/${TAG}_ops.jsonl 2> gpurun_out/${TAG}_ops.err || { tail -20 gpurun_out/${TAG}_ops.err; exit 1; }; cut -c1-200 gpurun_out/${TAG}_ops.jsonl ;;
+    *) echo "unknown step $STEP"; exit 2 ;;
+  esac || exit 1
+done
+echo "== done ($(date +%T))"

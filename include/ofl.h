@@ -159,6 +159,18 @@ int ofl_gather_bilinear_dev(const void *src, int dtype, int C, int H, int W,
                             const uint8_t *smask, const uint8_t *fmask,
                             void *dst, uint8_t *valid,
                             int quant, int arith, int rule, void *stream);
+/* K1 over a BATCH of fields in one launch (Flow.apply for a stack of independent warps: BASELINE config 2-sized jobs are one
+ * generation of waves per launch when launched alone, utils.py:231-236 / flow_class.py:632-695 per field).  Field b of the
+ * batch reads flow [b][fH][fW][2], fmask [b][fH][fW] (or NULL), writes dst [b][H][W][C] and valid [b][H][W] (or NULL);
+ * src is [b][H][W][C] -- or ONE image [H][W][C] warped by every flow when src_shared != 0 -- and smask likewise
+ * ([b][H][W], one shared [H][W] when smask_shared != 0, or NULL).  Everything else as ofl_gather_bilinear_dev, whose results
+ * the fields equal bit for bit.  batch in [1, 65535].
+ */
+int ofl_gather_bilinear_batch_dev(const void *src, int src_shared, int dtype, int C, int H, int W, int batch,
+                                  const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
+                                  const uint8_t *smask, int smask_shared, const uint8_t *fmask,
+                                  void *dst, uint8_t *valid, int quant, int arith, int rule, void *stream);
+
 /* One row band of the same result, for a field split over several GPUs: the source
  * image (and smask) are replicated, each rank holds rows [row0, row0 + rows) of the flow / its mask and
  * produces the same rows of dst / valid:

@@ -77,6 +77,8 @@ SIGNATURES = {
                                       _ci, _ci, _ci, _vp]),
     "ofl_gather_bilinear": (_ci, [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp,
                                   _ci, _ci, _ci]),
+    "ofl_gather_bilinear_batch_dev": (_ci, [_vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp,
+                                            _vp, _vp, _ci, _ci, _ci, _vp]),
     "ofl_flow_stats_dev": (_ci, [_vp, _vp, _cs, _cf, _vp, _vp]),
     "ofl_flow_stats": (_ci, [_vp, _vp, _cs, _cf, _vp]),
     "ofl_axpy_dev": (_ci, [_vp, _vp, _vp, _vp, _cf, _cs, _vp, _vp, _vp]),

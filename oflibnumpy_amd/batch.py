@@ -57,6 +57,29 @@ class DeviceFlowBatch:
         return out, words.to_host((self.n, 8), np.uint32), (fa, fb)
 
 
+    def apply_images(self, images, dtype, channels, shared=False, target_masks=None, shared_masks=False, quant=nat.QUANT_OPENCV):
+        """self[i].apply(image_i, target_mask_i, return_valid_area=True) for every i in ONE launch of the gather kernel
+        (ref 't' batches; Flow.apply, flow_class.py:604-695 without padding).  `images`: a DeviceBuffer holding [n][H][W][C] of
+        `dtype` back to back -- or ONE [H][W][C] image warped by every field when `shared`; `target_masks` uint8 [n][H][W] (one
+        [H][W] when `shared_masks`) or None.  Returns (warped [n][H][W][C] DeviceBuffer, valid [n][H][W] DeviceBuffer), field
+        for field what DeviceFlow.apply_image gives (the dtype rules of the reference's concatenated array, device.apply_image).
+        A field whose vectors are all below the 1e-3 threshold is warped like any other: under cv2's 1/32-px coordinate
+        snapping that IS the identity of utils.py:215-216."""
+        if self.ref != 't':
+            raise ValueError("apply_images batches the gather ('t') warp; 's' fields go through DeviceFlow.apply_image one by one")
+        dtype = np.dtype(dtype)
+        h, w = self.shape
+        arith, rule = nat.ARITH_NATIVE, nat.RULE_EQ1
+        if dtype == np.uint8:      # concat dtype of the reference: bool mask -> uint8, default int8 -> int16
+            arith, rule = (nat.ARITH_NATIVE, nat.RULE_GE_HALF) if target_masks is not None else (nat.ARITH_FLOAT_RNE, nat.RULE_GT_HALF)
+        elif dtype == np.int16 or (dtype == np.uint16 and target_masks is not None):
+            rule = nat.RULE_GT_HALF
+        elif dtype == np.uint16:
+            raise TypeError("uint16 image with the default int8 mask needs an int32 remap, which cv2.remap does not provide")
+        return dev.gather_bilinear_batch(images, dtype, channels, h, w, self.n, self.vecs, -1, smask=target_masks, fmask=self.mask,
+                                         valid=True, shared_src=shared, shared_smask=shared_masks, quant=quant, arith=arith, rule=rule)
+
+
 def combine_flows_batch(flows_1, flows_2, ref=None, rank=0, world=1, thresholded=False):
     """Mode-3 composition of many independent pairs.  `flows_1[i] (+) flows_2[i]`; inputs are lists of
     `Flow` objects or of (H, W, 2) arrays with reference `ref`.  With world > 1 only the contiguous block of

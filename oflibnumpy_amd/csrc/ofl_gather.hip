@@ -882,14 +882,25 @@ template <> __device__ __forceinline__ int16_t  finish<int16_t>(float s, int) { 
 template <> __device__ __forceinline__ uint16_t finish<uint16_t>(float s, int) { return (uint16_t)min(max(cv_round(s), 0), 65535); }
 template <> __device__ __forceinline__ uint8_t  finish<uint8_t>(float s, int) { return (uint8_t)sat_s16(cv_round(s)); }
 
+// Batched launches of K1 (ofl_gather_bilinear_batch_dev): blockIdx.y = the field of the batch; element strides from one field's
+// arrays to the next (0: the array is shared by the whole batch -- one source image warped by B flows; or absent).
+struct GBatch { size_t src, smask, flow, fmask, dst, valid; };
+
 template <typename T, int CT>
 __global__ __launch_bounds__(256)
-void gather_kernel(const T *__restrict__ src, int Crt, int H, int W,
-                   const float *__restrict__ flow, int fH, int fW, int pad_top, int pad_left, int sign,
-                   const uint8_t *__restrict__ smask, const uint8_t *__restrict__ fmask,
-                   T *__restrict__ dst, uint8_t *__restrict__ valid,
-                   int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows)
+void gather_kernel(const T *__restrict__ src0, int Crt, int H, int W,
+                   const float *__restrict__ flow0, int fH, int fW, int pad_top, int pad_left, int sign,
+                   const uint8_t *__restrict__ smask0, const uint8_t *__restrict__ fmask0,
+                   T *__restrict__ dst0, uint8_t *__restrict__ valid0,
+                   int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows, GBatch bs)
 {
+    const size_t bi = blockIdx.y;
+    const T *__restrict__ src = src0 + bi * bs.src;
+    const float *__restrict__ flow = flow0 + bi * bs.flow;
+    const uint8_t *__restrict__ smask = smask0 ? smask0 + bi * bs.smask : nullptr;
+    const uint8_t *__restrict__ fmask = fmask0 ? fmask0 + bi * bs.fmask : nullptr;
+    T *__restrict__ dst = dst0 + bi * bs.dst;
+    uint8_t *__restrict__ valid = valid0 ? valid0 + bi * bs.valid : nullptr;
     const int C    = CT > 0 ? CT : Crt;
     const int tile = xcd_swizzle(blockIdx.x, nblocks);
     const int ty   = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -1170,12 +1181,20 @@ __device__ __forceinline__ void gather2_core(const T *__restrict__ src, const ui
 #endif
 template <typename T, int CT>
 __global__ __launch_bounds__(256)
-void gather2_kernel(const T *__restrict__ src, int H, int W,
-                    const float *__restrict__ flow, int fH, int fW, int pad_top, int pad_left, int sign,
-                    const uint8_t *__restrict__ smask, const uint8_t *__restrict__ fmask,
-                    T *__restrict__ dst, uint8_t *__restrict__ valid,
-                    int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows, int xpose_rows)
+void gather2_kernel(const T *__restrict__ src0, int H, int W,
+                    const float *__restrict__ flow0, int fH, int fW, int pad_top, int pad_left, int sign,
+                    const uint8_t *__restrict__ smask0, const uint8_t *__restrict__ fmask0,
+                    T *__restrict__ dst0, uint8_t *__restrict__ valid0,
+                    int quant, int arith, int rule, int tiles_x, int nblocks, int row0, int rows, int xpose_rows, GBatch bs)
 {
+    // (batched launches: one field per blockIdx.y; the offsets below stay 32-bit relative to the FIELD's base pointers)
+    const size_t bi = blockIdx.y;
+    const T *__restrict__ src = src0 + bi * bs.src;
+    const float *__restrict__ flow = flow0 + bi * bs.flow;
+    const uint8_t *__restrict__ smask = smask0 ? smask0 + bi * bs.smask : nullptr;
+    const uint8_t *__restrict__ fmask = fmask0 ? fmask0 + bi * bs.fmask : nullptr;
+    T *__restrict__ dst = dst0 + bi * bs.dst;
+    uint8_t *__restrict__ valid = valid0 ? valid0 + bi * bs.valid : nullptr;
     const int tile = nblocks > 0 ? xcd_swizzle(blockIdx.x, nblocks) : (int)blockIdx.x;     // nblocks <= 0: natural order
     const int ty   = tile / tiles_x, tx = tile - ty * tiles_x;
     const int lx   = threadIdx.x & 31, yl = ty * 8 + (threadIdx.x >> 5), y = row0 + yl;     // output band [row0, row0 + rows)
@@ -1362,8 +1381,12 @@ void gather2_kernel(const T *__restrict__ src, int H, int W,
 template <typename T>
 int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int fH, int fW, int pad_top,
                     int pad_left, int sign, const uint8_t *smask, const uint8_t *fmask, void *dst,
-                    uint8_t *valid, int quant, int arith, int rule, int row0, int rows, hipStream_t s)
+                    uint8_t *valid, int quant, int arith, int rule, int row0, int rows, hipStream_t s,
+                    int batch = 1, bool shared_src = false, bool shared_smask = false)
 {
+    GBatch bs;
+    bs.src = shared_src ? 0 : (size_t)H * W * C; bs.smask = shared_smask ? 0 : (size_t)H * W;
+    bs.flow = (size_t)fH * fW * 2; bs.fmask = (size_t)fH * fW; bs.dst = (size_t)rows * W * C; bs.valid = (size_t)rows * W;
     // (the paired kernel addresses with 32-bit offsets: images, flows and results below 4 GiB)
     if (W % 2 == 0 && C >= 1 && C <= 4 && (unsigned long long)H * W * C * sizeof(T) < (1ull << 32) && (unsigned long long)fH * fW * 8 < (1ull << 32)) {
         const int tiles_x = (W + 127) / 128, tiles_y = (rows + 7) / 8;
@@ -1371,9 +1394,9 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
         static const int swz = OFL_KNOB_INT("OFL_G2_SWZ", 0);                      // 1 = XCD swizzle (experiments build only)
         static const int xpose_rows = OFL_KNOB_INT("OFL_G2_XPOSE_ROWS", kXposeRows);   // (experiments build only)
 #define OFL_GATHER2_LAUNCH(CT)                                                                           \
-        hipLaunchKernelGGL((gather2_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, H, W, \
+        hipLaunchKernelGGL((gather2_kernel<T, CT>), dim3(nblocks, batch), dim3(256), 0, s, (const T *)src, H, W, \
                            flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,   \
-                           arith, rule, tiles_x, swz ? nblocks : 0, row0, rows, xpose_rows)
+                           arith, rule, tiles_x, swz ? nblocks : 0, row0, rows, xpose_rows, bs)
         switch (C) {
         case 1: OFL_GATHER2_LAUNCH(1); break;
         case 2: OFL_GATHER2_LAUNCH(2); break;
@@ -1387,9 +1410,9 @@ int launch_gather_t(const void *src, int C, int H, int W, const float *flow, int
     const int tiles_x = (W + 31) / 32, tiles_y = (rows + 7) / 8;
     const int nblocks = tiles_x * tiles_y;
 #define OFL_GATHER_LAUNCH(CT)                                                                          \
-    hipLaunchKernelGGL((gather_kernel<T, CT>), dim3(nblocks), dim3(256), 0, s, (const T *)src, C, H, W, \
+    hipLaunchKernelGGL((gather_kernel<T, CT>), dim3(nblocks, batch), dim3(256), 0, s, (const T *)src, C, H, W, \
                        flow, fH, fW, pad_top, pad_left, sign, smask, fmask, (T *)dst, valid, quant,     \
-                       arith, rule, tiles_x, nblocks, row0, rows)
+                       arith, rule, tiles_x, nblocks, row0, rows, bs)
     switch (C) {
     case 1: OFL_GATHER_LAUNCH(1); break;
     case 2: OFL_GATHER_LAUNCH(2); break;
@@ -1579,7 +1602,8 @@ static int gather_rows_impl(const void *src, int dtype, int C, int H, int W,
                             const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
                             const uint8_t *smask, const uint8_t *fmask,
                             void *dst, uint8_t *valid,
-                            int quant, int arith, int rule, int row0, int rows, void *stream)
+                            int quant, int arith, int rule, int row0, int rows, void *stream,
+                            int batch = 1, bool shared_src = false, bool shared_smask = false)
 {
     OFL_TRY(need_device());
     OFL_TRY(check_dims("ofl_gather_bilinear", H, W));
@@ -1603,11 +1627,11 @@ static int gather_rows_impl(const void *src, int dtype, int C, int H, int W,
         return fail(OFL_E_INVALID, "ofl_gather_bilinear: rows [%d, %d) outside the %d-row result", row0, row0 + rows, H);
     hipStream_t s = stream_of(stream);
     switch (dtype) {
-    case OFL_U8:  return launch_gather_t<uint8_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
-    case OFL_I16: return launch_gather_t<int16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
-    case OFL_U16: return launch_gather_t<uint16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
-    case OFL_F32: return launch_gather_t<float>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
-    default:      return launch_gather_t<double>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s);
+    case OFL_U8:  return launch_gather_t<uint8_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s, batch, shared_src, shared_smask);
+    case OFL_I16: return launch_gather_t<int16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s, batch, shared_src, shared_smask);
+    case OFL_U16: return launch_gather_t<uint16_t>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s, batch, shared_src, shared_smask);
+    case OFL_F32: return launch_gather_t<float>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s, batch, shared_src, shared_smask);
+    default:      return launch_gather_t<double>(src, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid, quant, arith, rule, row0, rows, s, batch, shared_src, shared_smask);
     }
 }
 
@@ -1619,6 +1643,16 @@ int ofl_gather_bilinear_dev(const void *src, int dtype, int C, int H, int W,
 {
     return gather_rows_impl(src, dtype, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid,
                             quant, arith, rule, 0, H, stream);
+}
+
+int ofl_gather_bilinear_batch_dev(const void *src, int src_shared, int dtype, int C, int H, int W, int batch,
+                                  const float *flow, int fH, int fW, int pad_top, int pad_left, int sign,
+                                  const uint8_t *smask, int smask_shared, const uint8_t *fmask,
+                                  void *dst, uint8_t *valid, int quant, int arith, int rule, void *stream)
+{
+    if (batch < 1 || batch > 65535) return fail(OFL_E_INVALID, "ofl_gather_bilinear_batch: batch must be in [1, 65535]");
+    return gather_rows_impl(src, dtype, C, H, W, flow, fH, fW, pad_top, pad_left, sign, smask, fmask, dst, valid,
+                            quant, arith, rule, 0, H, stream, batch, src_shared != 0, smask_shared != 0);
 }
 
 int ofl_gather_rows_dev(const void *src, int dtype, int C, int H, int W, int row0, int rows,

@@ -273,6 +273,27 @@ def gather_bilinear(src, flow_buf, flow_shape, sign, smask=None, fmask=None, wan
     return dst, valid
 
 
+def gather_bilinear_batch(src, dtype, C, H, W, batch, flow, sign, smask=None, fmask=None, dst=None, valid=None,
+                          shared_src=False, shared_smask=False, flow_shape=None, pad=(0, 0),
+                          quant=nat.QUANT_OPENCV, arith=nat.ARITH_NATIVE, rule=nat.RULE_EQ1, stream=None):
+    """K1 over `batch` fields in ONE launch (ofl_gather_bilinear_batch_dev): buffers hold the fields back to back -- flow
+    [B][fH][fW][2], fmask [B][fH][fW], src [B][H][W][C] (or one [H][W][C] image for all with shared_src), smask likewise,
+    dst [B][H][W][C], valid [B][H][W].  dst / valid are allocated when not given (valid only if `valid is True`).
+    Returns (dst buffer, valid buffer or None)."""
+    dtype = np.dtype(dtype)
+    fH, fW = flow_shape if flow_shape is not None else (H, W)
+    if dst is None:
+        dst = DeviceBuffer(batch * H * W * C * dtype.itemsize)
+    if valid is True:
+        valid = DeviceBuffer(batch * H * W)
+    nat.check(_lib().ofl_gather_bilinear_batch_dev(
+        src.ptr if src is not None else None, 1 if shared_src else 0, _DT_CODE[dtype], C, H, W, batch, flow.ptr, fH, fW,
+        pad[0], pad[1], sign, smask.ptr if smask is not None else None, 1 if shared_smask else 0,
+        fmask.ptr if fmask is not None else None, dst.ptr if C else None, valid.ptr if valid is not None else None,
+        quant, arith, rule, stream))
+    return dst, valid
+
+
 def gather_rows(src, row0, rows, flow_rows, sign, smask=None, fmask_rows=None, want_valid=False,
                 quant=nat.QUANT_OPENCV, arith=nat.ARITH_NATIVE, rule=nat.RULE_EQ1, stream=None):
     """K1 on one row band of a field split over several GPUs: `src` is the replicated

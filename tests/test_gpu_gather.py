@@ -751,3 +751,57 @@ def test_sintel_flo_roundtrip_through_pinned_buffers(gpu, tmp_path):
     assert open(str(tmp_path / "host.flo"), 'rb').read() == open(path, 'rb').read()
     with pytest.raises(ValueError):
         dev.load_sintel_device(os.path.join(os.path.dirname(__file__), "golden", "sintel_wrong.flo"))
+
+
+def test_gather_batch_equals_field_by_field(gpu):
+    """ofl_gather_bilinear_batch_dev: B fields in one launch == B launches of ofl_gather_bilinear_dev, bit for bit -- own and
+    shared source image / target mask, three dtypes, odd and even widths (paired and one-pixel kernels), validity-only
+    launches (C = 0), and DeviceFlowBatch.apply_images == DeviceFlow.apply_image field by field"""
+    from oflibnumpy_amd import device as dev
+    from oflibnumpy_amd.batch import DeviceFlowBatch
+    of, nat = gpu, gpu.native
+    rng = np.random.default_rng(77)
+    B = 5
+    for h, w in ((72, 200), (41, 67)):
+        n = h * w
+        flows = [(rng.standard_normal((h, w, 2)) * (0.5 + 3 * i)).astype(np.float32) + np.float32(1.5 * i) for i in range(B)]
+        fmasks = [(rng.random((h, w)) > 0.1).astype(np.uint8) for _ in range(B)]
+        smasks = [(rng.random((h, w)) > 0.1).astype(np.uint8) for _ in range(B)]
+        fb = dev.DeviceBuffer.from_host(np.stack(flows))
+        mb = dev.DeviceBuffer.from_host(np.stack(fmasks))
+        sb = dev.DeviceBuffer.from_host(np.stack(smasks))
+        for dt, C, kw in ((np.float32, 3, {}), (np.uint8, 3, dict(arith=nat.ARITH_NATIVE, rule=nat.RULE_GE_HALF)),
+                          (np.uint16, 1, dict(rule=nat.RULE_GT_HALF)), (np.float32, 2, {})):
+            imgs = [(rng.random((h, w, C)) * (255 if dt != np.float32 else 1)).astype(dt) for _ in range(B)]
+            ib = dev.DeviceBuffer.from_host(np.stack(imgs))
+            for shared in (False, True):
+                dst, valid = dev.gather_bilinear_batch(ib, dt, C, h, w, B, fb, -1, smask=sb, fmask=mb, valid=True,
+                                                       shared_src=shared, shared_smask=shared, **kw)
+                got = dst.to_host((B, h, w, C), dt)
+                gotv = valid.to_host((B, h, w), np.uint8)
+                for i in range(B):
+                    j = 0 if shared else i
+                    d1, v1 = dev.gather_bilinear(dev.DeviceImage.from_host(imgs[j]), dev.DeviceBuffer.from_host(flows[i]), (h, w), -1,
+                                                 smask=dev.DeviceBuffer.from_host(smasks[j]), fmask=dev.DeviceBuffer.from_host(fmasks[i]),
+                                                 want_valid=True, **kw)
+                    assert np.array_equal(got[i].view(np.uint8), d1.to_host().view(np.uint8)), (h, w, dt, C, shared, i)
+                    assert np.array_equal(gotv[i], v1.to_host((h, w), np.uint8)), (h, w, dt, C, shared, i)
+        # validity only (valid_target of B fields at once)
+        _, valid = dev.gather_bilinear_batch(None, np.uint8, 0, h, w, B, fb, -1, fmask=mb, valid=True)
+        gotv = valid.to_host((B, h, w), np.uint8)
+        for i in range(B):
+            v1 = dev.gather_valid_only(h, w, dev.DeviceBuffer.from_host(flows[i]), (h, w), -1, fmask=dev.DeviceBuffer.from_host(fmasks[i]))
+            assert np.array_equal(gotv[i], v1.to_host((h, w), np.uint8))
+        # the Flow-level batch: uint8 images with the default (int8) mask take the float / round-half-even arithmetic
+        fl = [of.Flow(flows[i], 't', fmasks[i].astype(bool)) for i in range(B)]
+        batch = DeviceFlowBatch.from_flows(fl)
+        img8 = [(rng.random((h, w, 3)) * 255).astype(np.uint8) for _ in range(B)]
+        for masks in (None, sb):
+            wb, vb = batch.apply_images(dev.DeviceBuffer.from_host(np.stack(img8)), np.uint8, 3, target_masks=masks)
+            got, gotv = wb.to_host((B, h, w, 3), np.uint8), vb.to_host((B, h, w), np.uint8)
+            for i in range(B):
+                tm = None if masks is None else dev.DeviceBuffer.from_host(smasks[i])
+                d1, v1 = fl[i].to_device().apply_image(dev.DeviceImage.from_host(img8[i]), target_mask=tm)
+                assert np.array_equal(got[i], d1.to_host()) and np.array_equal(gotv[i], v1.to_host((h, w), np.uint8))
+    lib = nat.load()
+    assert lib.ofl_gather_bilinear_batch_dev(ib.ptr, 0, nat.F32, 2, h, w, 0, fb.ptr, h, w, 0, 0, -1, None, 0, None, dst.ptr, None, 0, 0, 0, None) == nat.E_INVALID

@@ -84,8 +84,9 @@ struct DlHead {                           // device header of the exact path (25
     unsigned live_huge;                              // distinct sites left in buckets of more than kMaxBucket entries
     double   need_lo, need_hi;                       // slab mode: only sites with need_lo <= y <= need_hi get a star from cells / fans / clip (else -inf, +inf)
     unsigned slab_stamp;                             // slab mode: slab_stamp_of(field, band) step 1 ran for (0: not a slab state)
-    unsigned skip_fans;                              // the mesh-cell pass settled (next to) nothing: the mesh is no guide to this triangulation
-    unsigned pad[4];
+    unsigned sample_all, sample_ok;                  // dl_cell_sample_kernel: sampled grid cells with four kept corners / of those, verified
+    unsigned pad[3];
+    unsigned dbg[8];                                 // experiments build: counters of the left-over pass (sites, chunks swept, steps, clips, seed/near/coarse clips)
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
 static_assert(offsetof(DlHead, slab_stamp) == ofl_sc::kSlabStampAt, "ofl_scatter_dev.h: kSlabStampAt");
@@ -98,8 +99,9 @@ struct DlWs {
     unsigned char *deg;    // [N] 0 .. 16, kDegTodo, kDegFar
     unsigned *todo_idx;    // [N] points for the fan pass (what the cell pass did not settle), ascending
     unsigned char *cellflag; // [N] per grid cell (x, y): 0 = not verified, 1 / 2 = both triangles Delaunay, diagonal a - c / b - d (ofl_dl::cell_verify)
+    unsigned char *tileflag; // [ceil(W / 32) * ceil(H / 8)] 1 = every cell of the 32 x 8 tile is verified (a CLEAN tile)
     unsigned char *dup;    // [N] 1 = an exact duplicate of a site with a smaller index (not a site of the triangulation)
-    unsigned *nbr;         // [N][kSlots]   (doubles as the bucket cursors while sorting)
+    unsigned *nbr;         // [N][kSlots]
     unsigned *far_idx;     // [N]
     unsigned *far_deg;     // [N]
     unsigned *far_off;     // [N]
@@ -115,9 +117,10 @@ struct DlWs {
     unsigned *left_pt;     // [N] their point indices
     double   *left_box;    // [N / 256 + 1][2][8] oriented boxes of the two image halves of 256 consecutive left-over points
     int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
+    unsigned *cstate;      // [4][cstride] ticket + tile words of the four ordered compactions (dl_compact_kernel)
     unsigned *big;         // [big_cap] triangle ids with a large bounding box
     uint32_t *owner;       // [H][W] (biased by the first row of the band)
-    size_t    bcap, b1cap, pool_cap, big_cap;
+    size_t    bcap, b1cap, pool_cap, big_cap, cstride;
     int       oy0, oy1;
 };
 
@@ -309,14 +312,17 @@ void dl_fill1_kernel(const float *__restrict__ flow, int sign, int W, const DlHe
 
 __global__ __launch_bounds__(256)
 void dl_count_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
-                     const DlHead *__restrict__ head, unsigned *__restrict__ bcount, unsigned char *__restrict__ dup)
+                     const DlHead *__restrict__ head, unsigned *__restrict__ bcount, unsigned char *__restrict__ dup,
+                     unsigned *__restrict__ slot)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)H * W || !kept_pt(pmask, i)) return;
     const Grid g = head->grid;
     const P2 p = PosFn(flow, sign, W)((int)i);
     if (!finite_pt(p.x, p.y)) { dup[i] = 1; return; }      // not a site (flagged like a dropped duplicate)
-    atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
+    // the count a site draws is its slot in the bucket (any order will do: the buckets are sorted by index afterwards), so the
+    // fill pass needs neither a second atomic per site nor a zeroed array of bucket cursors (265 MB at 8K)
+    slot[i] = atomicAdd(&bcount[(size_t)g.by(p.y) * g.gx + g.bx(p.x)], 1u);
 }
 
 // exclusive scan in three launches: sums of 8192-element chunks, ONE workgroup scans up to 8192 of those sums in place,
@@ -399,7 +405,7 @@ void dl_scan_small_kernel(unsigned *__restrict__ data, unsigned n)
 
 __global__ __launch_bounds__(256)
 void dl_fill_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
-                    const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, unsigned *__restrict__ cursor,
+                    const DlHead *__restrict__ head, const unsigned *__restrict__ bstart, const unsigned *__restrict__ slot,
                     unsigned *__restrict__ sorted, const unsigned char *__restrict__ dup)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -407,7 +413,7 @@ void dl_fill_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     const Grid g = head->grid;
     const P2 p = PosFn(flow, sign, W)((int)i);
     const size_t b = (size_t)g.by(p.y) * g.gx + g.bx(p.x);
-    sorted[bstart[b] + atomicAdd(&cursor[b], 1u)] = (unsigned)i;
+    sorted[bstart[b] + slot[i]] = (unsigned)i;
 }
 
 // ascending point index inside every bucket (the fill order is not deterministic)
@@ -591,8 +597,18 @@ void dl_big_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bstar
     }
 }
 
-// every how-manieth grid cell dl_fan_decide_kernel looks at (about 4 096 of them)
+// every how-manieth grid cell dl_cell_sample_kernel looks at (about 4 096 of them)
 __host__ __device__ inline size_t fan_sample_stride(size_t n) { return n / 4096 + 1; }
+
+// Is the mesh worth proposing stars from?  On a strongly sheared field (BASELINE config 5: every source row slides 1 .. 19 px
+// against the next, 42 % of the sites are duplicates) the Delaunay neighbours of a site have nothing to do with its grid
+// neighbours: no cell verifies, and the cell, cell-flag and fan passes (0.6 ms at 8K) verify nothing.  dl_cell_sample_kernel
+// runs the cell test on every fan_sample_stride-th grid cell BEFORE those passes (a few thousand cells, whatever the slab: the
+// ranks of a slab-wise call and a whole-field call must decide alike -- which pass settles a site shows in the order of its
+// neighbours, hence in triangle ids and ties); when at least 64 samples have four kept corners and fewer than 1 in 128 of those
+// verify, all three passes step aside and every site goes to the clip pass.  A speed decision only: the clip pass computes the
+// same stars the cells and fans would have verified.
+__device__ __forceinline__ bool dl_skip_mesh(const DlHead *head) { return head->sample_all >= 64u && head->sample_ok * 128u < head->sample_all; }
 
 // ------------------------------------------------------------------------------------------------ stars, mesh-cell pass
 // One thread per grid cell: both triangles of an intact, convex, positively oriented cell are verified ONCE against the
@@ -602,30 +618,60 @@ __global__ __launch_bounds__(256)
 void dl_cell_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
                     const DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
                     const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy, const unsigned char *__restrict__ dup,
-                    unsigned char *__restrict__ cellflag, int tiles_x, int ntiles)
+                    unsigned char *__restrict__ cellflag, unsigned char *__restrict__ tileflag, int tiles_x, int ntiles)
 {
     const unsigned per = gridDim.x >> 3;                        // (grid padded to a multiple of 8) one contiguous eighth per XCD
     const int tile = (int)((blockIdx.x & 7u) * per + (blockIdx.x >> 3));
     if (tile >= ntiles) return;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x = tx * 32 + (threadIdx.x & 31), y = ty * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    const size_t ia = (size_t)y * W + x;
+    const bool in_grid = x < W && y < H;
+    const size_t ia = in_grid ? (size_t)y * W + x : 0;
     int flag = 0;
-    if (x < W - 1 && y < H - 1 && !(head->err & kErrDegenerate) &&
+    if (in_grid && x < W - 1 && y < H - 1 && !(head->err & kErrDegenerate) && !dl_skip_mesh(head) &&
         kept_pt(pmask, ia) && kept_pt(pmask, ia + 1) && kept_pt(pmask, ia + W) && kept_pt(pmask, ia + W + 1) &&
         !(dup[ia] | dup[ia + 1] | dup[ia + W] | dup[ia + W + 1])) {
         const D2 a = point_of(flow, sign, W, x, y), b = point_of(flow, sign, W, x + 1, y);
         const D2 c = point_of(flow, sign, W, x + 1, y + 1), d = point_of(flow, sign, W, x, y + 1);
         // (slab mode: a cell none of whose corners gets a star here is not looked at -- every site that does get one still
         // finds all four of its cells verified, so its star comes out of the same pass as in a whole-field run)
-        // (... except the cells dl_fan_decide_kernel samples: its decision must not depend on the slab)
         const double lo = head->need_lo, hi = head->need_hi;
-        if ((fmax(fmax(a.y, b.y), fmax(c.y, d.y)) >= lo && fmin(fmin(a.y, b.y), fmin(c.y, d.y)) <= hi) || ia % fan_sample_stride((size_t)H * W) == 0)
+        if (fmax(fmax(a.y, b.y), fmax(c.y, d.y)) >= lo && fmin(fmin(a.y, b.y), fmin(c.y, d.y)) <= hi)
         flag = cell_verify((int)ia, W, P2{ a.x, a.y }, P2{ b.x, b.y }, P2{ c.x, c.y }, P2{ d.x, d.y }, head->grid, bstart, sorted, sorted_xy,
                            PosFn(flow, sign, W), kFanSpan);
     }
-    cellflag[ia] = (unsigned char)flag;
+    if (in_grid) cellflag[ia] = (unsigned char)flag;
+    // a CLEAN tile: every one of its 256 cells verified (tiles that reach the last row or column of sites never are)
+    const int clean = __syncthreads_and(flag != 0);
+    if (threadIdx.x == 0) tileflag[tile] = clean ? 1 : 0;
+}
+
+// the sample of grid cells that decides whether the mesh is a guide to this triangulation at all (dl_skip_mesh)
+__global__ __launch_bounds__(256)
+void dl_cell_sample_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                           DlHead *__restrict__ head, const unsigned *__restrict__ bstart,
+                           const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy, const unsigned char *__restrict__ dup)
+{
+    const size_t n = (size_t)H * W, stride = fan_sample_stride(n);
+    const size_t ia = ((size_t)blockIdx.x * 256 + threadIdx.x) * stride;
+    unsigned all = 0, ok = 0;
+    if (ia < n && !(head->err & kErrDegenerate)) {
+        const int y = (int)(ia / (unsigned)W), x = (int)(ia - (size_t)y * W);
+        if (x < W - 1 && y < H - 1 &&
+            kept_pt(pmask, ia) && kept_pt(pmask, ia + 1) && kept_pt(pmask, ia + W) && kept_pt(pmask, ia + W + 1) &&
+            !(dup[ia] | dup[ia + 1] | dup[ia + W] | dup[ia + W + 1])) {
+            const D2 a = point_of(flow, sign, W, x, y), b = point_of(flow, sign, W, x + 1, y);
+            const D2 c = point_of(flow, sign, W, x + 1, y + 1), d = point_of(flow, sign, W, x, y + 1);
+            all = 1;
+            ok = cell_verify((int)ia, W, P2{ a.x, a.y }, P2{ b.x, b.y }, P2{ c.x, c.y }, P2{ d.x, d.y }, head->grid, bstart, sorted, sorted_xy,
+                             PosFn(flow, sign, W), kFanSpan) != 0 ? 1u : 0u;
+        }
+    }
+    const unsigned long long ball = __ballot(all != 0), bok = __ballot(ok != 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (ball) atomicAdd(&head->sample_all, (unsigned)__popcll(ball));
+        if (bok) atomicAdd(&head->sample_ok, (unsigned)__popcll(bok));
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -652,38 +698,7 @@ void dl_site_cells_kernel(const float *__restrict__ flow, int sign, const uint8_
             row[1] = make_uint4(out[4], n > 5 ? out[5] : 0u, n > 6 ? out[6] : 0u, n > 7 ? out[7] : 0u);
         }
     }
-    deg[p] = n > 0 ? (unsigned char)n : kDegFan;
-}
-
-// Is the mesh worth proposing fans from?  On a strongly sheared field (BASELINE config 5: every source row slides 1 .. 19 px
-// against the next, 42 % of the sites are duplicates) the Delaunay neighbours of a site have nothing to do with its grid
-// neighbours: the cell pass verifies NO cell and the fan pass would spend 0.84 ms at 8K to verify no fan.  Every
-// fan_sample_stride-th grid cell is a SAMPLE (the cell pass verifies those whatever the slab, so that the ranks of a slab-wise
-// call and a whole-field call decide alike -- which pass settles a site shows in the order of its neighbours, hence in triangle
-// ids and ties): when at least 64 samples have four kept corners and fewer than 1 in 128 of those were verified, the fan pass
-// only relabels its list for the clip pass.  A speed decision only -- the clip pass computes the same stars the fans would
-// have verified.
-__global__ __launch_bounds__(1024)
-void dl_fan_decide_kernel(const uint8_t *__restrict__ pmask, const unsigned char *__restrict__ dup, const unsigned char *__restrict__ cellflag,
-                          int H, int W, DlHead *head)
-{
-    __shared__ unsigned s_all, s_ok;
-    if (threadIdx.x == 0) { s_all = 0; s_ok = 0; }
-    __syncthreads();
-    const size_t n = (size_t)H * W, stride = fan_sample_stride(n);
-    unsigned all = 0, ok = 0;
-    for (size_t i = (size_t)threadIdx.x * stride; i < n; i += 1024 * stride) {
-        const int y = (int)(i / (unsigned)W), x = (int)(i - (size_t)y * W);
-        if (x >= W - 1 || y >= H - 1) continue;
-        if (!(kept_pt(pmask, i) && kept_pt(pmask, i + 1) && kept_pt(pmask, i + W) && kept_pt(pmask, i + W + 1))) continue;
-        if (dup[i] | dup[i + 1] | dup[i + W] | dup[i + W + 1]) continue;
-        ++all;
-        ok += cellflag[i] != 0;
-    }
-    if (all) atomicAdd(&s_all, all);
-    if (ok) atomicAdd(&s_ok, ok);
-    __syncthreads();
-    if (threadIdx.x == 0) head->skip_fans = (s_all >= 64 && s_ok * 128 < s_all) ? 1u : 0u;
+    deg[p] = n > 0 ? (unsigned char)n : (dl_skip_mesh(head) ? kDegTodo : kDegFan);      // (no fans either on a mesh that is no guide)
 }
 
 // ------------------------------------------------------------------------------------------------ stars, mesh-fan pass
@@ -697,11 +712,7 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
 {
     __shared__ P2 s_rel[8][kFanBlock];
-    const unsigned n_fan = head->n_fan;                         // the sites the cell pass did not settle, in index order
-    if (head->skip_fans) {                                      // (dl_fan_decide_kernel)
-        for (unsigned i = blockIdx.x * kFanBlock + threadIdx.x; i < n_fan; i += gridDim.x * kFanBlock) deg[todo[i]] = kDegTodo;
-        return;
-    }
+    const unsigned n_fan = head->n_fan;                         // the sites the cell pass did not settle, in index order (none when dl_skip_mesh)
     for (unsigned i = blockIdx.x * kFanBlock + threadIdx.x; i < n_fan; i += gridDim.x * kFanBlock) {
         const size_t p = todo[i];
         const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
@@ -835,6 +846,11 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
 // MODE 1 also lists the ranks the wave pass finished beyond kMidRings coarse rings (aux = far_wide): they are not computed
 // again, but the workgroup pass searches the coarse grid only that far around a point, and a neighbour whose own cell
 // reaches farther would otherwise be missing from its candidates.
+// the flags of the eight elements [base, base + 8) as bits (base a multiple of 8; elements at or beyond n are not flagged):
+// one 8-byte load of the degree bytes -- or two 16-byte loads of the ranks' words and one 8-byte load of `aux`
+template <int MODE>
+__device__ __forceinline__ unsigned flagged8(const void *src, const unsigned char *aux, size_t base, size_t n);
+
 template <int MODE>
 __device__ __forceinline__ bool flagged(const void *src, const unsigned char *aux, size_t i)
 {
@@ -843,40 +859,102 @@ __device__ __forceinline__ bool flagged(const void *src, const unsigned char *au
          : MODE == 2 ? ((const unsigned char *)src)[i] == kDegFan : (((const unsigned *)src)[i] == kDegLeft || aux[i] != 0);
 }
 
+// Ordered compaction in ONE launch (decoupled look-back).  A workgroup draws a SUPER TILE of kCompactTiles x kScanChunk elements by
+// ticket -- so a tile's predecessors are resident or done when it starts waiting for them -- counts it, publishes the count
+// as (flag | value) in one word (1 << 30: the tile's own aggregate, 1 << 31: the inclusive prefix) with agent-scope (sc1)
+// stores, and its first wave looks back 64 tiles at a time (sc1 loads: the per-XCD L2s are not coherent) until it meets an
+// inclusive word; then the super tile is walked a second time (its flags come from L2) and the list is written.  A 4K field is
+// 254 super tiles -- one per CU, one look-back window deep: with one tile per 2048 elements the thousands of tiles that start
+// together each walked back over all the others (65 us per list; the three-kernel count / scan / write it replaced: 27 us).
+// state[0] = the ticket counter, state[4 + t] = tile t's word; zeroed by the caller.
 template <int MODE>
-__global__ __launch_bounds__(256)
-void dl_flag_count_kernel(const void *__restrict__ src, const unsigned char *__restrict__ aux, const DlHead *__restrict__ head, size_t n_fixed, unsigned *__restrict__ cnt)
+__device__ __forceinline__ unsigned flagged8(const void *src, const unsigned char *aux, size_t base, size_t n)
 {
-    const size_t n = MODE != 1 ? n_fixed : head->n_far;
-    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
-    unsigned v = 0;
+    unsigned bits = 0;
+    if (base + 8 <= n) {
+        if (MODE != 1) {
+            const unsigned char want = MODE == 3 ? kDegTodo : (MODE == 0 ? kDegFar : kDegFan);
+            const uint2 w = *reinterpret_cast<const uint2 *>((const unsigned char *)src + base);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, aux, base + k)) ++v;
-    unsigned total;
-    (void)block_exscan(v, total);
-    if (threadIdx.x == 0) cnt[blockIdx.x] = total;
+            for (int k = 0; k < 8; ++k) if ((((k < 4 ? w.x : w.y) >> (8 * (k & 3))) & 0xFFu) == want) bits |= 1u << k;
+        } else {
+            const uint4 a = *reinterpret_cast<const uint4 *>((const unsigned *)src + base), b = *reinterpret_cast<const uint4 *>((const unsigned *)src + base + 4);
+            const uint2 x = *reinterpret_cast<const uint2 *>(aux + base);
+            const unsigned d[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (d[k] == kDegLeft || (((k < 4 ? x.x : x.y) >> (8 * (k & 3))) & 0xFFu) != 0u) bits |= 1u << k;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, aux, base + k)) bits |= 1u << k;
+    }
+    return bits;
 }
 
+constexpr int kCompactTiles = 16;
 template <int MODE>
 __global__ __launch_bounds__(256)
-void dl_flag_write_kernel(const void *__restrict__ src, const unsigned char *__restrict__ aux, DlHead *head, size_t n_fixed, const unsigned *__restrict__ offs,
-                          unsigned *__restrict__ list, unsigned last_block, unsigned *__restrict__ rank_of)
+void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__restrict__ aux, DlHead *head, size_t n_fixed,
+                       unsigned *__restrict__ state, unsigned *__restrict__ list, unsigned *__restrict__ rank_of)
 {
+    __shared__ unsigned s_tile, s_prefix;
+    if (threadIdx.x == 0) s_tile = atomicAdd(&state[0], 1u);
+    __syncthreads();
+    const unsigned tile = s_tile;
     const size_t n = MODE != 1 ? n_fixed : head->n_far;
-    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * 8;
+    const size_t base0 = (size_t)tile * kCompactTiles * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n && flagged<MODE>(src, aux, base + k)) ++v;
+    for (int c = 0; c < kCompactTiles; ++c) {
+        v += (unsigned)__popc(flagged8<MODE>(src, aux, base0 + (size_t)c * kScanChunk, n));
+    }
     unsigned total;
-    unsigned at = block_exscan(v, total) + offs[blockIdx.x];
+    (void)block_exscan(v, total);
+    if (threadIdx.x < 64) {
+        unsigned *st = state + 4;
+        const int lane = threadIdx.x;
+        if (tile > 0 && lane == 0) __hip_atomic_store(&st[tile], 0x40000000u | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned prefix = 0;
+        for (long long hi = (long long)tile - 1; hi >= 0;) {
+            const long long j = hi - lane;
+            unsigned w;
+            for (;;) {
+                w = j >= 0 ? __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x80000000u;     // (before tile 0: an inclusive 0)
+                if (!__ballot(w == 0u)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned long long inc = __ballot((w & 0x80000000u) != 0u);
+            const int stop = inc ? __ffsll((long long)inc) - 1 : 63;          // the nearest inclusive word of the window (lane 0 = nearest tile)
+            unsigned v2 = lane <= stop ? (w & 0x3FFFFFFFu) : 0u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (base + k < n && flagged<MODE>(src, aux, base + k)) {
-            if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
-            list[at++] = (unsigned)(base + k);
+            for (int off = 32; off > 0; off >>= 1) v2 += (unsigned)__shfl_xor((int)v2, off);
+            prefix += v2;
+            if (inc) break;
+            hi -= 64;
         }
-    if (blockIdx.x == last_block && threadIdx.x == 0) {
-        unsigned cnt = offs[blockIdx.x] + total;
+        if (lane == 0) {
+            __hip_atomic_store(&st[tile], 0x80000000u | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+        }
+    }
+    __syncthreads();
+    unsigned run = s_prefix;
+    for (int c = 0; c < kCompactTiles; ++c) {
+        const size_t base = base0 + (size_t)c * kScanChunk;
+        if (base - (size_t)threadIdx.x * 8 >= n) break;        // (uniform: the whole chunk lies beyond the end)
+        const unsigned bits = flagged8<MODE>(src, aux, base, n), cv = (unsigned)__popc(bits);
+        unsigned ctotal;
+        unsigned at = run + block_exscan(cv, ctotal);
+        run += ctotal;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((bits >> k) & 1u) {
+                if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
+                list[at++] = (unsigned)(base + k);
+            }
+    }
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) {
+        unsigned cnt = s_prefix + total;
         if (MODE == 0 && (unsigned long long)n_fixed * kSlots + (unsigned long long)cnt * kFarK >= 0xFFFFFFF0ull) {
             atomicOr(&head->err, 8u);                      // the unfinished stars exceed the triangle-id space: none is built, the caller is told
             cnt = 0;
@@ -915,6 +993,7 @@ struct FarLds {
     unsigned run_lo[64];       // candidate runs of the current step (ranges of a sorted list) ...
     int    run_pre[65];        // ... and the exclusive prefix of their lengths
     int    n, a, ncut, nstart, status;
+    int    napply;             // cooperative clips applied to this cell so far (counted for the experiments build's debug line)
     // Candidate rejection: a site can only cut a vertex v if it is closer than 2 |v| to the cell's site.  Vertices well
     // outside the data (|v|^2 > t2: the box vertices of an unbounded cell, the circumcentres of sliver triangles along a
     // straight border) would make that radius useless, so they are listed and tested one by one; reach2 covers the rest.
@@ -1081,7 +1160,7 @@ __device__ void far_apply(FarLds<CAP, NT> &L, const P2 &C, int ctag, int ptag, R
             L.vx[m + 1] = v2.x; L.vy[m + 1] = v2.y; L.tag[m + 1] = tb;
         }
     }
-    if (t == 0) L.n = n2;
+    if (t == 0) { L.n = n2; ++L.napply; }
     __syncthreads();
     far_refresh(L);
 }
@@ -1163,7 +1242,9 @@ __device__ void far_chunks(FarLds<CAP, NT> &L, int p, const P2 &pp, const int (&
         int bestk = -1;
 #pragma unroll
         for (int k = 0; k < K; ++k) if (((pend >> k) & 1u) && d2[k] < best) { best = d2[k]; bestk = k; }
-        if (!__syncthreads_or(bestk >= 0)) return;         // (every application below ends with a barrier: the cell is stable here)
+        // (every application below ends with a barrier: the cell is stable here.  A single wave votes with a ballot:
+        // __syncthreads_or is a workgroup reduction through LDS, a hundred instructions for every step of every sweep)
+        if (NT == 64 ? (__ballot(bestk >= 0) == 0ull) : !__syncthreads_or(bestk >= 0)) return;
         // the nearest cutting candidate of the workgroup: lowest lane of the wave minimum, lowest wave of equal minima
         double wmin = best;
 #pragma unroll
@@ -1307,7 +1388,7 @@ __device__ void far_seeds(FarLds<CAP, NT> &L, int p, const P2 &pp, const unsigne
         vx = (ah * by - bh * ay) / det; vy = (ax * bh - bx * ah) / det;
         bad = det == 0.0 || !(isfinite(vx) && isfinite(vy)) || fabs(vx) > 4.0 * kBox || fabs(vy) > 4.0 * kBox;
     }
-    if (!__syncthreads_or(bad)) {
+    if (NT == 64 ? (__ballot(bad) == 0ull) : !__syncthreads_or(bad)) {
         if (t < ns) { L.vx[t] = vx; L.vy[t] = vy; L.tag[t] = tag; }
         if (t == 0) L.n = ns;
         __syncthreads();
@@ -1439,49 +1520,57 @@ __device__ void far_point(FarLds<CAP, NT> &L, unsigned &s_off, unsigned li, unsi
     if (t == 0) {
         Poly P{ L.vx, L.vy, L.tag, 1, CAP, 0 };
         poly_init(P);
-        L.n = P.n; L.status = 0; L.t2 = head->far_t2;
+        L.n = P.n; L.status = 0; L.t2 = head->far_t2; L.napply = 0;
     }
     __syncthreads();
     far_refresh(L);
     far_seeds(L, p, pp, nbr, pos, rel);
     far_near_rows(L, p, pp, g, bstart, sorted, sorted_xy, rel);
     far_coarse_annulus(L, p, pp, -1, kMidRings, g1, b1start, sorted1_pt, sorted1_xy, rel);
-    // Every other left-over point, kVote x NT per vote -- but only the chunks of 256 whose bounding box could hold a site
-    // that cuts the cell AS IT STANDS NOW (later the cell only shrinks: its reach falls, its far vertices stay inside the
-    // present cone and below the present largest distance, so what cannot cut now cannot cut later).  The test is
-    // far_test's, applied to a box: nearer than the reach of the near vertices, or not excluded by the far cone.
+#ifdef OFL_EXPERIMENTS
+    __syncthreads();
+    const int dbg_before = L.napply;
+    unsigned dbg_chunks = 0;
+#endif
+    // Every other left-over point -- but only the chunks of 256 whose bounding box could hold a site that cuts the cell AS IT
+    // STANDS (later the cell only shrinks: its reach falls, its far vertices stay inside the present cone and below the present
+    // largest distance, so what cannot cut now cannot cut later).  The test is far_test's, applied to a box: nearer than the
+    // reach of the near vertices, or not excluded by the far cone.
     const unsigned n_chunks = (n_left + 255) / 256;
+    // could chunk ck hold a site that cuts the cell as it stands now?
+    auto chunk_keep = [&](unsigned ck) -> bool {
+        bool keep = false;
+#pragma unroll 1
+        for (int half = 0; half < 2 && !keep; ++half) {
+            const double *b = left_box + ((size_t)ck * 2 + half) * 8;
+            const double ax = b[2], ay = b[3], t0 = b[4], t1 = b[5], s0 = b[6], s1 = b[7];
+            if (!(t0 <= t1)) continue;                       // empty half
+            const double rx = b[0] - pp.x, ry = b[1] - pp.y;              // the box origin seen from the site
+            const double tp = -(rx * ax + ry * ay), sp = -(ry * ax - rx * ay);        // the site in the box frame
+            const double dt = fmax(fmax(t0 - tp, tp - t1), 0.0), ds = fmax(fmax(s0 - sp, sp - s1), 0.0), dmin2 = dt * dt + ds * ds;
+            if (dmin2 < L.reach2) { keep = true; break; }
+            if (L.nfar == 0) continue;
+            if (!L.cone) { keep = true; break; }
+            double mmax = 0.0, amax = 0.0;
+            bool right0 = true, left1 = true;                // every corner strictly outside one side of the cone?
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double tt = (k & 1) ? t1 : t0, ss = (k & 2) ? s1 : s0;
+                const double cx = rx + tt * ax - ss * ay, cy = ry + tt * ay + ss * ax;
+                mmax = fmax(mmax, fmax(L.c0x * cx + L.c0y * cy, L.c1x * cx + L.c1y * cy));
+                amax = fmax(amax, fabs(cx) + fabs(cy));
+                right0 = right0 && (L.c0x * cy - L.c0y * cx < 0.0);
+                left1 = left1 && (cx * L.c1y - cy * L.c1x < 0.0);
+            }
+            // (the corners are rounded: a margin of 1e-9 of their size on the dot products, as on the sites themselves)
+            if (!((right0 || left1) && mmax + 2e-9 * amax < dmin2 * L.kcone)) keep = true;
+        }
+        return keep;
+    };
     for (unsigned cbase = 0; cbase < n_chunks; cbase += NT) {
         __syncthreads();
-        bool keep = false;
         const unsigned ck = cbase + t;
-        if (ck < n_chunks) {
-#pragma unroll 1
-            for (int half = 0; half < 2 && !keep; ++half) {
-                const double *b = left_box + ((size_t)ck * 2 + half) * 8;
-                const double ax = b[2], ay = b[3], t0 = b[4], t1 = b[5], s0 = b[6], s1 = b[7];
-                if (!(t0 <= t1)) continue;                       // empty half
-                const double rx = b[0] - pp.x, ry = b[1] - pp.y;              // the box origin seen from the site
-                const double tp = -(rx * ax + ry * ay), sp = -(ry * ax - rx * ay);        // the site in the box frame
-                const double dt = fmax(fmax(t0 - tp, tp - t1), 0.0), ds = fmax(fmax(s0 - sp, sp - s1), 0.0), dmin2 = dt * dt + ds * ds;
-                if (dmin2 < L.reach2) { keep = true; break; }
-                if (L.nfar == 0) continue;
-                if (!L.cone) { keep = true; break; }
-                double mmax = 0.0, amax = 0.0;
-                bool right0 = true, left1 = true;                // every corner strictly outside one side of the cone?
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double tt = (k & 1) ? t1 : t0, ss = (k & 2) ? s1 : s0;
-                    const double cx = rx + tt * ax - ss * ay, cy = ry + tt * ay + ss * ax;
-                    mmax = fmax(mmax, fmax(L.c0x * cx + L.c0y * cy, L.c1x * cx + L.c1y * cy));
-                    amax = fmax(amax, fabs(cx) + fabs(cy));
-                    right0 = right0 && (L.c0x * cy - L.c0y * cx < 0.0);
-                    left1 = left1 && (cx * L.c1y - cy * L.c1x < 0.0);
-                }
-                // (the corners are rounded: a margin of 1e-9 of their size on the dot products, as on the sites themselves)
-                if (!((right0 || left1) && mmax + 2e-9 * amax < dmin2 * L.kcone)) keep = true;
-            }
-        }
+        const bool keep = ck < n_chunks && chunk_keep(ck);
         // ordered compaction of the kept chunk numbers of this group
         const unsigned long long bal = __ballot(keep);
         if ((t & 63) == 0) L.hit[t >> 6] = bal;
@@ -1490,6 +1579,9 @@ __device__ void far_point(FarLds<CAP, NT> &L, unsigned &s_off, unsigned li, unsi
         for (int w = 0; w < NT / 64; ++w) { const unsigned c = (unsigned)__popcll(L.hit[w]); if (w < (t >> 6)) before += c; total += c; }
         if (keep) L.clist[before + (unsigned)__popcll(bal & ((1ull << (t & 63)) - 1ull))] = ck;
         __syncthreads();
+#ifdef OFL_EXPERIMENTS
+        dbg_chunks += total;
+#endif
         constexpr int kVote = NT == 64 ? 1 : 4;            // steps under one vote (a wave's own vote is cheap)
         constexpr int kPer = 256 / NT;                     // steps of NT candidates per chunk of 256
         for (unsigned k0 = 0; k0 < total * kPer; k0 += kVote) {
@@ -1509,12 +1601,25 @@ __device__ void far_point(FarLds<CAP, NT> &L, unsigned &s_off, unsigned li, unsi
         }
     }
     __syncthreads();
+#ifdef OFL_EXPERIMENTS
+    if (t == 0 && NT == 64) {
+        atomicAdd(&head->dbg[0], 1u); atomicAdd(&head->dbg[1], dbg_chunks); atomicAdd(&head->dbg[2], (unsigned)dbg_before);
+        atomicAdd(&head->dbg[3], (unsigned)(L.napply - dbg_before)); atomicAdd(&head->dbg[4], (unsigned)L.n);
+        atomicMax(&head->dbg[5], dbg_chunks); if (dbg_chunks > 12) atomicAdd(&head->dbg[6], 1u); atomicMax(&head->dbg[7], (unsigned)L.napply);
+    }
+#endif
     if (CAP < kFarCap && L.status) return;               // overflow of the small capacity: far_deg stays kDegLeft for the next pass
     far_store(L, rank, head, far_deg, far_off, pool, pool_cap, &s_off);
 }
 
+#ifndef OFL_FAR_WAVES
+#define OFL_FAR_WAVES 4
+#endif
+#ifndef OFL_FAR_CAP
+#define OFL_FAR_CAP 384
+#endif
 template <int CAP, int NT>          // first single waves with a small cell capacity, then -- for the few fans that overflowed it -- workgroups with the large one
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT, NT == 64 ? OFL_FAR_WAVES : 1)
 void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, DlHead *head,
                         const unsigned *__restrict__ bstart, const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                         const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt, const P2 *__restrict__ sorted1_xy,
@@ -1526,8 +1631,9 @@ void dl_star_far_kernel(const float *__restrict__ flow, int sign, int H, int W, 
     __shared__ FarLds<CAP, NT> L;
     __shared__ unsigned s_off;
     const unsigned n_left = head->n_left;
-    for (unsigned li = blockIdx.x; li < n_left; li += gridDim.x) {
+    for (unsigned lb = blockIdx.x; lb < n_left; lb += gridDim.x) {
         __syncthreads();
+        const unsigned li = lb;
         far_point<CAP, NT>(L, s_off, li, n_left, flow, sign, H, W, head, bstart, sorted, sorted_xy, b1start, sorted1_pt, sorted1_xy, far_idx,
                        left_idx, left_pt, left_xy, left_box, nbr, far_deg, far_off, pool, pool_cap);
     }
@@ -1595,7 +1701,41 @@ __device__ __forceinline__ bool star_has(const DlWs &ws, unsigned s, unsigned a,
     return false;
 }
 
-// one triangle by one thread; large bounding boxes go to the list swept by whole waves.  Every triangle is listed by
+// scan conversion of ONE triangle by one thread (vertices in canonical rotation: every copy sets up the same edge functions);
+// large bounding boxes go to the list swept by whole waves
+__device__ __forceinline__ void raster_tri(unsigned id, const D2 &q0, const D2 &q1, const D2 &q2, int H, int W, const DlWs &ws)
+{
+    const TriBox b = box_rows(q0, q1, q2, W, H, ws);
+    if (b.x1 < b.x0 || b.y1 < b.y0) return;
+    const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
+    if (area > kSmallArea) {
+        const unsigned long long slot = atomicAdd(&ws.head->big_n, 1ull);
+        if (slot < ws.big_cap) ws.big[slot] = id; else atomicOr(&ws.head->err, 4u);
+        return;
+    }
+    TriEdge te;
+    if (!tri_setup(q0, q1, q2, te)) return;
+    for (int gy = b.y0; gy <= b.y1; ++gy)
+        for (int gx = b.x0; gx <= b.x1; ++gx)
+            if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
+    // (per-row intervals as in dl_raster_big_kernel were measured here for the wide boxes of sheared lattices: the extra
+    // registers and code slow every field down by 4 - 10 %, config 5 included)
+}
+
+// Is grid site (x, y) CLEAN: do the four cells around it, and the four cells around each of its grid neighbours NW, N, NE and W
+// (the only ones with a smaller index), all lie in clean tiles (dl_cell_kernel: every cell of the 32 x 8 tile verified)?  Then
+// its star and theirs were written from cell flags (dl_site_cells_kernel; ofl_dl::star_from_cells: E, SE?, S, SW?, W, NW?, N,
+// NE?), every triangle it lists is a triangle of a verified cell and is owned by a site whose star lists it: the triangles a
+// clean site OWNS are drawn cell by cell (dl_raster_cells_kernel) with the ids the site-wise raster would give them, and that
+// raster has nothing to do for a clean site.  The cells in question are [x - 2, x + 1] x [y - 2, y]: at most four tiles.
+__device__ __forceinline__ bool site_clean(const unsigned char *__restrict__ tileflag, int x, int y, int W, int H, int tiles_x)
+{
+    if (x < 2 || y < 2 || x > W - 3 || y > H - 2) return false;
+    const int tx0 = (x - 2) >> 5, tx1 = (x + 1) >> 5, ty0 = (y - 2) >> 3, ty1 = y >> 3;
+    return tileflag[ty0 * tiles_x + tx0] && tileflag[ty0 * tiles_x + tx1] && tileflag[ty1 * tiles_x + tx0] && tileflag[ty1 * tiles_x + tx1];
+}
+
+// one triangle of a star by one thread.  Every triangle is listed by
 // each of its three sites; the copy of the site with the smallest index is the one that is drawn -- unless that
 // site's star does not list the triangle (stars that disagree on a co-circular cell), in which case this copy is drawn too.
 // `trust`: bit 0 = `self` was settled by the mesh-cell pass (its neighbours are grid neighbours), bits 1 .. 4 = so were its
@@ -1614,22 +1754,40 @@ __device__ __forceinline__ void thread_raster(unsigned id, unsigned self, const 
         }
         if (skip || star_has(ws, tr.i0, tr.i1, tr.i2)) return;
     }
-    const D2 q0 = pt(pos, tr.i0), q1 = pt(pos, tr.i1), q2 = pt(pos, tr.i2);
-    const TriBox b = box_rows(q0, q1, q2, W, H, ws);
-    if (b.x1 < b.x0 || b.y1 < b.y0) return;
-    const long long area = (long long)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1);
-    if (area > kSmallArea) {
-        const unsigned long long slot = atomicAdd(&ws.head->big_n, 1ull);
-        if (slot < ws.big_cap) ws.big[slot] = id; else atomicOr(&ws.head->err, 4u);
-        return;
+    raster_tri(id, pt(pos, tr.i0), pt(pos, tr.i1), pt(pos, tr.i2), H, W, ws);
+}
+
+// Cell-centric raster of the intact parts of the mesh: one thread per grid cell of a clean tile draws the cell's two
+// triangles -- corner positions from two coalesced rows of the flow, no star to decode, no look-up into another site's star --
+// with exactly the ids the site-wise raster gives them: a triangle belongs to its smallest-index vertex s, and when s is a
+// clean site (site_clean) its position k in s's star follows from s's own cell flags:
+//   diagonal a - c:  (a, b, c) = a's triangle 0 (E, SE),  (a, c, d) = a's triangle 1 (SE, S)
+//   diagonal b - d:  (a, b, d) = a's triangle 0 (E, S),   (b, c, d) = b's triangle (S, SW): k = 1 + [b's own cell has diagonal a - c]
+// (a = (x, y), b = (x + 1, y), c = (x + 1, y + 1), d = (x, y + 1): a < b < d < c in index order).  Triangles whose owner is
+// not clean -- rims of holes and tears, neighbourhoods of dropped points -- stay with the site-wise raster, which in turn
+// returns at once for clean sites: whole waves of it, since cleanliness goes by tiles.  An intact mesh with a hole or a
+// moving object in it is drawn almost entirely here (4K: 0.49 -> 0.27 ms); on a field that is broken all over (speckled
+// point masks, BASELINE config 5) no tile is clean and this kernel ends after one byte per workgroup.
+__global__ __launch_bounds__(256)
+void dl_raster_cells_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base, int tiles_x, int ntiles)
+{
+    const unsigned per = gridDim.x >> 3;                        // (grid padded to a multiple of 8) one contiguous eighth per XCD
+    const int tile = (int)((blockIdx.x & 7u) * per + (blockIdx.x >> 3));
+    if (tile >= ntiles || !ws.tileflag[tile]) return;           // (the owner of a triangle is clean only if the cell's own tile is)
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x = tx * 32 + (threadIdx.x & 31), y = ty * 8 + (threadIdx.x >> 5);
+    const size_t ia = (size_t)y * W + x;
+    const unsigned f = ws.cellflag[ia];                         // (a clean tile lies inside the grid, all flags non-zero)
+    const bool sa = site_clean(ws.tileflag, x, y, W, H, tiles_x);
+    const bool sb = f == 2 && site_clean(ws.tileflag, x + 1, y, W, H, tiles_x);
+    if (!sa && !sb) return;
+    const D2 a = point_of(flow, sign, W, x, y), b = point_of(flow, sign, W, x + 1, y);
+    const D2 c = point_of(flow, sign, W, x + 1, y + 1), d = point_of(flow, sign, W, x, y + 1);
+    if (sa) {
+        raster_tri((unsigned)ia * kSlots, a, b, f == 1 ? c : d, H, W, ws);
+        if (f == 1) raster_tri((unsigned)ia * kSlots + 1u, a, c, d, H, W, ws);
     }
-    TriEdge te;
-    if (!tri_setup(q0, q1, q2, te)) return;
-    for (int gy = b.y0; gy <= b.y1; ++gy)
-        for (int gx = b.x0; gx <= b.x1; ++gx)
-            if (tri_inside(te, (double)gx, (double)gy)) atomicMin(&ws.owner[(size_t)gy * W + gx], id);
-    // (per-row intervals as in dl_raster_big_kernel were measured here for the wide boxes of sheared lattices: the extra
-    // registers and code slow every field down by 4 - 10 %, config 5 included)
+    if (sb) raster_tri((unsigned)(ia + 1) * kSlots + 1u + (ws.cellflag[ia + 1] == 1 ? 1u : 0u), b, c, d, H, W, ws);
 }
 
 __global__ __launch_bounds__(256)
@@ -1655,6 +1813,7 @@ void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int
     unsigned trust = 0;
     {
         const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
+        if (site_clean(ws.tileflag, x, y, W, H, (W + 31) / 32)) return;      // everything this site lists is drawn cell by cell (dl_raster_cells_kernel)
         if (x >= 2 && y >= 2 && x <= W - 3 && y <= H - 2) {
             const unsigned char *f = ws.cellflag + (size_t)(y - 2) * W + (x - 2);
             struct __attribute__((packed, aligned(1))) U32u { unsigned v; };
@@ -2047,7 +2206,8 @@ Sizes sizes_for(int H, int W)
 {
     Sizes z;
     z.n = (size_t)H * W;
-    z.bcap = 2 * z.n + 1024;
+    z.bcap = z.n + z.n / 4 + 4096;  // ~ one site per bucket needs n + O(sqrt n) buckets; dl_params_kernel widens the buckets of a point set
+                                    // whose shape would need more (2 n + 1 in the worst case: all sites on one slanted line)
     z.b1cap = z.bcap / 6 + 64;      // ceil(gx / 8) * ceil(gy / 8) <= gx gy / 64 + (gx + gy) / 8 + 1 with gx gy <= bcap, gx + gy <= bcap + 1
     z.pool_cap = 8 * z.n + 65536;
     z.big_cap = 6 * z.n + 1024;
@@ -2068,8 +2228,9 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.deg = (unsigned char *)p;            p += align_up(n, 256);
     ws.todo_idx = (unsigned *)p;            p += align_up(n * 4, 256);
     ws.cellflag = (unsigned char *)p;       p += align_up(n, 256);
+    ws.tileflag = (unsigned char *)p;       p += align_up((size_t)((W + 31) / 32) * ((H + 7) / 8), 256);
     ws.dup = (unsigned char *)p;            p += align_up(n, 256);
-    ws.nbr = (unsigned *)p;                 p += align_up(std::max(n * kSlots, ws.bcap) * 4, 256);
+    ws.nbr = (unsigned *)p;                 p += align_up(n * kSlots * 4, 256);
     ws.far_idx = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_deg = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.far_off = (unsigned *)p;             p += align_up(n * 4, 256);
@@ -2085,6 +2246,8 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.left_pt = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.left_box = (double *)p;              p += align_up((n / 256 + 1) * 128, 256);
     ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
+    ws.cstride = align_up((n + kScanChunk - 1) / kScanChunk + 4, 64);
+    ws.cstate = (unsigned *)p;              p += align_up(4 * ws.cstride * 4, 256);
     ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
     ws.oy0 = 0; ws.oy1 = H;
@@ -2150,17 +2313,17 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
     init.kx0 = init.ky0 = ~0ull;
     OFL_HIP(hipMemcpyAsync(ws.head, &init, sizeof(init), hipMemcpyHostToDevice, s));
     OFL_HIP(hipMemsetAsync(ws.bstart, 0, (ws.bcap + 1) * 4, s));
-    OFL_HIP(hipMemsetAsync(ws.nbr, 0, ws.bcap * 4, s));                 // bucket cursors
     const unsigned nblk = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 1024 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
     static const double bucket_scale = OFL_KNOB_DOUBLE("OFL_DL_BUCKET", 1.0);      // development knob (experiments build only)
     hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W, slab ? 1 : 0, row0, rows);
     OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
-    hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup);
+    hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup,
+                       ws.todo_idx);                                     // (the fan pass's list is free until the cells are done)
     OFL_HIP(hipGetLastError());
     OFL_TRY(scan_exclusive(ws.bstart, ws.bcap + 1, ws.scan_tmp, s));
     hipLaunchKernelGGL(dl_fill_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
-                       (const unsigned *)ws.bstart, ws.nbr, ws.sorted, (const unsigned char *)ws.dup);
+                       (const unsigned *)ws.bstart, (const unsigned *)ws.todo_idx, ws.sorted, (const unsigned char *)ws.dup);
     hipLaunchKernelGGL(dl_sort_kernel, dim3(std::min<unsigned>((unsigned)((ws.bcap + 255) / 256), 65535u)), dim3(256), 0, s,
                        (const DlHead *)ws.head, 0, (const unsigned *)ws.bstart, ws.sorted);
     hipLaunchKernelGGL(dl_list_xy_kernel<0>, dim3(std::min<unsigned>(nblk, 65535u)), dim3(256), 0, s, flow, sign_pp, W, (const DlHead *)ws.head,
@@ -2176,29 +2339,27 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
                            ws.dup, (unsigned *)ws.pool, (unsigned long long)ws.pool_cap, n, flow, sign_pp, W);
     }
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
-    unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
+    OFL_HIP(hipMemsetAsync(ws.cstate + 2 * ws.cstride, 0, 2 * ws.cstride * 4, s));      // tickets and tile words of the two compactions below
     // mesh cells (one verification per triangle), the sites they settle, then the fans of the rest (compacted in index order)
     {
+        const unsigned sblk = (unsigned)((n / fan_sample_stride(n) + 1 + 255) / 256);
+        hipLaunchKernelGGL(dl_cell_sample_kernel, dim3(sblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head, (const unsigned *)ws.bstart,
+                           (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned char *)ws.dup);
         const int ctx = (W + 31) / 32, cty = (H + 7) / 8;
         hipLaunchKernelGGL(dl_cell_kernel, dim3((unsigned)((ctx * cty + 7) / 8 * 8)), dim3(256), 0, s, flow, sign_pp, pmask, H, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
-                           (const unsigned char *)ws.dup, ws.cellflag, ctx, ctx * cty);
+                           (const unsigned char *)ws.dup, ws.cellflag, ws.tileflag, ctx, ctx * cty);
         hipLaunchKernelGGL(dl_site_cells_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head,
                            (const unsigned char *)ws.dup, (const unsigned char *)ws.cellflag, ws.deg, ws.nbr);
     }
-    hipLaunchKernelGGL(dl_fan_decide_kernel, dim3(1), dim3(1024), 0, s, pmask, (const unsigned char *)ws.dup, (const unsigned char *)ws.cellflag, H, W, ws.head);
-    hipLaunchKernelGGL(dl_flag_count_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
-    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_flag_write_kernel<2>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
-                       ws.todo_idx, fblk - 1, (unsigned *)nullptr);
+    hipLaunchKernelGGL(dl_compact_kernel<2>, dim3((fblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n,
+                       ws.cstate + 2 * ws.cstride, ws.todo_idx, (unsigned *)nullptr);
     hipLaunchKernelGGL(dl_star_fan_kernel, dim3(std::min<unsigned>((unsigned)((n + kFanBlock - 1) / kFanBlock), 16384u)), dim3(kFanBlock), 0, s, flow, sign_pp, pmask, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.todo_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy,
                        (const unsigned char *)ws.dup, ws.deg, ws.nbr);
     // what cells and fans did not settle, in index order, for the clip pass
-    hipLaunchKernelGGL(dl_flag_count_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
-    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_flag_write_kernel<3>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
-                       ws.far_idx, fblk - 1, (unsigned *)nullptr);           // (far_idx is free until the unfinished points are listed)
+    hipLaunchKernelGGL(dl_compact_kernel<3>, dim3((fblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n,
+                       ws.cstate + 3 * ws.cstride, ws.far_idx, (unsigned *)nullptr);           // (far_idx is free until the unfinished points are listed)
     hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
                        (const P2 *)ws.sorted_xy, ws.deg, ws.nbr);
@@ -2216,13 +2377,11 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
     const size_t n = (size_t)H * W;
     const unsigned nblk = (unsigned)((n + 255) / 256);
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
-    unsigned *fcnt = ws.far_off;                                         // scratch until the cooperative passes write it
     static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
     // unfinished points in index order
-    hipLaunchKernelGGL(dl_flag_count_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, (const DlHead *)ws.head, n, fcnt);
-    OFL_TRY(scan_exclusive(fcnt, fblk, ws.scan_tmp, s));
-    hipLaunchKernelGGL(dl_flag_write_kernel<0>, dim3(fblk), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n, (const unsigned *)fcnt,
-                       ws.far_idx, fblk - 1, ws.nbr);
+    OFL_HIP(hipMemsetAsync(ws.cstate, 0, 2 * ws.cstride * 4, s));
+    hipLaunchKernelGGL(dl_compact_kernel<0>, dim3((fblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n,
+                       ws.cstate, ws.far_idx, ws.nbr);
     OFL_HIP(hipGetLastError());
     // From here on every launch is sized on the device: fixed grids walk the unfinished points, whose numbers stay in the
     // header.  Nothing is read back unless the caller asks for the counts (info_host) -- then ONE read-back at the end,
@@ -2254,15 +2413,12 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned char *)ws.deg, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
                            (unsigned long long)ws.pool_cap, ws.far_wide);
         OFL_HIP(hipGetLastError());
-        unsigned *lcnt = (unsigned *)ws.big;                             // the large-triangle list is empty until the raster passes
-        hipLaunchKernelGGL(dl_flag_count_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, (const unsigned char *)ws.far_wide, (const DlHead *)ws.head, (size_t)0, lcnt);
-        OFL_TRY(scan_exclusive(lcnt, fblk, ws.scan_tmp, s));
-        hipLaunchKernelGGL(dl_flag_write_kernel<1>, dim3(fblk), dim3(256), 0, s, (const void *)ws.far_deg, (const unsigned char *)ws.far_wide, ws.head, (size_t)0,
-                           (const unsigned *)lcnt, ws.left_idx, fblk - 1, (unsigned *)nullptr);
+        hipLaunchKernelGGL(dl_compact_kernel<1>, dim3((fblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.far_deg, (const unsigned char *)ws.far_wide, ws.head, (size_t)0,
+                           ws.cstate + ws.cstride, ws.left_idx, (unsigned *)nullptr);
         hipLaunchKernelGGL(dl_list_xy_kernel<2>, dim3(rblk), dim3(256), 0, s, flow, sign_pp, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.left_idx, (const unsigned *)ws.far_idx, ws.left_xy, ws.left_pt);
         hipLaunchKernelGGL(dl_left_box_kernel, dim3(rblk), dim3(256), 0, s, (const DlHead *)ws.head, W, (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, ws.left_box);
-        hipLaunchKernelGGL((dl_star_far_kernel<384, 64>), dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
+        hipLaunchKernelGGL((dl_star_far_kernel<OFL_FAR_CAP, 64>), dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned *)ws.left_idx,
                            (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
@@ -2273,6 +2429,10 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
                            (const unsigned *)ws.left_pt, (const P2 *)ws.left_xy, (const double *)ws.left_box, (const unsigned *)ws.nbr,
                            ws.far_deg, ws.far_off, ws.pool, (unsigned long long)ws.pool_cap);
         OFL_HIP(hipGetLastError());
+    }
+    {
+        const int ctx = (W + 31) / 32, cty = (H + 7) / 8;
+        hipLaunchKernelGGL(dl_raster_cells_kernel, dim3((unsigned)((ctx * cty + 7) / 8 * 8)), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base, ctx, ctx * cty);
     }
     hipLaunchKernelGGL(dl_raster_small_kernel, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base,
                        OFL_KNOB_INT("OFL_DL_RASTER_BUCKET", 0));
@@ -2286,6 +2446,10 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
         OFL_HIP(hipStreamSynchronize(s));
         if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = h.n_left; }
         if (debug) fprintf(stderr, "[ofl exact] kept %u, fan pass %u, clip pass %u, unfinished %u, left over %u\n", h.kept, h.n_fan, h.n_todo, h.n_far, h.n_left);
+        if (debug && h.dbg[0]) fprintf(stderr, "[ofl exact] left-over pass: %u sites, per site %.1f chunks swept, %.1f clips before the sweep, %.1f clips in it, %.1f edges\n",
+                                       h.dbg[0], (double)h.dbg[1] / h.dbg[0], (double)h.dbg[2] / h.dbg[0], (double)h.dbg[3] / h.dbg[0], (double)h.dbg[4] / h.dbg[0]);
+        if (debug && h.dbg[0]) fprintf(stderr, "[ofl exact] left-over pass: most chunks swept by one site %u (of %u), sites with more than 12: %u, most clips of one site %u\n",
+                                       h.dbg[5], (h.n_left + 255) / 256, h.dbg[6], h.dbg[7]);
         if (!info_host) return OFL_OK;
         if (h.err) {
             // a capacity or degeneracy error leaves SOME stars rasterised: blank the owner map, so that the result is what

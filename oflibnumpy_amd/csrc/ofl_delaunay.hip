@@ -85,7 +85,8 @@ struct DlHead {                           // device header of the exact path (25
     double   need_lo, need_hi;                       // slab mode: only sites with need_lo <= y <= need_hi get a star from cells / fans / clip (else -inf, +inf)
     unsigned slab_stamp;                             // slab mode: slab_stamp_of(field, band) step 1 ran for (0: not a slab state)
     unsigned sample_all, sample_ok;                  // dl_cell_sample_kernel: sampled grid cells with four kept corners / of those, verified
-    unsigned pad[3];
+    unsigned n_raster;                               // sites the site-wise raster looks at (stars of 1 .. kSlots neighbours outside the clean tiles)
+    unsigned pad[2];
     unsigned dbg[8];                                 // experiments build: counters of the left-over pass (sites, chunks swept, steps, clips, seed/near/coarse clips)
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
@@ -117,7 +118,7 @@ struct DlWs {
     unsigned *left_pt;     // [N] their point indices
     double   *left_box;    // [N / 256 + 1][2][8] oriented boxes of the two image halves of 256 consecutive left-over points
     int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
-    unsigned *cstate;      // [4][cstride] ticket + tile words of the four ordered compactions (dl_compact_kernel)
+    unsigned *cstate;      // [5][cstride] ticket + tile words of the five ordered compactions (dl_compact_kernel)
     unsigned *big;         // [big_cap] triangle ids with a large bounding box
     uint32_t *owner;       // [H][W] (biased by the first row of the band)
     size_t    bcap, b1cap, pool_cap, big_cap, cstride;
@@ -839,6 +840,19 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
     }
 }
 
+// Is grid site (x, y) CLEAN: do the four cells around it, and the four cells around each of its grid neighbours NW, N, NE and W
+// (the only ones with a smaller index), all lie in clean tiles (dl_cell_kernel: every cell of the 32 x 8 tile verified)?  Then
+// its star and theirs were written from cell flags (dl_site_cells_kernel; ofl_dl::star_from_cells: E, SE?, S, SW?, W, NW?, N,
+// NE?), every triangle it lists is a triangle of a verified cell and is owned by a site whose star lists it: the triangles a
+// clean site OWNS are drawn cell by cell (dl_raster_cells_kernel) with the ids the site-wise raster would give them, and that
+// raster has nothing to do for a clean site.  The cells in question are [x - 2, x + 1] x [y - 2, y]: at most four tiles.
+__device__ __forceinline__ bool site_clean(const unsigned char *__restrict__ tileflag, int x, int y, int W, int H, int tiles_x)
+{
+    if (x < 2 || y < 2 || x > W - 3 || y > H - 2) return false;
+    const int tx0 = (x - 2) >> 5, tx1 = (x + 1) >> 5, ty0 = (y - 2) >> 3, ty1 = y >> 3;
+    return tileflag[ty0 * tiles_x + tx0] && tileflag[ty0 * tiles_x + tx1] && tileflag[ty1 * tiles_x + tx0] && tileflag[ty1 * tiles_x + tx1];
+}
+
 // compaction in ascending order: MODE 0 = points with deg == kDegFar -> far_idx, MODE 1 = ranks with far_deg == kDegLeft -> left_idx,
 // MODE 2 = points with deg == kDegFan -> todo_idx (what the cell pass left to the fan pass),
 // MODE 3 = points with deg == kDegTodo -> the clip pass's list (a list in BUCKET order -- entries of `sorted` -- was measured:
@@ -849,7 +863,7 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
 // the flags of the eight elements [base, base + 8) as bits (base a multiple of 8; elements at or beyond n are not flagged):
 // one 8-byte load of the degree bytes -- or two 16-byte loads of the ranks' words and one 8-byte load of `aux`
 template <int MODE>
-__device__ __forceinline__ unsigned flagged8(const void *src, const unsigned char *aux, size_t base, size_t n);
+__device__ __forceinline__ unsigned flagged8(const void *src, const unsigned char *aux, size_t base, size_t n, int W, int H);
 
 template <int MODE>
 __device__ __forceinline__ bool flagged(const void *src, const unsigned char *aux, size_t i)
@@ -868,9 +882,32 @@ __device__ __forceinline__ bool flagged(const void *src, const unsigned char *au
 // together each walked back over all the others (65 us per list; the three-kernel count / scan / write it replaced: 27 us).
 // state[0] = the ticket counter, state[4 + t] = tile t's word; zeroed by the caller.
 template <int MODE>
-__device__ __forceinline__ unsigned flagged8(const void *src, const unsigned char *aux, size_t base, size_t n)
+__device__ __forceinline__ unsigned flagged8(const void *src, const unsigned char *aux, size_t base, size_t n, int W, int H)
 {
     unsigned bits = 0;
+    if (MODE == 4) {
+        // MODE 4: the sites the site-wise raster has to look at -- a star of 1 .. kSlots neighbours, and not clean (aux = the
+        // tile flags): the clean ones are drawn cell by cell
+        if (base >= n) return 0u;
+        const uint2 w = base + 8 <= n ? *reinterpret_cast<const uint2 *>((const unsigned char *)src + base) : make_uint2(0u, 0u);
+        int y = (int)((float)base / (float)W);
+        int x = (int)((long long)base - (long long)y * W);
+        while (x < 0) { --y; x += W; }
+        while (x >= W) { ++y; x -= W; }
+        const int tiles_x = (W + 31) / 32;
+        // (eight sites of one row whose cells all lie in clean tiles: nothing to list -- four bytes instead of thirty-two)
+        if (x + 7 < W && x >= 2 && y >= 2 && x + 7 <= W - 3 && y <= H - 2) {
+            const int tx0 = (x - 2) >> 5, tx1 = (x + 8) >> 5, ty0 = (y - 2) >> 3, ty1 = y >> 3;
+            if (aux[ty0 * tiles_x + tx0] && aux[ty0 * tiles_x + tx1] && aux[ty1 * tiles_x + tx0] && aux[ty1 * tiles_x + tx1]) return 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned d = base + 8 <= n ? (((k < 4 ? w.x : w.y) >> (8 * (k & 3))) & 0xFFu) : (base + k < n ? ((const unsigned char *)src)[base + k] : 0u);
+            if (d >= 1u && d <= (unsigned)kSlots && !site_clean(aux, x, y, W, H, tiles_x)) bits |= 1u << k;
+            if (++x == W) { x = 0; ++y; }
+        }
+        return bits;
+    }
     if (base + 8 <= n) {
         if (MODE != 1) {
             const unsigned char want = MODE == 3 ? kDegTodo : (MODE == 0 ? kDegFar : kDegFan);
@@ -895,7 +932,7 @@ constexpr int kCompactTiles = 16;
 template <int MODE>
 __global__ __launch_bounds__(256)
 void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__restrict__ aux, DlHead *head, size_t n_fixed,
-                       unsigned *__restrict__ state, unsigned *__restrict__ list, unsigned *__restrict__ rank_of)
+                       unsigned *__restrict__ state, unsigned *__restrict__ list, unsigned *__restrict__ rank_of, int W = 0, int H = 0)
 {
     __shared__ unsigned s_tile, s_prefix;
     if (threadIdx.x == 0) s_tile = atomicAdd(&state[0], 1u);
@@ -904,9 +941,12 @@ void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__rest
     const size_t n = MODE != 1 ? n_fixed : head->n_far;
     const size_t base0 = (size_t)tile * kCompactTiles * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
+    unsigned keep[kCompactTiles / 4];                     // the flag bits of the thread's 16 x 8 elements: the second walk does not evaluate them again
 #pragma unroll
     for (int c = 0; c < kCompactTiles; ++c) {
-        v += (unsigned)__popc(flagged8<MODE>(src, aux, base0 + (size_t)c * kScanChunk, n));
+        const unsigned b8 = flagged8<MODE>(src, aux, base0 + (size_t)c * kScanChunk, n, W, H);
+        v += (unsigned)__popc(b8);
+        if ((c & 3) == 0) keep[c >> 2] = b8; else keep[c >> 2] |= b8 << (8 * (c & 3));
     }
     unsigned total;
     (void)block_exscan(v, total);
@@ -939,10 +979,11 @@ void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__rest
     }
     __syncthreads();
     unsigned run = s_prefix;
+#pragma unroll
     for (int c = 0; c < kCompactTiles; ++c) {
         const size_t base = base0 + (size_t)c * kScanChunk;
         if (base - (size_t)threadIdx.x * 8 >= n) break;        // (uniform: the whole chunk lies beyond the end)
-        const unsigned bits = flagged8<MODE>(src, aux, base, n), cv = (unsigned)__popc(bits);
+        const unsigned bits = (keep[c >> 2] >> (8 * (c & 3))) & 0xFFu, cv = (unsigned)__popc(bits);
         unsigned ctotal;
         unsigned at = run + block_exscan(cv, ctotal);
         run += ctotal;
@@ -961,7 +1002,8 @@ void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__rest
         }
         if ((MODE == 0 && cnt > kMaxFar) || (MODE == 1 && cnt > kMaxLeft)) { atomicOr(&head->err, kErrDegenerate); cnt = 0; }
         if (head->err & kErrDegenerate) cnt = 0;           // a degenerate point set: no star pass runs (their loops are sized for ordinary buckets)
-        if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else if (MODE == 2) head->n_fan = cnt; else head->n_todo = cnt;
+        if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else if (MODE == 2) head->n_fan = cnt;
+        else if (MODE == 3) head->n_todo = cnt; else head->n_raster = cnt;
     }
 }
 
@@ -1722,19 +1764,6 @@ __device__ __forceinline__ void raster_tri(unsigned id, const D2 &q0, const D2 &
     // registers and code slow every field down by 4 - 10 %, config 5 included)
 }
 
-// Is grid site (x, y) CLEAN: do the four cells around it, and the four cells around each of its grid neighbours NW, N, NE and W
-// (the only ones with a smaller index), all lie in clean tiles (dl_cell_kernel: every cell of the 32 x 8 tile verified)?  Then
-// its star and theirs were written from cell flags (dl_site_cells_kernel; ofl_dl::star_from_cells: E, SE?, S, SW?, W, NW?, N,
-// NE?), every triangle it lists is a triangle of a verified cell and is owned by a site whose star lists it: the triangles a
-// clean site OWNS are drawn cell by cell (dl_raster_cells_kernel) with the ids the site-wise raster would give them, and that
-// raster has nothing to do for a clean site.  The cells in question are [x - 2, x + 1] x [y - 2, y]: at most four tiles.
-__device__ __forceinline__ bool site_clean(const unsigned char *__restrict__ tileflag, int x, int y, int W, int H, int tiles_x)
-{
-    if (x < 2 || y < 2 || x > W - 3 || y > H - 2) return false;
-    const int tx0 = (x - 2) >> 5, tx1 = (x + 1) >> 5, ty0 = (y - 2) >> 3, ty1 = y >> 3;
-    return tileflag[ty0 * tiles_x + tx0] && tileflag[ty0 * tiles_x + tx1] && tileflag[ty1 * tiles_x + tx0] && tileflag[ty1 * tiles_x + tx1];
-}
-
 // one triangle of a star by one thread.  Every triangle is listed by
 // each of its three sites; the copy of the site with the smallest index is the one that is drawn -- unless that
 // site's star does not list the triangle (stars that disagree on a co-circular cell), in which case this copy is drawn too.
@@ -1791,46 +1820,45 @@ void dl_raster_cells_kernel(const float *__restrict__ flow, int sign, int H, int
 }
 
 __global__ __launch_bounds__(256)
-void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base, int by_bucket)
+void dl_raster_small_kernel(const float *__restrict__ flow, int sign, int H, int W, DlWs ws, unsigned far_base, const unsigned *__restrict__ list)
 {
-    // workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the field, so that the neighbour
+    // The sites that are not clean, compacted in index order (dl_compact_kernel<4>): on a field with a few tears or holes they
+    // are the rims -- one or two sites of 64 -- and a wave that also held the 62 clean ones ran as long as its rim sites took
+    // (64-px stripes at 4K: 0.93 ms, every wave crossing a tear).
+    // Workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the list, so that the neighbour
     // rows a point looks up (the stars of the sites above and below it) are in ITS L2
     // (a row band draws from the sites around its rows only -- often one contiguous stretch of indices, which that mapping
     // would hand to a single XCD: 3.1 ms instead of 0.5 for an eighth of config 5 -- so bands keep the round-robin order)
-    const unsigned nb = gridDim.x, per = (nb + 7) / 8;
-    const unsigned blk = ws.oy1 - ws.oy0 < H ? blockIdx.x : (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if (blk >= nb) return;
-    size_t p = (size_t)blk * 256 + threadIdx.x;
-    if (p >= (size_t)H * W) return;
-    if (by_bucket) {                                           // (experiments build) sites in bucket order instead of index order
-        const unsigned c = ws.sorted[p];
-        if (c == 0xFFFFFFFFu) return;
-        p = c;
-    }
-    const unsigned d = ws.deg[p];
-    if (d == 0 || d > kSlots) return;
-    // which of this site and its four smaller-index grid neighbours were settled from the cell flags (three dword loads)
-    unsigned trust = 0;
-    {
-        const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
-        if (site_clean(ws.tileflag, x, y, W, H, (W + 31) / 32)) return;      // everything this site lists is drawn cell by cell (dl_raster_cells_kernel)
-        if (x >= 2 && y >= 2 && x <= W - 3 && y <= H - 2) {
-            const unsigned char *f = ws.cellflag + (size_t)(y - 2) * W + (x - 2);
-            struct __attribute__((packed, aligned(1))) U32u { unsigned v; };
-            const unsigned r0 = reinterpret_cast<const U32u *>(f)->v, r1 = reinterpret_cast<const U32u *>(f + W)->v,
-                           r2 = reinterpret_cast<const U32u *>(f + 2 * (size_t)W)->v;
-            auto nz = [](unsigned r, int k) { return ((r >> (8 * k)) & 0xFFu) != 0u; };
-            if (nz(r2, 2) && nz(r2, 1) && nz(r1, 1) && nz(r1, 2)) {
-                trust = 1u;
-                if (nz(r1, 1) && nz(r1, 0) && nz(r0, 0) && nz(r0, 1)) trust |= 2u;       // NW
-                if (nz(r1, 2) && nz(r1, 1) && nz(r0, 1) && nz(r0, 2)) trust |= 4u;       // N
-                if (nz(r1, 3) && nz(r1, 2) && nz(r0, 2) && nz(r0, 3)) trust |= 8u;       // NE
-                if (nz(r2, 1) && nz(r2, 0) && nz(r1, 0) && nz(r1, 1)) trust |= 16u;      // W
+    const unsigned n_list = ws.head->n_raster;
+    const unsigned nb = (n_list + 255u) / 256u, per = (nb + 7u) / 8u;
+    const PosFn pos(flow, sign, W);
+    for (unsigned blk0 = blockIdx.x; blk0 < per * 8u; blk0 += gridDim.x) {
+        const unsigned blk = ws.oy1 - ws.oy0 < H ? blk0 : (blk0 & 7u) * per + (blk0 >> 3);
+        const unsigned i = blk * 256u + threadIdx.x;
+        if (blk >= nb || i >= n_list) continue;
+        const size_t p = list[i];
+        const unsigned d = ws.deg[p];
+        // which of this site and its four smaller-index grid neighbours were settled from the cell flags (three dword loads)
+        unsigned trust = 0;
+        {
+            const int y = (int)(p / (unsigned)W), x = (int)(p - (size_t)y * W);
+            if (x >= 2 && y >= 2 && x <= W - 3 && y <= H - 2) {
+                const unsigned char *f = ws.cellflag + (size_t)(y - 2) * W + (x - 2);
+                struct __attribute__((packed, aligned(1))) U32u { unsigned v; };
+                const unsigned r0 = reinterpret_cast<const U32u *>(f)->v, r1 = reinterpret_cast<const U32u *>(f + W)->v,
+                               r2 = reinterpret_cast<const U32u *>(f + 2 * (size_t)W)->v;
+                auto nz = [](unsigned r, int k) { return ((r >> (8 * k)) & 0xFFu) != 0u; };
+                if (nz(r2, 2) && nz(r2, 1) && nz(r1, 1) && nz(r1, 2)) {
+                    trust = 1u;
+                    if (nz(r1, 1) && nz(r1, 0) && nz(r0, 0) && nz(r0, 1)) trust |= 2u;       // NW
+                    if (nz(r1, 2) && nz(r1, 1) && nz(r0, 1) && nz(r0, 2)) trust |= 4u;       // N
+                    if (nz(r1, 3) && nz(r1, 2) && nz(r0, 2) && nz(r0, 3)) trust |= 8u;       // NE
+                    if (nz(r2, 1) && nz(r2, 0) && nz(r1, 0) && nz(r1, 1)) trust |= 16u;      // W
+                }
             }
         }
+        for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, (unsigned)p, pos, H, W, ws, far_base, trust);
     }
-    const PosFn pos(flow, sign, W);
-    for (unsigned k = 0; k < d; ++k) thread_raster((unsigned)p * kSlots + k, (unsigned)p, pos, H, W, ws, far_base, trust);
 }
 
 // one WAVE per unfinished point (their stars run to hundreds of triangles: a thread per point would crawl)
@@ -2247,7 +2275,7 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.left_box = (double *)p;              p += align_up((n / 256 + 1) * 128, 256);
     ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
     ws.cstride = align_up((n + kScanChunk - 1) / kScanChunk + 4, 64);
-    ws.cstate = (unsigned *)p;              p += align_up(4 * ws.cstride * 4, 256);
+    ws.cstate = (unsigned *)p;              p += align_up(5 * ws.cstride * 4, 256);
     ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
     ws.oy0 = 0; ws.oy1 = H;
@@ -2380,6 +2408,7 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
     static const bool debug = OFL_KNOB_SET("OFL_DL_DEBUG");                      // development aid (experiments build only)
     // unfinished points in index order
     OFL_HIP(hipMemsetAsync(ws.cstate, 0, 2 * ws.cstride * 4, s));
+    OFL_HIP(hipMemsetAsync(ws.cstate + 4 * ws.cstride, 0, ws.cstride * 4, s));
     hipLaunchKernelGGL(dl_compact_kernel<0>, dim3((fblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n,
                        ws.cstate, ws.far_idx, ws.nbr);
     OFL_HIP(hipGetLastError());
@@ -2434,8 +2463,10 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
         const int ctx = (W + 31) / 32, cty = (H + 7) / 8;
         hipLaunchKernelGGL(dl_raster_cells_kernel, dim3((unsigned)((ctx * cty + 7) / 8 * 8)), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base, ctx, ctx * cty);
     }
-    hipLaunchKernelGGL(dl_raster_small_kernel, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base,
-                       OFL_KNOB_INT("OFL_DL_RASTER_BUCKET", 0));
+    hipLaunchKernelGGL(dl_compact_kernel<4>, dim3((fblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)ws.tileflag, ws.head, n,
+                       ws.cstate + 4 * ws.cstride, ws.todo_idx, (unsigned *)nullptr, W, H);     // (the fan pass's list is free again)
+    hipLaunchKernelGGL(dl_raster_small_kernel, dim3(std::min<unsigned>((nblk + 7) / 8 * 8, 32768u)), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base,
+                       (const unsigned *)ws.todo_idx);
     hipLaunchKernelGGL(dl_raster_far_kernel, dim3(std::min<unsigned>(walk, 4096u)), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     hipLaunchKernelGGL(dl_raster_big_kernel, dim3((unsigned)rt().n_cu * 4), dim3(256), 0, s, flow, sign_pp, H, W, ws, (unsigned)far_base);
     far_base_out = (unsigned)far_base;

@@ -25,6 +25,10 @@
 // Everything is a pure function of the inputs (buckets are sorted by point index, far points are compacted in
 // index order, triangle ids derive from point indices), so row bands concatenate to the full result bit for bit.
 #include "ofl_scatter_dev.h"
+#ifdef OFL_EXPERIMENTS
+__device__ unsigned long long dl_dbg_counters[8];      // development counters of the geometry core (experiments build, OFL_DL_DEBUG prints them)
+#define DL_DBG(i, v) atomicAdd(&dl_dbg_counters[i], (unsigned long long)(v))
+#endif
 #include "ofl_delaunay_core.h"
 #include <algorithm>
 #include <limits>
@@ -62,9 +66,7 @@ constexpr unsigned char kDegTodo = 0xFE;  // not settled by the mesh-fan pass: t
 constexpr unsigned char kDegFan = 0xFD;   // not settled by the mesh-cell pass: the fan pass looks at this site
 constexpr int      kFanSpan  = 6;        // buckets per axis a fan's circumcircles may span (wider: clip pass)
 constexpr int      kFanBlock = 128;
-constexpr unsigned kMaxBucket = 4096;     // entries beyond which a bucket counts as huge ...
-constexpr unsigned kMaxLiveHuge = 1u << 16;   // ... and the DISTINCT sites all huge buckets together may hold (more: the point set is degenerate)
-constexpr unsigned kDedupeSmall = 256;    // buckets up to this size drop their duplicates by pairwise comparison, larger ones through a hash table
+constexpr unsigned kDedupeSmall = 64;     // buckets up to this size drop their duplicates by pairwise comparison (quadratic, one thread), larger ones through a hash table
 constexpr unsigned kMaxFar   = 1u << 20;  // unfinished stars ...
 constexpr unsigned kMaxLeft  = 1u << 18;  // ... and stars for the workgroup pass (quadratic in their number) before the call gives up
 constexpr unsigned kErrDegenerate = 16u;  // err bit: one of the three limits above -- Qhull, too, refuses such input ("initial simplex is flat")
@@ -81,12 +83,13 @@ struct DlHead {                           // device header of the exact path (25
     unsigned n_fan;                                  // points the mesh-cell pass left to the fan pass
     double   far_t2;                                 // squared distance beyond which a cell vertex counts as "far" (well outside the data)
     unsigned n_big;                                  // sorted entries that live in buckets of more than kDedupeSmall entries
-    unsigned live_huge;                              // distinct sites left in buckets of more than kMaxBucket entries
+    unsigned any_heavy;                              // some bucket holds more than kHeavy entries (else the heavy-bucket passes return at once)
     double   need_lo, need_hi;                       // slab mode: only sites with need_lo <= y <= need_hi get a star from cells / fans / clip (else -inf, +inf)
     unsigned slab_stamp;                             // slab mode: slab_stamp_of(field, band) step 1 ran for (0: not a slab state)
     unsigned sample_all, sample_ok;                  // dl_cell_sample_kernel: sampled grid cells with four kept corners / of those, verified
     unsigned n_raster;                               // sites the site-wise raster looks at (stars of 1 .. kSlots neighbours outside the clean tiles)
-    unsigned pad[2];
+    unsigned n_heavy;                                // buckets of more than kHeavy entries (dense clusters): they get grids of their own
+    unsigned sub_used;                               // words of DlWs::sub_start handed out to those grids
     unsigned dbg[8];                                 // experiments build: counters of the left-over pass (sites, chunks swept, steps, clips, seed/near/coarse clips)
 };
 static_assert(sizeof(DlHead) <= 256, "DlHead");
@@ -118,10 +121,13 @@ struct DlWs {
     unsigned *left_pt;     // [N] their point indices
     double   *left_box;    // [N / 256 + 1][2][8] oriented boxes of the two image halves of 256 consecutive left-over points
     int      *pool;        // [pool_cap] neighbour lists of the far points (negative: unbounded gap)
-    unsigned *cstate;      // [5][cstride] ticket + tile words of the five ordered compactions (dl_compact_kernel)
+    unsigned *cstate;      // [6][cstride] ticket + tile words of the ordered compactions (dl_compact_kernel)
+    unsigned *heavy_bucket; // [heavy_cap] numbers of the buckets of more than kHeavy entries, ascending
+    SubGrid  *heavy_info;  // [heavy_cap] their grids
+    unsigned *sub_start;   // [sub_cap] cell starts of those grids (absolute positions in `sorted`)
     unsigned *big;         // [big_cap] triangle ids with a large bounding box
     uint32_t *owner;       // [H][W] (biased by the first row of the band)
-    size_t    bcap, b1cap, pool_cap, big_cap, cstride;
+    size_t    bcap, b1cap, pool_cap, big_cap, cstride, heavy_cap, sub_cap;
     int       oy0, oy1;
 };
 
@@ -424,7 +430,9 @@ void dl_sort_kernel(const DlHead *__restrict__ head, int coarse, const unsigned 
     const size_t nb = coarse ? (size_t)head->grid1.gx * head->grid1.gy : (size_t)head->grid.gx * head->grid.gy;
     for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
         const unsigned lo = bstart[b], hi = bstart[b + 1];
-        if (hi - lo < 2 || hi - lo > 256) continue;                 // (a bucket of hundreds of coincident points keeps its fill order)
+        // (a heavy bucket of the fine grid keeps its fill order here: dl_sub_bin_kernel re-orders it cell by cell, every cell by
+        // index, whatever order it finds; a coarse bucket of more than 256 unfinished sites keeps its fill order)
+        if (hi - lo < 2 || hi - lo > (coarse ? 256u : kHeavy)) continue;
         for (unsigned i = lo + 1; i < hi; ++i) {
             const unsigned v = sorted[i];
             unsigned j = i;
@@ -519,6 +527,7 @@ void dl_dedupe_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bs
     for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
         const unsigned lo = bstart[b], hi = bstart[b + 1];
         if (hi - lo > kDedupeSmall) atomicAdd(&head->n_big, hi - lo);     // rare: dl_big_* below take these buckets
+        if (hi - lo > kHeavy) head->any_heavy = 1u;                       // rare: dl_sub_bin_kernel gives these buckets grids of their own
         if (hi - lo < 2 || hi - lo > kDedupeSmall) continue;
         for (unsigned j = lo + 1; j < hi; ++j) {
             const P2 q = sorted_xy[j];
@@ -590,11 +599,94 @@ void dl_big_kernel(DlHead *__restrict__ head, const unsigned *__restrict__ bstar
                 const P2 o = pos((int)cur);
                 if (o.x == q.x && o.y == q.y) {
                     if (cur != c) { dup[c] = 1; sorted[j] = 0xFFFFFFFFu; }
-                    else if (cnt > kMaxBucket && atomicAdd(&head->live_huge, 1u) + 1u > kMaxLiveHuge) atomicOr(&head->err, kErrDegenerate);
                     break;
                 }
             }
         }
+    }
+}
+
+// A grid of its own for every heavy bucket (ofl_dl::SubGrid; the list of their numbers comes from dl_compact_kernel<5>): one
+// workgroup per bucket measures the bounding box of the bucket's entries, lays K x K cells over it -- K = ceil(sqrt(m / 2)),
+// at most 256 -- counts, scans and re-orders the bucket's stretch of `sorted` / `sorted_xy` cell by cell (through the scratch
+// arrays: entries move within [lo, hi) only) and sorts every cell by point index, so that the order of a cluster's sites --
+// and with it the order in which every star meets its neighbours -- does not depend on the order the fill pass happened to
+// leave (buckets of more than 256 entries keep their fill order in dl_sort_kernel).
+__global__ __launch_bounds__(256)
+void dl_sub_bin_kernel(DlHead *head, const unsigned *__restrict__ bstart, unsigned *__restrict__ sorted, P2 *__restrict__ sorted_xy,
+                       const unsigned *__restrict__ heavy_bucket, SubGrid *__restrict__ info, unsigned *__restrict__ sub_start,
+                       unsigned long long sub_cap, unsigned *__restrict__ tmp_idx, P2 *__restrict__ tmp_xy, unsigned *__restrict__ tmp_slot)
+{
+    __shared__ unsigned long long s_k[4];
+    __shared__ unsigned s_off, s_carry;
+    const int t = threadIdx.x;
+    const unsigned n_heavy = head->n_heavy;
+    for (unsigned h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        __syncthreads();
+        const size_t b = heavy_bucket[h];
+        const unsigned lo = bstart[b], hi = bstart[b + 1], m = hi - lo;
+        if (t < 4) s_k[t] = (t & 1) ? 0ull : ~0ull;            // ordered keys of xmin, xmax, ymin, ymax
+        __syncthreads();
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (unsigned j = lo + t; j < hi; j += 256) {
+            const P2 q = sorted_xy[j];
+            x0 = fmin(x0, q.x); x1 = fmax(x1, q.x); y0 = fmin(y0, q.y); y1 = fmax(y1, q.y);
+        }
+        if (x0 <= x1) { atomicMin(&s_k[0], okey(x0)); atomicMax(&s_k[1], okey(x1)); atomicMin(&s_k[2], okey(y0)); atomicMax(&s_k[3], okey(y1)); }
+        __syncthreads();
+        x0 = okey_inv(s_k[0]); x1 = okey_inv(s_k[1]); y0 = okey_inv(s_k[2]); y1 = okey_inv(s_k[3]);
+        int K = (int)ceil(sqrt(0.5 * (double)m));
+        K = K < 1 ? 1 : (K > 256 ? 256 : K);
+        double cs = fmax(x1 - x0, y1 - y0) / (double)K * 1.0000001;
+        if (!(cs > 0.0) || !isfinite(cs)) { K = 1; cs = 1.0; }   // (every entry on one spot: duplicates that were blanked, one live site)
+        Grid g;
+        g.ox = x0; g.oy = y0; g.s = cs; g.inv_s = 1.0 / cs; g.gx = K; g.gy = K;
+        const unsigned cells = (unsigned)(K * K);
+        if (t == 0) s_off = atomicAdd(&head->sub_used, cells + 1u);
+        __syncthreads();
+        const unsigned off = s_off;
+        if ((unsigned long long)off + cells + 1u > sub_cap) { if (t == 0) atomicOr(&head->err, kErrDegenerate); continue; }   // (cannot happen: DlWs::sub_cap)
+        unsigned *st = sub_start + off;
+        for (unsigned c = t; c <= cells; c += 256) st[c] = 0u;
+        __syncthreads();
+        for (unsigned j = lo + t; j < hi; j += 256) {
+            const P2 q = sorted_xy[j];
+            tmp_slot[j] = atomicAdd(&st[(unsigned)g.by(q.y) * (unsigned)K + (unsigned)g.bx(q.x)], 1u);
+        }
+        __syncthreads();
+        if (t == 0) s_carry = lo;
+        __syncthreads();
+        for (unsigned base = 0; base <= cells; base += 1024u) {       // counts -> absolute starts, in place
+            unsigned e[4], v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const unsigned i = base + 4u * t + k; e[k] = i <= cells ? st[i] : 0u; v += e[k]; }
+            unsigned total;
+            unsigned run = block_exscan(v, total) + s_carry;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const unsigned i = base + 4u * t + k; if (i <= cells) st[i] = run; run += e[k]; }
+            __syncthreads();
+            if (t == 0) s_carry += total;
+            __syncthreads();
+        }
+        for (unsigned j = lo + t; j < hi; j += 256) {
+            const P2 q = sorted_xy[j];
+            const unsigned dst = st[(unsigned)g.by(q.y) * (unsigned)K + (unsigned)g.bx(q.x)] + tmp_slot[j];
+            tmp_idx[dst] = sorted[j]; tmp_xy[dst] = q;
+        }
+        __syncthreads();
+        for (unsigned j = lo + t; j < hi; j += 256) { sorted[j] = tmp_idx[j]; sorted_xy[j] = tmp_xy[j]; }
+        __syncthreads();
+        for (unsigned c = t; c < cells; c += 256) {                   // every cell ascending by point index (blanked entries last)
+            const unsigned a = st[c], e = st[c + 1];
+            for (unsigned i = a + 1; i < e; ++i) {
+                const unsigned v = sorted[i];
+                const P2 q = sorted_xy[i];
+                unsigned j = i;
+                while (j > a && sorted[j - 1] > v) { sorted[j] = sorted[j - 1]; sorted_xy[j] = sorted_xy[j - 1]; --j; }
+                sorted[j] = v; sorted_xy[j] = q;
+            }
+        }
+        if (t == 0) { SubGrid sg; sg.g = g; sg.off = off; sg.pad = 0u; info[h] = sg; }
     }
 }
 
@@ -753,13 +845,16 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
                          const DlHead *__restrict__ head, const unsigned *__restrict__ todo,
                          const unsigned *__restrict__ bstart,
                          const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
-                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr)
+                         unsigned char *__restrict__ deg, unsigned *__restrict__ nbr,
+                         const unsigned *__restrict__ heavy_bucket, const SubGrid *__restrict__ heavy_info, const unsigned *__restrict__ sub_start)
 {
     __shared__ float s_vx[kNearCap][64], s_vy[kNearCap][64];
     __shared__ int   s_tag[kNearCap][64];
     const unsigned n_todo = head->n_todo;
     const Grid g = head->grid;
     const PosFn pos(flow, sign, W);
+    const SubGrids subs{ heavy_bucket, heavy_info, sub_start, head->n_heavy };       // (dense clusters: ofl_dl::apply_heavy_run)
+    const SubGrids *sub = subs.n ? &subs : nullptr;
     for (unsigned base = blockIdx.x * 64; base < n_todo; base += gridDim.x * 64) {
         if (base + threadIdx.x >= n_todo) return;
         const size_t p = todo[base + threadIdx.x];
@@ -786,7 +881,7 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
             return 0;
         };
         // (a tighter bound -- reach beyond 1 .. 16 times the ring search's own radius -- was measured: no further gain)
-        const int rc = star_near(P, (int)p, pp, g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings, &rings_done, rescue, 4.0 * head->far_t2);
+        const int rc = star_near(P, (int)p, pp, g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings, &rings_done, rescue, 4.0 * head->far_t2, sub);
         bool ok = rc == 1;
         for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
         if (!ok) {
@@ -815,7 +910,8 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
                           const unsigned *__restrict__ sorted, const P2 *__restrict__ sorted_xy,
                           const unsigned *__restrict__ b1start, const unsigned *__restrict__ sorted1_pt,
                           const P2 *__restrict__ sorted1_xy, unsigned char *__restrict__ deg, unsigned *__restrict__ nbr,
-                          unsigned *__restrict__ far_deg, unsigned char *__restrict__ far_wide, unsigned min_points)
+                          unsigned *__restrict__ far_deg, unsigned char *__restrict__ far_wide, unsigned min_points,
+                          const unsigned *__restrict__ heavy_bucket, const SubGrid *__restrict__ heavy_info, const unsigned *__restrict__ sub_start)
 {
     __shared__ float s_vx[kSlots][64], s_vy[kSlots][64];
     __shared__ int   s_tag[kSlots][64];
@@ -830,8 +926,9 @@ void dl_star_near2_kernel(const float *__restrict__ flow, int sign, int H, int W
     unsigned *row = nbr + (size_t)p * kSlots;
     const int ns = min((int)row[1], kSlots - 4);
     PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kSlots, 0 };
+    const SubGrids subs{ heavy_bucket, heavy_info, sub_start, head->n_heavy };
     const int rc = star_near2(P, p, pos(p), row + 2, ns, (int)row[14], kRings, g, bstart, sorted, sorted_xy,
-                              kNear2Rings, g1, b1start, sorted1_pt, sorted1_xy, pos, kNear2Open, 4.0 * head->far_t2);
+                              kNear2Rings, g1, b1start, sorted1_pt, sorted1_xy, pos, kNear2Open, 4.0 * head->far_t2, subs.n ? &subs : nullptr);
     if (rc != 1) continue;
     for (int k = 0; k < P.n; ++k) row[k] = (unsigned)P.T(k);
     deg[p] = (unsigned char)P.n;
@@ -868,6 +965,7 @@ __device__ __forceinline__ unsigned flagged8(const void *src, const unsigned cha
 template <int MODE>
 __device__ __forceinline__ bool flagged(const void *src, const unsigned char *aux, size_t i)
 {
+    if (MODE == 5) return ((const unsigned *)src)[i + 1] - ((const unsigned *)src)[i] > kHeavy;      // (src = bstart: a heavy bucket)
     if (MODE == 3) return ((const unsigned char *)src)[i] == kDegTodo;
     return MODE == 0 ? ((const unsigned char *)src)[i] == kDegFar
          : MODE == 2 ? ((const unsigned char *)src)[i] == kDegFan : (((const unsigned *)src)[i] == kDegLeft || aux[i] != 0);
@@ -908,6 +1006,18 @@ __device__ __forceinline__ unsigned flagged8(const void *src, const unsigned cha
         }
         return bits;
     }
+    if (MODE == 5) {
+        if (base + 8 <= n) {
+            const uint4 a = *reinterpret_cast<const uint4 *>((const unsigned *)src + base), b = *reinterpret_cast<const uint4 *>((const unsigned *)src + base + 4);
+            const unsigned e[9] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, ((const unsigned *)src)[base + 8] };
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (e[k + 1] - e[k] > kHeavy) bits |= 1u << k;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (base + k < n && flagged<5>(src, aux, base + k)) bits |= 1u << k;
+        }
+        return bits;
+    }
     if (base + 8 <= n) {
         if (MODE != 1) {
             const unsigned char want = MODE == 3 ? kDegTodo : (MODE == 0 ? kDegFar : kDegFan);
@@ -938,7 +1048,8 @@ void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__rest
     if (threadIdx.x == 0) s_tile = atomicAdd(&state[0], 1u);
     __syncthreads();
     const unsigned tile = s_tile;
-    const size_t n = MODE != 1 ? n_fixed : head->n_far;
+    // (MODE 5, the heavy buckets: nothing to look at unless the dedupe pass met one -- every tile then publishes an empty prefix)
+    const size_t n = MODE == 5 ? (head->any_heavy ? (size_t)head->grid.gx * head->grid.gy : 0) : (MODE != 1 ? n_fixed : head->n_far);
     const size_t base0 = (size_t)tile * kCompactTiles * kScanChunk + (size_t)threadIdx.x * 8;
     unsigned v = 0;
     unsigned keep[kCompactTiles / 4];                     // the flag bits of the thread's 16 x 8 elements: the second walk does not evaluate them again
@@ -991,7 +1102,8 @@ void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__rest
         for (int k = 0; k < 8; ++k)
             if ((bits >> k) & 1u) {
                 if (MODE == 0 && rank_of) rank_of[(base + k) * kSlots] = at;     // an unfinished point's first neighbour slot holds its rank
-                list[at++] = (unsigned)(base + k);
+                if (MODE != 5 || at < n_fixed) list[at] = (unsigned)(base + k);
+                ++at;
             }
     }
     if (tile == gridDim.x - 1 && threadIdx.x == 0) {
@@ -1002,8 +1114,9 @@ void dl_compact_kernel(const void *__restrict__ src, const unsigned char *__rest
         }
         if ((MODE == 0 && cnt > kMaxFar) || (MODE == 1 && cnt > kMaxLeft)) { atomicOr(&head->err, kErrDegenerate); cnt = 0; }
         if (head->err & kErrDegenerate) cnt = 0;           // a degenerate point set: no star pass runs (their loops are sized for ordinary buckets)
+        if (MODE == 5 && cnt > n_fixed) { atomicOr(&head->err, kErrDegenerate); cnt = 0; }       // (n_fixed: the capacity of the list; cannot happen by its bound)
         if (MODE == 0) head->n_far = cnt; else if (MODE == 1) head->n_left = cnt; else if (MODE == 2) head->n_fan = cnt;
-        else if (MODE == 3) head->n_todo = cnt; else head->n_raster = cnt;
+        else if (MODE == 3) head->n_todo = cnt; else if (MODE == 4) head->n_raster = cnt; else head->n_heavy = cnt;
     }
 }
 
@@ -2274,8 +2387,13 @@ DlWs carve_exact(void *base, int H, int W, size_t *total = nullptr)
     ws.left_pt = (unsigned *)p;             p += align_up(n * 4, 256);
     ws.left_box = (double *)p;              p += align_up((n / 256 + 1) * 128, 256);
     ws.pool = (int *)p;                     p += align_up(ws.pool_cap * 4, 256);
-    ws.cstride = align_up((n + kScanChunk - 1) / kScanChunk + 4, 64);
-    ws.cstate = (unsigned *)p;              p += align_up(5 * ws.cstride * 4, 256);
+    ws.cstride = align_up(std::max(n, ws.bcap) / kScanChunk + 5, 64);
+    ws.cstate = (unsigned *)p;              p += align_up(6 * ws.cstride * 4, 256);
+    ws.heavy_cap = n / kHeavy + 64;         // (a heavy bucket holds more than kHeavy of the n entries)
+    ws.sub_cap = n + ws.heavy_cap + 64;     // (a grid of K x K cells for m entries: K = ceil(sqrt(m / 2)), K * K + 1 <= m for m > kHeavy)
+    ws.heavy_bucket = (unsigned *)p;        p += align_up(ws.heavy_cap * 4, 256);
+    ws.heavy_info = (SubGrid *)p;           p += align_up(ws.heavy_cap * sizeof(SubGrid), 256);
+    ws.sub_start = (unsigned *)p;           p += align_up(ws.sub_cap * 4, 256);
     ws.big = (unsigned *)p;                 p += align_up(ws.big_cap * 4, 256);
     ws.owner = (uint32_t *)p;               p += align_up(n * 4, 256);
     ws.oy0 = 0; ws.oy1 = H;
@@ -2368,6 +2486,14 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
     }
     const unsigned fblk = (unsigned)((n + kScanChunk - 1) / kScanChunk);
     OFL_HIP(hipMemsetAsync(ws.cstate + 2 * ws.cstride, 0, 2 * ws.cstride * 4, s));      // tickets and tile words of the two compactions below
+    {   // dense clusters: the buckets of more than kHeavy entries get grids of their own (two launches that return at once without such a bucket)
+        OFL_HIP(hipMemsetAsync(ws.cstate + 5 * ws.cstride, 0, ws.cstride * 4, s));
+        const unsigned bblk = (unsigned)((ws.bcap + kScanChunk - 1) / kScanChunk);
+        hipLaunchKernelGGL(dl_compact_kernel<5>, dim3((bblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.bstart, (const unsigned char *)nullptr,
+                           ws.head, ws.heavy_cap, ws.cstate + 5 * ws.cstride, ws.heavy_bucket, (unsigned *)nullptr);
+        hipLaunchKernelGGL(dl_sub_bin_kernel, dim3(1024), dim3(256), 0, s, ws.head, (const unsigned *)ws.bstart, ws.sorted, ws.sorted_xy,
+                           (const unsigned *)ws.heavy_bucket, ws.heavy_info, ws.sub_start, (unsigned long long)ws.sub_cap, ws.far_off, ws.left_xy, ws.far_deg);
+    }
     // mesh cells (one verification per triangle), the sites they settle, then the fans of the rest (compacted in index order)
     {
         const unsigned sblk = (unsigned)((n / fan_sample_stride(n) + 1 + 255) / 256);
@@ -2390,7 +2516,7 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
                        ws.cstate + 3 * ws.cstride, ws.far_idx, (unsigned *)nullptr);           // (far_idx is free until the unfinished points are listed)
     hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
-                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr);
+                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr, (const unsigned *)ws.heavy_bucket, (const SubGrid *)ws.heavy_info, (const unsigned *)ws.sub_start);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }
@@ -2436,7 +2562,7 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
         hipLaunchKernelGGL(dl_star_near2_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 8192u)), dim3(64), 0, s, flow, sign_pp, H, W,
                            (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
                            (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start, (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy,
-                           ws.deg, ws.nbr, ws.far_deg, ws.far_wide, near2_min);
+                           ws.deg, ws.nbr, ws.far_deg, ws.far_wide, near2_min, (const unsigned *)ws.heavy_bucket, (const SubGrid *)ws.heavy_info, (const unsigned *)ws.sub_start);
         hipLaunchKernelGGL(dl_star_mid_kernel, dim3(walk), dim3(64), 0, s, flow, sign_pp, H, W, ws.head,
                            (const unsigned *)ws.bstart, (const unsigned *)ws.sorted, (const P2 *)ws.sorted_xy, (const unsigned *)ws.b1start,
                            (const unsigned *)ws.sorted1_pt, (const P2 *)ws.sorted1_xy, (const unsigned *)ws.far_idx, (const unsigned char *)ws.deg, (const unsigned *)ws.nbr, ws.far_deg, ws.far_off, ws.pool,
@@ -2477,6 +2603,15 @@ int exact_finish(const float *flow, int sign_pp, int H, int W, int row0, int row
         OFL_HIP(hipStreamSynchronize(s));
         if (info_host) { info_host[0] = h.kept; info_host[1] = h.n_far; info_host[2] = h.n_left; }
         if (debug) fprintf(stderr, "[ofl exact] kept %u, fan pass %u, clip pass %u, unfinished %u, left over %u\n", h.kept, h.n_fan, h.n_todo, h.n_far, h.n_left);
+#ifdef OFL_EXPERIMENTS
+        if (debug) {
+            unsigned long long c[8], z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(dl_dbg_counters), sizeof(c));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(dl_dbg_counters), z, sizeof(z));
+            fprintf(stderr, "[ofl exact] heavy buckets %u (grid words %u): heavy runs %llu, candidates scanned in them %llu, cells given up %llu, heavy buckets without a grid %llu, grid rows walked %llu; ordinary runs: %llu candidates, %llu clip tests\n",
+                    h.n_heavy, h.sub_used, c[0], c[1], c[2], c[3], c[5], c[6], c[7]);
+        }
+#endif
         if (debug && h.dbg[0]) fprintf(stderr, "[ofl exact] left-over pass: %u sites, per site %.1f chunks swept, %.1f clips before the sweep, %.1f clips in it, %.1f edges\n",
                                        h.dbg[0], (double)h.dbg[1] / h.dbg[0], (double)h.dbg[2] / h.dbg[0], (double)h.dbg[3] / h.dbg[0], (double)h.dbg[4] / h.dbg[0]);
         if (debug && h.dbg[0]) fprintf(stderr, "[ofl exact] left-over pass: most chunks swept by one site %u (of %u), sites with more than 12: %u, most clips of one site %u\n",

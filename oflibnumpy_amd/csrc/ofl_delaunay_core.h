@@ -25,6 +25,10 @@
 #define DL_HD inline
 #endif
 
+#ifndef DL_DBG
+#define DL_DBG(i, v)
+#endif
+
 namespace ofl_dl {
 
 struct P2 { double x, y; };
@@ -277,6 +281,106 @@ struct Grid {
     DL_HD int by(double y) const { const double f = floor((y - oy) * inv_s); return f < 0.0 ? 0 : (f >= (double)gy ? gy - 1 : (int)f); }
 };
 
+// Dense clusters of DISTINCT sites -- a flow that contracts a block of the image a hundredfold puts ten thousand sites into
+// each of a few buckets of the uniform grid (scipy's Qhull triangulates such a set like any other: src/oflibnumpy/utils.py:253).
+// Every bucket of more than kHeavy entries gets a grid of its own over the bounding box of its sites, about two sites per
+// cell, and its stretch of the sorted list is re-ordered cell by cell (dl_sub_bin_kernel).  A ring search that meets such a
+// bucket does not scan it: it walks the rings of the bucket's grid around the point of the box nearest to the site -- sites
+// in cells beyond ring r are at least r cell widths from that point, hence from the site -- until the reach of the cell
+// under construction is covered.
+constexpr unsigned kHeavy = 64;
+constexpr unsigned kHeavyBudget = 1024;    // sites of heavy buckets one thread looks at for one star before it hands the star on
+struct SubGrid  { Grid g; unsigned off, pad; };        // start[off .. off + gx * gy]: ABSOLUTE positions in the sorted list, cell by cell
+struct SubGrids { const unsigned *bucket; const SubGrid *info; const unsigned *start; unsigned n; };     // bucket[]: ascending bucket numbers
+
+DL_HD int find_heavy(const SubGrids &sub, unsigned bucket)
+{
+    unsigned lo = 0, hi = sub.n;
+    while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (sub.bucket[mid] < bucket) lo = mid + 1; else hi = mid; }
+    return lo < sub.n && sub.bucket[lo] == bucket ? (int)lo : -1;
+}
+
+// the candidates [lo, hi) of the sorted list, one after the other (the rare, compact form of apply_ring's inner loop)
+template <class PolyX, class PosFn>
+DL_HD int apply_range(PolyX &P, int p, const P2 &pp, unsigned lo, unsigned hi, const unsigned *sorted, const P2 *sorted_xy, PosFn pos, double &reach2)
+{
+    auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
+    DL_DBG(1, hi - lo);
+    for (unsigned j0 = lo; j0 < hi; j0 += 4) {
+        int c4[4];
+        P2  q4[4];                                           // four candidates' indices, then their positions, in flight together
+        for (int k = 0; k < 4; ++k) c4[k] = j0 + k < hi ? (int)sorted[j0 + k] : -1;
+        for (int k = 0; k < 4; ++k) q4[k] = c4[k] >= 0 ? (sorted_xy ? sorted_xy[j0 + k] : pos(c4[k])) : pp;
+        for (int k = 0; k < 4; ++k) {
+            const int c = c4[k];
+            if (c < 0 || c == p) continue;
+            const P2 C = { q4[k].x - pp.x, q4[k].y - pp.y };
+            const double d2 = C.x * C.x + C.y * C.y;
+            if (d2 == 0.0 || d2 >= reach2) continue;
+            const int rc = poly_clip(P, C, c, p, rel);
+            if (rc < 0) return -1;
+            if (rc > 0) reach2 = 4.0 * poly_rmax2(P);
+        }
+    }
+    return 0;
+}
+
+// the buckets x0 .. x1 of row `row`, heavy ones through their own grids; not inlined: the ordinary ring search must not grow by it
+template <class PolyX, class PosFn>
+#if defined(__HIPCC__)
+__host__ __device__ __noinline__
+#endif
+int apply_heavy_run(PolyX &P, int p, const P2 &pp, int row, int x0, int x1, const Grid &g, const unsigned *bstart,
+                    const unsigned *sorted, const P2 *sorted_xy, PosFn pos, double &reach2, const SubGrids &sub, unsigned *budget)
+{
+    const bool give_up = budget != nullptr;
+    DL_DBG(0, 1);
+    for (int bx = x0; bx <= x1; ++bx) {
+        const size_t b = (size_t)row * g.gx + bx;
+        const unsigned lo = bstart[b], hi = bstart[b + 1];
+        const int h = hi - lo > kHeavy ? find_heavy(sub, (unsigned)b) : -1;
+        if (hi - lo > kHeavy && h < 0) DL_DBG(3, 1);
+        if (h < 0) { if (apply_range(P, p, pp, lo, hi, sorted, sorted_xy, pos, reach2) < 0) return -1; continue; }
+        const SubGrid sg = sub.info[h];
+        const Grid &q = sg.g;
+        const unsigned *st = sub.start + sg.off;
+        // rings of the bucket's own grid around the point of its box nearest to the site
+        const double cx = fmin(fmax(pp.x, q.ox), q.ox + q.s * q.gx), cy = fmin(fmax(pp.y, q.oy), q.oy + q.s * q.gy);
+        const double d0 = (cx - pp.x) * (cx - pp.x) + (cy - pp.y) * (cy - pp.y);
+        if (d0 >= reach2) continue;                              // the whole box is out of reach
+        const int sx = q.bx(cx), sy = q.by(cy);
+        const int ax = sx > q.gx - 1 - sx ? sx : q.gx - 1 - sx, ay = sy > q.gy - 1 - sy ? sy : q.gy - 1 - sy;
+        const int rmax = ax > ay ? ax : ay;
+        for (int r = 0; r <= rmax; ++r) {
+            for (int yy = sy - r; yy <= sy + r; ++yy) {
+                DL_DBG(5, 1);
+                if (yy < 0 || yy >= q.gy) continue;
+                const bool full = yy == sy - r || yy == sy + r;
+                for (int part = 0; part < (full ? 1 : 2); ++part) {
+                    int u0 = full ? sx - r : (part ? sx + r : sx - r), u1 = full ? sx + r : u0;
+                    if (!full && (u0 < 0 || u0 >= q.gx)) continue;
+                    if (u0 < 0) u0 = 0;
+                    if (u1 > q.gx - 1) u1 = q.gx - 1;
+                    if (u1 < u0) continue;
+                    const unsigned c0 = st[(size_t)yy * q.gx + u0], c1 = st[(size_t)yy * q.gx + u1 + 1];
+                    if (apply_range(P, p, pp, c0, c1, sorted, sorted_xy, pos, reach2) < 0) return -1;
+                    if (give_up) *budget += c1 - c0;
+                }
+            }
+            const double cover = (double)r * q.s;
+            if (cover * cover >= reach2) break;           // (what lies beyond ring r is at least r cells from the box point, hence from the site)
+            // A site ON THE RIM of a cluster, or next to one: its cell reaches out into the sparse surroundings, every site of the
+            // cluster is within that reach -- ten thousand per bucket, each dragged through the vertex loop by ONE thread (a
+            // few hundred such sites made the clip pass of a 4K field with a 400 x 400 block contracted 100 times 0.4 s long) --
+            // and a rim cell does not close within the rings anyway.  A cell that has looked at more than kHeavyBudget sites
+            // of heavy buckets (an interior site of a cluster needs a few hundred) is given up (1: the caller hands it on
+            // unfinished, with the edges found so far as seeds): the cooperative passes scan clusters 64 sites at a time.
+            if (give_up && *budget > kHeavyBudget) { DL_DBG(2, 1); return 1; }
+        }
+    }
+    return 0;
+}
+
 // All sites of the buckets on the Chebyshev ring r around bucket (bx, by) are applied to the cell of site p (at pp).
 // Buckets are stored row-major and `sorted` lists the sites bucket by bucket, so a run of buckets in one row is ONE
 // contiguous range of `sorted`.  Returns -1 when the polygon overflows.
@@ -285,7 +389,9 @@ struct Grid {
 template <class PolyX, class PosFn>
 DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const Grid &g,
                      const unsigned *bstart, const unsigned *sorted, PosFn pos, double &reach2,
-                     const P2 *sorted_xy = nullptr)          // positions in `sorted` order (one contiguous read per run) or null
+                     const P2 *sorted_xy = nullptr,          // positions in `sorted` order (one contiguous read per run) or null
+                     const SubGrids *sub = nullptr,          // the grids of the heavy buckets of g (or null: every bucket is scanned)
+                     unsigned *budget = nullptr)             // counts the sites of heavy buckets looked at; non-null: may return 1 (given up, see apply_heavy_run)
 {
     auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
     // The ring as a sequence of runs -- top row, bottom row, then the two end buckets of the rows between -- walked by ONE
@@ -294,8 +400,8 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
     // loads per run off a thread's chain (measured: no change in the kernels' times -- PMC shows 87 000 vector instructions
     // per wave on the rim of a large hole: the few hundred waves such fields leave to this pass compute, they do not wait).
     const int nseg = r == 0 ? 1 : 2 + 2 * (2 * r - 1);
+    int row = 0, x0 = 0, x1 = -1;                        // the buckets of the run `bounds` looked up last
     auto bounds = [&](int seg, unsigned &lo, unsigned &hi) {
-        int row, x0, x1;
         if (r == 0) { row = by; x0 = bx; x1 = bx; }
         else if (seg == 0) { row = by - r; x0 = bx - r; x1 = bx + r; }
         else if (seg == 1) { row = by + r; x0 = bx - r; x1 = bx + r; }
@@ -313,8 +419,16 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
     unsigned lo, hi;
     bounds(0, lo, hi);
     for (int seg = 0; seg < nseg; ++seg) {
+        if (sub && sub->n && hi - lo > kHeavy) {
+            // (rare) a run that may hold a heavy bucket: bucket by bucket, heavy ones through their own grids
+            const int hr = apply_heavy_run(P, p, pp, row, x0, x1, g, bstart, sorted, sorted_xy, pos, reach2, *sub, budget);
+            if (hr != 0) return hr;                        // -1: overflow, 1: given up (the rim of a cluster)
+            if (seg + 1 < nseg) bounds(seg + 1, lo, hi);
+            continue;
+        }
         unsigned nlo = 0, nhi = 0;
         if (seg + 1 < nseg) bounds(seg + 1, nlo, nhi);
+        DL_DBG(6, hi - lo);
         for (unsigned j = lo; j < hi; j += 4) {
             // four candidates at a time: their indices, then their positions, are in flight together
             int c[4];
@@ -335,6 +449,7 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
                 const P2 C = { q[k].x - pp.x, q[k].y - pp.y };
                 const double d2 = C.x * C.x + C.y * C.y;
                 if (d2 == 0.0 || d2 >= reach2) continue;      // a duplicate of p (same cell), or too far to matter
+                DL_DBG(7, 1);
                 const int rc = poly_clip(P, C, c[k], p, rel);
                 if (rc < 0) return -1;
                 if (rc > 0) reach2 = 4.0 * poly_rmax2(P);
@@ -365,14 +480,18 @@ template <class PolyX, class PosFn, class RescueFn = NoRescue>
 DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
                     PosFn pos, int rings, const P2 *sorted_xy = nullptr, int open_rings = 1 << 30,
                     int *rings_done = nullptr,               // receives the last ring that was applied completely (-1: none)
-                    RescueFn rescue = RescueFn(), double open_reach2 = 1e300)
+                    RescueFn rescue = RescueFn(), double open_reach2 = 1e300,
+                    const SubGrids *sub = nullptr)           // the grids of g's heavy buckets (dense clusters), or null
 {
     poly_init(P);
     const int bx = g.bx(pp.x), by = g.by(pp.y);
     double reach2 = 4.0 * poly_rmax2(P);
     if (rings_done) *rings_done = -1;
+    unsigned heavy_seen = 0;
     for (int r = 0; r <= rings; ++r) {
-        if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy) < 0) return -1;
+        const int ar = apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy, sub, sub ? &heavy_seen : nullptr);
+        if (ar < 0) return -1;
+        if (ar > 0) return rescue(P) < 0 ? -1 : 0;         // the rim of a dense cluster: unfinished (ring r was not applied completely)
         if (rings_done) *rings_done = r;
         const double cover = (double)r * g.s;
         if (cover * cover >= reach2) return 1;
@@ -513,6 +632,7 @@ DL_HD int star_fan(int p, int W, const P2 &pp, unsigned kept8, PosFn pos, SlotPo
     if (cb1 - cb0 >= max_span || rb1 - rb0 >= max_span) return 0;
     for (int row = rb0; row <= rb1; ++row) {
         const unsigned lo = bstart[(size_t)row * g.gx + cb0], hi = bstart[(size_t)row * g.gx + cb1 + 1];
+        if (hi - lo > 4 * kHeavy) return 0;                      // a dense cluster under the circles: the clip pass (which searches such buckets by their own grids)
         for (unsigned j = lo; j < hi; ++j) {
             const P2 qa = sorted_xy ? sorted_xy[j] : pos((int)sorted[j]);
             const int qi = (int)sorted[j];
@@ -630,6 +750,7 @@ DL_HD int cell_verify(int ia, int W, const P2 &A, const P2 &B, const P2 &C, cons
     if (cb1 - cb0 >= max_span || rb1 - rb0 >= max_span) return 0;
     for (int row = rb0; row <= rb1; ++row) {
         const unsigned lo = bstart[(size_t)row * g.gx + cb0], hi = bstart[(size_t)row * g.gx + cb1 + 1];
+        if (hi - lo > 4 * kHeavy) return 0;                          // a dense cluster under the circles: left to the clip pass
         for (unsigned j = lo; j < hi; ++j) {
             const P2 qa = sorted_xy ? sorted_xy[j] : pos((int)sorted[j]);
             const P2 Cq = { qa.x - O.x, qa.y - O.y };
@@ -715,7 +836,7 @@ template <class PolyX, class PosFn>
 DL_HD int star_near2(PolyX &P, int p, const P2 &pp, const unsigned *seeds, int nseeds, int rings_done, int rings,
                      const Grid &g, const unsigned *bstart, const unsigned *sorted, const P2 *sorted_xy,
                      int rings1, const Grid &g1, const unsigned *b1start, const unsigned *sorted1, const P2 *sorted1_xy,
-                     PosFn pos, int open_rings1 = 1 << 30, double open_reach2 = 1e300)
+                     PosFn pos, int open_rings1 = 1 << 30, double open_reach2 = 1e300, const SubGrids *sub = nullptr)
 {
     auto rel = [&](int t) { const P2 q = pos(t); return P2{ q.x - pp.x, q.y - pp.y }; };
     if (!poly_from_tags(P, seeds, nseeds, rel)) {
@@ -748,7 +869,7 @@ DL_HD int star_near2(PolyX &P, int p, const P2 &pp, const unsigned *seeds, int n
     {
         const int bx = g.bx(pp.x), by = g.by(pp.y);
         for (int r = rings_done + 1; r <= rings; ++r)
-            if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy) < 0) return -1;
+            if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy, sub) < 0) return -1;
     }
     for (int k = 0; k < P.n; ++k) if (P.T(k) < 0) return 0;
     return 1;

@@ -9,6 +9,8 @@ def make_case(seed, hmax, wmax):
     h, w = int(rng.integers(4, hmax)), int(rng.integers(4, wmax))
     yy, xx = np.mgrid[:h, :w].astype(np.float32)
     kind = int(rng.integers(0, 6))
+    if seed % 1_000_000 >= 900_000:                                 # (seed ranges of their own -- tools/soak_scatter.py --cluster: the cases of all
+        kind = 6                                                    # other seeds, the regression seeds of tests/ among them, stay what they were)
     amp = float(rng.uniform(0.1, 6))
     vecs = np.stack([amp * np.sin(xx / rng.uniform(3, 40) + yy / rng.uniform(5, 50)) + rng.uniform(-0.2, 0.2) * yy,
                      amp * np.cos(xx / rng.uniform(4, 35) - yy / rng.uniform(6, 45)) + rng.uniform(-0.2, 0.2) * xx], -1).astype(np.float32)
@@ -41,6 +43,16 @@ def make_case(seed, hmax, wmax):
             tab = np.round(rng.uniform(-6, 6, (gy.max() + 1, gx.max() + 1, 2))).astype(np.float32)
             vecs = tab[gy, gx]
         vecs = np.ascontiguousarray(vecs, np.float32)
+    elif kind == 6:                                                 # a dense cluster of DISTINCT sites: a block contracted 5 .. 200 times
+        y0, x0 = int(rng.integers(0, max(h // 2, 1))), int(rng.integers(0, max(w // 2, 1)))
+        bh, bw = max(h // 2, 2), max(w // 2, 2)
+        f = float(np.exp(rng.uniform(np.log(5), np.log(200))))
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        sl = (slice(y0, y0 + bh), slice(x0, x0 + bw))
+        ys, xs = yy[sl], xx[sl]
+        rip = 1.0 + 0.05 * np.sin(xs / 5.3 + ys / 7.1)             # (no cell of the contracted lattice exactly co-circular)
+        vecs[sl + (0,)] = (cx + (xs - xs.mean()) / f * rip - xs).astype(np.float32)
+        vecs[sl + (1,)] = (cy + (ys - ys.mean()) / f * rip - ys).astype(np.float32)
     pm = None
     if rng.random() < 0.6:
         pm = rng.random((h, w)) > rng.uniform(0, 0.5)

@@ -479,6 +479,86 @@ def test_block_collapsed_onto_one_pixel_matches_scipy(gpu, oracle):
     np.testing.assert_array_equal(a, b)
 
 
+def contracted_block(shape, blk, factor, centre):
+    """background: a rotation + scaling with a ripple; the block `blk` of the grid contracted `factor` times around `centre`
+    (every site distinct, the contracted lattice rippled so that none of its cells is co-circular)"""
+    import oflibnumpy_amd as of
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float32)
+    vecs = of.from_transforms([['rotation', shape[1] * 0.47, shape[0] * 0.52, 7], ['scaling', shape[1] * 0.23, shape[0] * 0.42, 1.04]], list(shape), 's')
+    vecs = vecs + wobble(shape, 0.6, 0.5)
+    ys, xs = yy[blk].astype(np.float64), xx[blk].astype(np.float64)
+    rip = 1.0 + 0.05 * np.sin(xs / 5.3 + ys / 7.1)
+    vecs[blk + (0,)] = (centre[0] + (xs - xs.mean()) / factor * rip - xs).astype(np.float32)
+    vecs[blk + (1,)] = (centre[1] + (ys - ys.mean()) / factor * rip - ys).astype(np.float32)
+    return np.ascontiguousarray(vecs, np.float32)
+
+
+@pytest.mark.parametrize("factor", [20.0, 100.0])
+def test_dense_clusters_of_distinct_sites_match_scipy(gpu, oracle, factor):
+    """A flow that CONTRACTS a 60 x 60 block of a 96 x 128 image 20 or 100 times puts 3 600 distinct sites into nine buckets -- or
+    one -- of the uniform grid; scipy's griddata (utils.py:253) triangulates them like any other point set.  Buckets of more
+    than 64 entries get grids of their own (dl_sub_bin_kernel; ofl_dl::apply_heavy_run) instead of counting against a limit:
+    masks bit-exact, values within 1e-4 wherever SciPy's triangulation is unique, with and without a point mask, and the
+    same bits on a second run (the order of a cluster's sites is fixed by index, not by the fill pass's atomics)."""
+    of, O = gpu, oracle
+    rng = np.random.default_rng(43)
+    shape = (96, 128)
+    blk = (slice(20, 80), slice(30, 90))
+    vecs = contracted_block(shape, blk, factor, (61.3, 47.7))
+    img = rng.random(shape + (3,), dtype=np.float32)
+    for pm in (None, rng.random(shape) > 0.1):
+        f = of.Flow(vecs, 's', pm)
+        got, valid = f.apply(img, return_valid_area=True)
+        want, wvalid = O.OFlow(vecs, 's', pm).apply(img, return_valid_area=True)
+        np.testing.assert_array_equal(valid, wvalid)
+        keep = None if pm is None else pm
+        amb, inside = nonunique_nodes(warped_points(vecs, keep), shape)
+        assert (inside & ~amb).mean() > 0.5
+        bad = ~np.isclose(got, want, rtol=RTOL, atol=ATOL).all(-1) & ~amb
+        assert not bad.any(), (factor, pm is not None, int(bad.sum()), np.argwhere(bad)[:5].tolist())
+        np.testing.assert_array_equal(f.apply(img), got)
+    # the nodes INSIDE the cluster are covered by its tiny triangles: the warped image there is the block's content, shrunk
+    cy, cx = 47.7, 61.3
+    assert valid[int(cy), int(cx)] and valid[int(cy) + 1, int(cx) + 1]
+
+
+def test_dense_cluster_at_4k_is_triangulated_in_milliseconds(gpu):
+    """2160 x 3840 static field with a 400 x 400 block contracted 100 times (160 000 distinct sites in 4 x 4 px, ten thousand per
+    bucket; round 3 refused it: more than 65 536 distinct sites in buckets of more than 4 096): OFL_OK, every site kept, the
+    block's old place filled by the fan around the cluster, in well under 50 ms"""
+    import time
+    of = gpu
+    from oflibnumpy_amd import device as dev
+    nat, lib = of.native, of.native.load()
+    h, w = 2160, 3840
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    vecs = np.zeros((h, w, 2), np.float32)
+    blk = (slice(700, 1100), slice(1500, 1900))
+    ys, xs = yy[blk].astype(np.float64), xx[blk].astype(np.float64)
+    rip = 1.0 + 0.05 * np.sin(xs / 5.3 + ys / 7.1)
+    vecs[blk + (0,)] = (1700.37 + (xs - xs.mean()) / 100.0 * rip - xs).astype(np.float32)
+    vecs[blk + (1,)] = (900.61 + (ys - ys.mean()) / 100.0 * rip - ys).astype(np.float32)
+    f = dev.DeviceBuffer.from_host(vecs)
+    vals = dev.DeviceBuffer.from_host((xx + 2 * yy)[..., None].astype(np.float32))
+    out, valid = dev.DeviceBuffer(h * w * 4), dev.DeviceBuffer(h * w)
+    info = dev.scatter_linear(f, +1, None, vals, 1, None, h, w, None, out, valid, nat.SCATTER_UNCERTIFIED)      # warm-up + the counts
+    assert info[0] == h * w
+    nat.check(lib.ofl_stream_sync(None))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dev.scatter_linear(f, +1, None, vals, 1, None, h, w, None, out, valid, nat.SCATTER_UNCERTIFIED)
+    nat.check(lib.ofl_stream_sync(None))
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print("4K field with a 400 x 400 block contracted 100 x: {:.2f} ms, unfinished {}, left over {}".format(ms, info[1], info[2]))
+    v = valid.to_host((h, w), np.uint8)
+    assert v.all()                                         # the hull is the image; the block's old place is covered by large triangles
+    o = out.to_host((h, w), np.float32)
+    far = np.ones((h, w), bool)
+    far[690:1110, 1490:1910] = False
+    np.testing.assert_allclose(o[far], (xx + 2 * yy)[far], rtol=1e-6, atol=1e-3)       # away from the block the field is the identity
+    assert ms < 50.0, ms
+
+
 def test_delaunay_path_without_counts(gpu, golden2):
     """info_host == NULL: the Delaunay path sizes every launch on the device and reads nothing back (the entry only
     enqueues); the result is bit-identical to the call that asks for the counts.  What can only be known after the

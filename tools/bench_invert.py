@@ -46,6 +46,15 @@ def main():
         big = np.tile(flo, (h // flo.shape[0], w // flo.shape[1], 1))
         h, w = big.shape[:2]
         d = dev.DeviceFlow.from_host(big, 's')
+    elif args.op == "cluster":                               # a 400 x 400 block contracted 100 times inside a static field: 160 000 distinct sites in 4 x 4 px
+        yy, xx = np.mgrid[:h, :w].astype(np.float32)
+        v = np.zeros((h, w, 2), np.float32)
+        blk = (slice(700, 1100), slice(1500, 1900))
+        ys, xs = yy[blk].astype(np.float64), xx[blk].astype(np.float64)
+        rip = 1.0 + 0.05 * np.sin(xs / 5.3 + ys / 7.1)
+        v[blk + (0,)] = (1700.37 + (xs - xs.mean()) / 100.0 * rip - xs).astype(np.float32)
+        v[blk + (1,)] = (900.61 + (ys - ys.mean()) / 100.0 * rip - ys).astype(np.float32)
+        d = dev.DeviceFlow.from_host(v, 's')
     elif args.op == "object":
         v = np.zeros((h, w, 2), np.float32)
         v[h // 4:h // 4 * 3, w // 4:w // 4 * 3] = [30.0, -12.0]

@@ -6,6 +6,7 @@
 #   bench2           the same with --gpus 2 on the one GPU (rehearsal of the N > 1 path; ranks share the card)
 #   cases[:ops]      per-kernel breakdown of the Delaunay-path cases (tools/prof_cases.sh)
 #   ops[:only]       tools/bench_ops.py [--only ...]            -> gpurun_out/<tag>_ops.jsonl
+#   soak:<seconds>   tools/soak_all.sh <seconds>                -> gpurun_out/<tag>_soak.jsonl
 set -o pipefail
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -22,6 +23,7 @@ for STEP in "$@"; do
     cases:*) bash tools/prof_cases.sh $TAG $(echo "${STEP#cases:}" | tr ',' ' ') || exit 1 ;;
     ops)     timeout -k 10 600 python tools/bench_ops.py > gpurun_out/${TAG}_ops.jsonl 2> gpurun_out/${TAG}_ops.err || { tail -20 gpurun_out/${TAG}_ops.err; exit 1; }; cut -c1-200 gpurun_out/${TAG}_ops.jsonl ;;
     ops:*)   timeout -k 10 600 python tools/bench_ops.py --only "${STEP#ops:}" > gpurun_out/${TAG}_ops.jsonl 2> gpurun_out/${TAG}_ops.err || { tail -20 gpurun_out/${TAG}_ops.err; exit 1; }; cut -c1-200 gpurun_out/${TAG}_ops.jsonl ;;
+    soak:*)  timeout -k 10 1100 bash tools/soak_all.sh "${STEP#soak:}" > gpurun_out/${TAG}_soak.log 2>&1; RC=$?; cat gpurun_out/${TAG}_soak.log; cat gpurun_out/soak/*.json > gpurun_out/${TAG}_soak.jsonl; [ $RC = 0 ] || exit 1 ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac || exit 1
 done

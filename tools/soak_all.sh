@@ -8,6 +8,7 @@ cd $ROOT
 python tools/soak_core_cpu.py --seconds $SECS --seed $SEED > $OUT/core_cpu.json 2> $OUT/core_cpu.err
 if python -c "import oflibnumpy_amd as of; of.native.ensure_device()" 2>/dev/null; then
   python tools/soak_scatter.py --seconds $SECS --seed $SEED > $OUT/scatter_grid.json 2> $OUT/scatter_grid.err
+  python tools/soak_scatter.py --cluster --seconds $SECS --seed $SEED > $OUT/scatter_cluster.json 2> $OUT/scatter_cluster.err
   python tools/soak_scatter.py --mode query --seconds $SECS --seed $SEED > $OUT/scatter_query.json 2> $OUT/scatter_query.err
   python tools/soak_scatter.py --mode track --seconds $SECS --seed $SEED --max 90 130 > $OUT/track.json 2> $OUT/track.err
   python tools/soak_gather.py --seconds $SECS --seed $SEED > $OUT/gather.json 2> $OUT/gather.err

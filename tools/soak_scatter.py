@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max", type=int, nargs=2, default=[160, 240])
+    ap.add_argument("--cluster", action="store_true", help="dense clusters of distinct sites: a block of every field contracted 5 .. 200 times (seeds base + 900 000 ...)")
     ap.add_argument("--mode", default="grid", choices=["grid", "query", "track"], help="grid nodes (apply 's', invert, ...) or scattered query positions (mode 2 't')")
     args = ap.parse_args()
     import oflibnumpy_amd as of
@@ -36,7 +37,7 @@ def main():
     of.native.ensure_device()
     O.build()
     t0, cases, nodes, bad, msgs = time.time(), 0, 0, 0, []
-    seed = args.seed * 1_000_000
+    seed = args.seed * 1_000_000 + (900_000 if args.cluster else 0)
     while time.time() - t0 < args.seconds:
         if args.mode == "track":
             n, b, msg = one_track_case(of, O, seed, args.max[0], args.max[1])
@@ -46,7 +47,7 @@ def main():
         if msg:
             msgs.append("seed {}: {}".format(seed, msg))
         seed += 1
-    print(json.dumps({"soak": "scatter path vs SciPy" + (" (query positions)" if args.mode == "query" else " (track_pts)" if args.mode == "track" else ""), "seed_base": args.seed * 1_000_000, "cases": cases, "nodes_compared": nodes,
+    print(json.dumps({"soak": "scatter path vs SciPy" + (" (dense clusters)" if args.cluster else "") + (" (query positions)" if args.mode == "query" else " (track_pts)" if args.mode == "track" else ""), "seed_base": args.seed * 1_000_000, "cases": cases, "nodes_compared": nodes,
                       "mismatching_nodes_or_cases": bad, "details": msgs[:20]}))
 
 

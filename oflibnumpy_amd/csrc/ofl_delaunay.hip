@@ -64,6 +64,7 @@ constexpr int      kLocateRings = 2;     // bucket rings dl_locate_brute searche
 constexpr unsigned char kDegFar = 0xFF;
 constexpr unsigned char kDegTodo = 0xFE;  // not settled by the mesh-fan pass: the clip pass builds this star
 constexpr unsigned char kDegFan = 0xFD;   // not settled by the mesh-cell pass: the fan pass looks at this site
+constexpr unsigned char kDegHeavy = 0xFC; // the clip pass met a dense cluster around this site: the heavy-bucket launch of the clip pass builds this star
 constexpr int      kFanSpan  = 6;        // buckets per axis a fan's circumcircles may span (wider: clip pass)
 constexpr int      kFanBlock = 128;
 constexpr unsigned kDedupeSmall = 64;     // buckets up to this size drop their duplicates by pairwise comparison (quadratic, one thread), larger ones through a hash table
@@ -840,6 +841,7 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
 // schedules for BASELINE config 5, whose source rows scatter over hundreds of buckets: one wave per 8 x 8 bucket tile -- half
 // empty waves, 24 -> 46 ms -- and a list compacted in bucket order -- no change: the pass is bound by the divergent clip
 // code of its 64 lanes, not by where the candidates come from.)
+template <bool HEAVY>       // false: every site of the list; true (a second launch, at once over when no bucket is heavy): the sites the first one marked kDegHeavy
 __global__ __launch_bounds__(64)
 void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, const unsigned char *__restrict__ dup, int H, int W,
                          const DlHead *__restrict__ head, const unsigned *__restrict__ todo,
@@ -855,9 +857,11 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
     const PosFn pos(flow, sign, W);
     const SubGrids subs{ heavy_bucket, heavy_info, sub_start, head->n_heavy };       // (dense clusters: ofl_dl::apply_heavy_run)
     const SubGrids *sub = subs.n ? &subs : nullptr;
+    if (HEAVY && !sub) return;
     for (unsigned base = blockIdx.x * 64; base < n_todo; base += gridDim.x * 64) {
         if (base + threadIdx.x >= n_todo) return;
         const size_t p = todo[base + threadIdx.x];
+        if (HEAVY && deg[p] != kDegHeavy) continue;
         PolyT<float> P{ &s_vx[0][threadIdx.x], &s_vy[0][threadIdx.x], &s_tag[0][threadIdx.x], 64, kNearCap, 0 };
         int rings_done;
         const P2 pp = pos((int)p);
@@ -881,7 +885,8 @@ void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t
             return 0;
         };
         // (a tighter bound -- reach beyond 1 .. 16 times the ring search's own radius -- was measured: no further gain)
-        const int rc = star_near(P, (int)p, pp, g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings, &rings_done, rescue, 4.0 * head->far_t2, sub);
+        const int rc = star_near<HEAVY>(P, (int)p, pp, g, bstart, sorted, pos, kRings, sorted_xy, kOpenRings, &rings_done, rescue, 4.0 * head->far_t2, sub);
+        if (!HEAVY && rc == 2) { deg[p] = kDegHeavy; continue; }
         bool ok = rc == 1;
         for (int k = 0; ok && k < P.n; ++k) ok = P.T(k) >= 0;
         if (!ok) {
@@ -2514,7 +2519,10 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
     // what cells and fans did not settle, in index order, for the clip pass
     hipLaunchKernelGGL(dl_compact_kernel<3>, dim3((fblk + kCompactTiles - 1) / kCompactTiles), dim3(256), 0, s, (const void *)ws.deg, (const unsigned char *)nullptr, ws.head, n,
                        ws.cstate + 3 * ws.cstride, ws.far_idx, (unsigned *)nullptr);           // (far_idx is free until the unfinished points are listed)
-    hipLaunchKernelGGL(dl_star_near_kernel, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
+    hipLaunchKernelGGL(dl_star_near_kernel<false>, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 16384u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
+                       (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
+                       (const P2 *)ws.sorted_xy, ws.deg, ws.nbr, (const unsigned *)ws.heavy_bucket, (const SubGrid *)ws.heavy_info, (const unsigned *)ws.sub_start);
+    hipLaunchKernelGGL(dl_star_near_kernel<true>, dim3(std::min<unsigned>((unsigned)((n + 63) / 64), 2048u)), dim3(64), 0, s, flow, sign_pp, pmask, (const unsigned char *)ws.dup, H, W,
                        (const DlHead *)ws.head, (const unsigned *)ws.far_idx, (const unsigned *)ws.bstart, (const unsigned *)ws.sorted,
                        (const P2 *)ws.sorted_xy, ws.deg, ws.nbr, (const unsigned *)ws.heavy_bucket, (const SubGrid *)ws.heavy_info, (const unsigned *)ws.sub_start);
     OFL_HIP(hipGetLastError());

@@ -386,7 +386,10 @@ int apply_heavy_run(PolyX &P, int p, const P2 &pp, int row, int x0, int x1, cons
 // contiguous range of `sorted`.  Returns -1 when the polygon overflows.
 // `reach2` = (2 * farthest cell vertex)^2, kept current by the caller's polygon: a site at or beyond that distance cannot
 // cut any vertex (|v - c| < |v| implies |c| < 2 |v|), which spares the vertex loop for most sites of the outer rings.
-template <class PolyX, class PosFn>
+// HEAVY = false (the passes every field runs): a run that may hold a heavy bucket is not touched -- 2 is returned and the caller
+// leaves the star to the HEAVY instantiation (a launch of its own, only for such sites): the few hundred lines of the heavy search,
+// a call that is not inlined and a polygon whose address escapes cost the ordinary clip pass half its speed when they sat in it.
+template <bool HEAVY = false, class PolyX, class PosFn>
 DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const Grid &g,
                      const unsigned *bstart, const unsigned *sorted, PosFn pos, double &reach2,
                      const P2 *sorted_xy = nullptr,          // positions in `sorted` order (one contiguous read per run) or null
@@ -419,12 +422,15 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
     unsigned lo, hi;
     bounds(0, lo, hi);
     for (int seg = 0; seg < nseg; ++seg) {
-        if (sub && sub->n && hi - lo > kHeavy) {
-            // (rare) a run that may hold a heavy bucket: bucket by bucket, heavy ones through their own grids
-            const int hr = apply_heavy_run(P, p, pp, row, x0, x1, g, bstart, sorted, sorted_xy, pos, reach2, *sub, budget);
-            if (hr != 0) return hr;                        // -1: overflow, 1: given up (the rim of a cluster)
-            if (seg + 1 < nseg) bounds(seg + 1, lo, hi);
-            continue;
+        if (sub && hi - lo > kHeavy) {
+            if constexpr (!HEAVY) return 2;                // (rare) a run that may hold a heavy bucket: for the HEAVY instantiation
+            else {
+                // bucket by bucket, heavy ones through their own grids
+                const int hr = apply_heavy_run(P, p, pp, row, x0, x1, g, bstart, sorted, sorted_xy, pos, reach2, *sub, budget);
+                if (hr != 0) return hr;                    // -1: overflow, 1: given up (the rim of a cluster)
+                if (seg + 1 < nseg) bounds(seg + 1, lo, hi);
+                continue;
+            }
         }
         unsigned nlo = 0, nhi = 0;
         if (seg + 1 < nseg) bounds(seg + 1, nlo, nhi);
@@ -476,7 +482,9 @@ struct NoRescue { template <class PolyX> DL_HD int operator()(PolyX &) const { r
 // up to float32 rounding of the flow and meet a million pixels out -- a "closed" cell by its tags, which then dragged every
 // candidate of all six rings through the vertex loop (87 000 vector instructions per wave on the rim of a 400 x 800 hole:
 // 0.9 ms for 14 000 sites) before being handed on anyway.
-template <class PolyX, class PosFn, class RescueFn = NoRescue>
+// Returns 2 (HEAVY = false only) when the search met a run that may hold a heavy bucket: the polygon is abandoned, the caller
+// hands the site to the HEAVY instantiation.
+template <bool HEAVY = false, class PolyX, class PosFn, class RescueFn = NoRescue>
 DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned *bstart, const unsigned *sorted,
                     PosFn pos, int rings, const P2 *sorted_xy = nullptr, int open_rings = 1 << 30,
                     int *rings_done = nullptr,               // receives the last ring that was applied completely (-1: none)
@@ -489,8 +497,9 @@ DL_HD int star_near(PolyX &P, int p, const P2 &pp, const Grid &g, const unsigned
     if (rings_done) *rings_done = -1;
     unsigned heavy_seen = 0;
     for (int r = 0; r <= rings; ++r) {
-        const int ar = apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy, sub, sub ? &heavy_seen : nullptr);
+        const int ar = apply_ring<HEAVY>(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy, sub, sub ? &heavy_seen : nullptr);
         if (ar < 0) return -1;
+        if (ar == 2) return 2;
         if (ar > 0) return rescue(P) < 0 ? -1 : 0;         // the rim of a dense cluster: unfinished (ring r was not applied completely)
         if (rings_done) *rings_done = r;
         const double cover = (double)r * g.s;
@@ -868,8 +877,11 @@ DL_HD int star_near2(PolyX &P, int p, const P2 &pp, const unsigned *seeds, int n
     }
     {
         const int bx = g.bx(pp.x), by = g.by(pp.y);
-        for (int r = rings_done + 1; r <= rings; ++r)
-            if (apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy, sub) < 0) return -1;
+        for (int r = rings_done + 1; r <= rings; ++r) {
+            const int ar = apply_ring(P, p, pp, bx, by, r, g, bstart, sorted, pos, reach2, sorted_xy, sub);
+            if (ar < 0) return -1;
+            if (ar != 0) return 0;                          // a dense cluster in the fine rings: left to the cooperative passes
+        }
     }
     for (int k = 0; k < P.n; ++k) if (P.T(k) < 0) return 0;
     return 1;

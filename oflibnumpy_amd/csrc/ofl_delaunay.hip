@@ -1692,6 +1692,13 @@ __device__ void far_point(FarLds<CAP, NT> &L, unsigned &s_off, unsigned li, unsi
     const int dbg_before = L.napply;
     unsigned dbg_chunks = 0;
 #endif
+    // (Round 4 measured five more forms of this pass, each bit-identical in its results, none faster -- profiles/HISTORY.md: the
+    // chunks nearest first with the box test repeated before every chunk (+ 2 .. 7 %); a chunk's 256 candidates in one round trip
+    // under one vote (+ 15 .. 20 %); 5 and 6 waves per SIMD instead of 4 (no change); the sites in another order (no change);
+    // scan first, clip afterwards -- every candidate only TESTED against the cell as it stands, loads of four to eight steps in
+    // flight, the few cutters noted in LDS, sorted by distance and then clipped (+ 20 .. 60 %; with far_test / far_apply /
+    // far_chunks out of line, a third of the code size: + 30 .. 100 %).  PMC: 7 000 vector + 5 000 scalar + 970 LDS + 120 memory
+    // instructions per site, 81 % of the wave cycles waiting, 1 500 of 4 096 wave slots occupied on average.)
     // Every other left-over point -- but only the chunks of 256 whose bounding box could hold a site that cuts the cell AS IT
     // STANDS (later the cell only shrinks: its reach falls, its far vertices stay inside the present cone and below the present
     // largest distance, so what cannot cut now cannot cut later).  The test is far_test's, applied to a box: nearer than the

@@ -144,6 +144,21 @@ int ofl_compose3(const float *fa, const uint8_t *ma, const float *fb, const uint
                  int sign, int H, int W, int batch, float *out, uint8_t *mout,
                  uint32_t *stats_host, int quant);
 
+/* K2 with PACKED masks, for chains that stay on the device (SURVEY hard part H5: "masks as bytes, or bit-packed internally").
+ * The three mask planes are one BIT per pixel -- bit (x & 31) of the uint32 word (x >> 5) of a row, rows padded to whole
+ * words: [batch][H][(W + 31) / 32] words, allocated with ofl_mask_bits_bytes (16 bytes of slack after the last row) -- which
+ * takes the masks from 3 of the 27 B/px of the contract to 0.4 (and from up to five times that, on a rotated sampling grid, in
+ * partially used cache lines).  Same arithmetic, same flag words as ofl_compose3_dev (OFL_QUANT_OPENCV); the result equals
+ * ofl_compose3_dev's bit for bit once unpacked.  W must be even.  ofl_mask_pack_dev / ofl_mask_unpack_dev convert between the
+ * uint8 masks of every other entry (and of the host API) and the planes.
+ */
+int ofl_mask_bits_bytes(int H, int W, int batch, size_t *bytes);
+int ofl_mask_pack_dev(const uint8_t *mask, int H, int W, int batch, uint32_t *bits, void *stream);
+int ofl_mask_unpack_dev(const uint32_t *bits, int H, int W, int batch, uint8_t *mask, void *stream);
+int ofl_compose3_bits_dev(const float *fa, const uint32_t *ma_bits, const float *fb, const uint32_t *mb_bits,
+                          int sign, int H, int W, int batch, float *out, uint32_t *mout_bits,
+                          uint32_t *stats, void *stream);
+
 /* ------------------------------------------------------------------ K1: general bilinear gather
  * Replaces apply_flow(flow, target, 't') utils.py:231-236 and the mask handling around it in
  * Flow.apply flow_class.py:632-695, valid_target :1148-1150, valid_source :1179-1183:

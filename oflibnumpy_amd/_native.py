@@ -72,6 +72,10 @@ SIGNATURES = {
     "ofl_png_unfilter": (_ci, [_vp, _cs, _ci, _ci, _ci, _vp]),
     "ofl_compose3_dev": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp]),
     "ofl_compose3": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci]),
+    "ofl_mask_bits_bytes": (_ci, [_ci, _ci, _ci, ctypes.POINTER(_cs)]),
+    "ofl_mask_pack_dev": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
+    "ofl_mask_unpack_dev": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
+    "ofl_compose3_bits_dev": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "ofl_gather_rows_dev": (_ci, [_vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _vp]),
     "ofl_gather_bilinear_dev": (_ci, [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp,
                                       _ci, _ci, _ci, _vp]),

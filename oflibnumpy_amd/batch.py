@@ -14,14 +14,38 @@ from .flow_class import Flow
 
 
 class DeviceFlowBatch:
-    def __init__(self, n, shape, ref):
+    def __init__(self, n, shape, ref, packed=False):
+        """packed: the masks live as bit planes (`self.bits`, include/ofl.h: ofl_compose3_bits_dev) instead of bytes -- for chains
+        of compositions that stay on the device; `mask` is then produced on demand (unpack)."""
         self.n, self.shape, self.ref = int(n), (int(shape[0]), int(shape[1])), ref
         px = self.shape[0] * self.shape[1]
         self.vecs = dev.DeviceBuffer(self.n * px * 8)
-        self.mask = dev.DeviceBuffer(self.n * px)
+        self.packed = bool(packed)
+        if self.packed:
+            self.bits = dev.DeviceBuffer(dev.mask_bits_bytes(self.shape[0], self.shape[1], self.n))
+            self._mask = None
+        else:
+            self.bits = None
+            self._mask = dev.DeviceBuffer(self.n * px)
+
+    @property
+    def mask(self):
+        if self._mask is None:
+            self._mask = dev.mask_unpack(self.bits, self.shape[0], self.shape[1], self.n)
+        return self._mask
+
+    def pack(self):
+        """the same fields with their masks as bit planes (a copy of the masks only; the vectors are shared)"""
+        if self.packed:
+            return self
+        b = DeviceFlowBatch.__new__(DeviceFlowBatch)
+        b.n, b.shape, b.ref, b.vecs, b.packed = self.n, self.shape, self.ref, self.vecs, True
+        b.bits = dev.mask_pack(self._mask, self.shape[0], self.shape[1], self.n)
+        b._mask = self._mask
+        return b
 
     @classmethod
-    def from_flows(cls, flows):
+    def from_flows(cls, flows, packed=False):
         flows = list(flows)
         if not flows:
             raise ValueError("empty batch")
@@ -37,7 +61,7 @@ class DeviceFlowBatch:
             nat.check(lib.ofl_upload(b.vecs.ptr + i * px * 8, v.ctypes.data, px * 8, None))
             nat.check(lib.ofl_upload(b.mask.ptr + i * px, m.ctypes.data, px, None))
             nat.check(lib.ofl_stream_sync(None))
-        return b
+        return b.pack() if packed else b
 
     def to_flows(self):
         h, w = self.shape
@@ -47,13 +71,18 @@ class DeviceFlowBatch:
 
     def compose3(self, other, quant=nat.QUANT_OPENCV):
         """self[i].combine_with(other[i], mode=3) for every i in ONE launch.
-        Returns (DeviceFlowBatch out, flag words uint32 [n][8]) -- see ofl_compose3_dev for the words."""
+        Returns (DeviceFlowBatch out, flag words uint32 [n][8]) -- see ofl_compose3_dev for the words.  Two PACKED batches
+        compose on their bit planes (ofl_compose3_bits_dev) and give a packed result: the same fields, bit for bit."""
         if (self.n, self.shape, self.ref) != (other.n, other.shape, other.ref):
             raise ValueError("batches need the same length, shape and reference")
         fa, fb, sign = (other, self, +1) if self.ref == 's' else (self, other, -1)
-        out = DeviceFlowBatch(self.n, self.shape, self.ref)
         words = dev.DeviceBuffer.zeros(32 * self.n)
-        dev.compose3_launch(fa, fb, sign, out, words, batch=self.n, quant=quant)
+        if self.packed and other.packed and quant == nat.QUANT_OPENCV and self.shape[1] % 2 == 0:
+            out = DeviceFlowBatch(self.n, self.shape, self.ref, packed=True)
+            dev.compose3_bits_launch(fa.vecs, fa.bits, fb.vecs, fb.bits, sign, self.shape, out.vecs, out.bits, words, batch=self.n)
+        else:
+            out = DeviceFlowBatch(self.n, self.shape, self.ref)
+            dev.compose3_launch(fa, fb, sign, out, words, batch=self.n, quant=quant)
         return out, words.to_host((self.n, 8), np.uint32), (fa, fb)
 
 

@@ -56,6 +56,25 @@ __device__ __forceinline__ void select_mask(uint32_t lo, uint32_t hi, int d, boo
     m1 = (hi1 ? (hi != 0) : (lo1 ? (lo != 0) : false)) ? 1.0f : 0.0f;
 }
 
+// Packed mask planes (device-resident chains, ofl_compose3_bits_dev): one BIT per pixel, bit x & 31 of the 32-bit word x >> 5,
+// rows padded to whole words.  The three 1-byte mask streams of the fused compose are 3 of its 27 B/px by the contract but up
+// to five times that in partially used 128-byte lines on a rotated sampling grid; as bit planes they are 0.4 B/px.
+// taps (x, x + 1) of a plane row as bits 0 and 1 -- one 4-byte load from the byte that holds bit x (x & 7 <= 7: both bits lie
+// within the 32; planes are allocated with 16 bytes of slack, ofl_mask_bits_bytes)
+__device__ __forceinline__ uint32_t c3_bits_at(const uint8_t *plane_row, int x)
+{
+    return reinterpret_cast<const U32u *>(plane_row + (x >> 3))->v >> (x & 7);
+}
+__device__ __forceinline__ uint32_t c3_bit(const uint8_t *plane_row, int x) { return ((uint32_t)plane_row[x >> 3] >> (x & 7)) & 1u; }
+// 16 bits -> the even bit positions of 32
+__device__ __forceinline__ uint32_t c3_spread16(uint32_t x)
+{
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
 // ------------------------------------------------------------------------------------ K2
 // Workgroup tile: 128 px x 8 rows, 256 threads.  Lane (lx, ly) owns the two pixel PAIRS at
 // x = 2*lx and x = 64 + 2*lx of its tile row, so that every stream instruction of a wave covers
@@ -147,6 +166,7 @@ struct C3Args {
     float *out; uint8_t *mout; uint32_t *stats;
     int sign, H, W, tiles_x, tiles_per_field, ntiles;
     float th;
+    int mwpr;              // BITS kernels: 32-bit words per row of the packed mask planes ma / mb / mout (bit x & 31 of word x >> 5); else 0
     int swz_group;         // default kernel: tile rows one XCD owns per group (<= 1: natural order); one-shot variant: workgroups per XCD-swizzle group
     int xpose_rows;        // transposed-gather kernel: source rows a streamed 128-px segment may cross on the direct path
 #ifdef OFL_EXPERIMENTS
@@ -181,7 +201,7 @@ __device__ __forceinline__ void c3_tile_coords(const C3Args &a, int tile, int &b
     xg[1] = xg[0] + 2 * LX;
 }
 
-template <int LX>
+template <int LX, bool BITS = false>
 __device__ __forceinline__ C3Stream c3_load_stream(const C3Args &a, int tile)
 {
     int b, y, xg[2];
@@ -192,6 +212,16 @@ __device__ __forceinline__ C3Stream c3_load_stream(const C3Args &a, int tile)
     for (int g = 0; g < 2; ++g) {
         s.v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
         s.m[g] = 0;
+        if (BITS) {
+            if (y < a.H && xg[g] < a.W) {
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.fb + 2 * (base + xg[g])));
+                s.v[g] = make_float4(t.x, t.y, t.z, t.w);
+                // the pair's two bits (xg is even: both in one word; the 16 lanes of a word read the same address)
+                const uint32_t w = reinterpret_cast<const uint32_t *>(a.mb)[((size_t)b * a.H + y) * a.mwpr + (xg[g] >> 5)] >> (xg[g] & 31);
+                s.m[g] = (w & 1u) | ((w & 2u) << 7);
+            }
+            continue;
+        }
         if (y < a.H && xg[g] < a.W) {
             if (OFL_C3_NT & 2) {
                 const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.fb + 2 * (base + xg[g])));
@@ -226,12 +256,43 @@ __device__ __forceinline__ void c3_flush_stats(const C3Args &a, int b, const C3S
 }
 
 // stream out: out = fb + B(fa), mout = mb & valid   (flow_class.py:332-334, 668, 680)
-template <bool STATS>
+template <bool STATS, bool BITS = false>
 __device__ __forceinline__ void c3_finish(const C3Args &a, size_t row, const int (&xg)[2], const bool (&act)[2],
                                           const float (&bu)[kC3Px], const float (&bv)[kC3Px], const bool (&bm)[kC3Px],
                                           const float (&su)[kC3Px], const float (&sv)[kC3Px], const bool (&ok)[kC3Px],
                                           C3Stat &st)
 {
+    if constexpr (BITS) {
+        // vectors as in the byte form; the mask leaves as whole words: a wave is two tile rows (lanes 0 .. 31 / 32 .. 63), the
+        // ballots of the pairs' even and odd pixels are interleaved by the lanes that store (lane 0 / 16 of a row: the words of
+        // pixels 0 .. 31 / 32 .. 63 of the 64-px stretch)
+        const int lx = threadIdx.x & 31;
+        const size_t wrow = (row / (size_t)a.W) * (size_t)a.mwpr;       // row = (b * H + y) * W
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int j = 2 * g;
+            const bool be = act[g] && ok[j] && bm[j], bo = act[g] && ok[j + 1] && bm[j + 1];
+            const unsigned long long me = __ballot(be), mo = __ballot(bo);
+            if (act[g]) {
+                const float4 o4 = make_float4(__fadd_rn(bu[j], su[j]), __fadd_rn(bv[j], sv[j]),
+                                              __fadd_rn(bu[j + 1], su[j + 1]), __fadd_rn(bv[j + 1], sv[j + 1]));
+                const v4f t = { o4.x, o4.y, o4.z, o4.w };
+                __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(a.out + 2 * (row + xg[g])));
+                if (STATS) {
+                    const float a0 = fmaxf(fabsf(bu[j]), fabsf(bv[j])), a1 = fmaxf(fabsf(bu[j + 1]), fabsf(bv[j + 1]));
+                    st.bmax   = fmaxf(st.bmax, fmaxf(a0, a1));
+                    st.bmax_m = fmaxf(st.bmax_m, fmaxf(bm[j] ? a0 : 0.0f, bm[j + 1] ? a1 : 0.0f));
+                }
+            }
+            // (lane 0 / 16 of a row: its pair starts the word, so its own `act` says whether the word exists -- x < W, y < H)
+            if ((lx & 15) == 0 && act[g]) {
+                const uint32_t e32 = (uint32_t)(me >> (threadIdx.x & 32)), o32 = (uint32_t)(mo >> (threadIdx.x & 32));
+                const uint32_t word = c3_spread16(e32 >> lx) | (c3_spread16(o32 >> lx) << 1);
+                __builtin_nontemporal_store(word, reinterpret_cast<uint32_t *>(a.mout) + wrow + (xg[g] >> 5));
+            }
+        }
+        return;
+    }
     // Mask bytes leave as DWORDS when the row length allows aligned ones: the lane pairs (2k, 2k + 1) own four consecutive
     // pixels, the even lane stores both lanes' bytes (sub-dword stores cost as much per instruction as 16-byte ones)
     const bool quad = (a.W & 3) == 0 && !OFL_ABLATE(a, 64);
@@ -267,7 +328,7 @@ __device__ __forceinline__ void c3_finish(const C3Args &a, size_t row, const int
 }
 
 // One tile: taps from the already loaded stream data, gather, blend, store.
-template <int QUANT, bool STATS>
+template <int QUANT, bool STATS, bool BITS = false>
 __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Stream &in, C3Stat &st)
 {
     int b, y, xg[2];
@@ -275,7 +336,8 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
     const int H = a.H, W = a.W, sign = a.sign;
     const size_t field = (size_t)b * H * W;
     const float   *fa = a.fa + field * 2;
-    const uint8_t *ma = a.ma + field;
+    const uint8_t *ma = BITS ? a.ma + (size_t)b * H * a.mwpr * 4 : a.ma + field;      // BITS: the field's bit plane, rows of mwpr words
+    const int      mrow = a.mwpr * 4;                                                  // ... and its row pitch in bytes
     const bool act[2] = { y < H && xg[0] < W, y < H && xg[1] < W };
     const size_t row = field + (size_t)y * W;
 
@@ -323,6 +385,20 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
             p0[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
             p1[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * (s0 + W));
             if (OFL_ABLATE(a, 16)) { m0[j] = 0x0101u; m1[j] = 0x0101u; continue; }       // TA-cost probe: no mask gathers
+            if (BITS) {
+                // bits 0 / 1 = taps ix / ix + 1 (bits 2, 3 serve the pair's other pixel when it shares the load)
+                if (share && (j & 1)) {
+                    const int sh = act[j >> 1] ? tp[j].ix - tp[j - 1].ix : 0;
+                    m0[j] = m0[j - 1] >> sh;
+                    m1[j] = m1[j - 1] >> sh;
+                } else {
+                    const uint8_t *r0 = ma + (size_t)(act[j >> 1] ? tp[j].iy : 0) * mrow;
+                    const int ix = act[j >> 1] ? tp[j].ix : 0;
+                    m0[j] = c3_bits_at(r0, ix);
+                    m1[j] = c3_bits_at(r0 + mrow, ix);
+                }
+                continue;
+            }
             if (share) {
                 if ((j & 1) == 0) {
                     m0[j] = reinterpret_cast<const U32u *>(ma + s0)->v;
@@ -342,8 +418,8 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
             const C3Tap w = c3_weights<QUANT>(tp[j]);
             su[j] = c3_blend(p0[j].lo_u, p0[j].hi_u, p1[j].lo_u, p1[j].hi_u, w);
             sv[j] = c3_blend(p0[j].lo_v, p0[j].hi_v, p1[j].lo_v, p1[j].hi_v, w);
-            const bool m00 = (m0[j] & 0xffu) != 0, m01 = (m0[j] & 0xff00u) != 0;
-            const bool m10 = (m1[j] & 0xffu) != 0, m11 = (m1[j] & 0xff00u) != 0;
+            const bool m00 = (m0[j] & (BITS ? 1u : 0xffu)) != 0, m01 = (m0[j] & (BITS ? 2u : 0xff00u)) != 0;
+            const bool m10 = (m1[j] & (BITS ? 1u : 0xffu)) != 0, m11 = (m1[j] & (BITS ? 2u : 0xff00u)) != 0;
             ok[j] = c3_valid<QUANT>(m00, m01, m10, m11, w);
             if (STATS) st.amax_m = fmaxf(st.amax_m, (m00 && act[j >> 1]) ? fmaxf(fabsf(p0[j].lo_u), fabsf(p0[j].lo_v)) : 0.0f);
         }
@@ -360,7 +436,11 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
             const size_t s0 = (size_t)y0c * W + ixc, s1 = (size_t)y1c * W + ixc;
             const Pair2 p0 = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
             const Pair2 p1 = *reinterpret_cast<const Pair2 *>(fa + 2 * s1);
-            const uint32_t q00 = ma[s0], q01 = ma[s0 + 1], q10 = ma[s1], q11 = ma[s1 + 1];
+            uint32_t q00, q01, q10, q11;
+            if (BITS) {
+                const uint8_t *r0p = ma + (size_t)y0c * mrow, *r1p = ma + (size_t)y1c * mrow;
+                q00 = c3_bit(r0p, ixc); q01 = c3_bit(r0p, min(ixc + 1, W - 1)); q10 = c3_bit(r1p, ixc); q11 = c3_bit(r1p, min(ixc + 1, W - 1));
+            } else { q00 = ma[s0]; q01 = ma[s0 + 1]; q10 = ma[s1]; q11 = ma[s1 + 1]; }
             float u00, v00, u01, v01, u10, v10, u11, v11, a00, a01, a10, a11;
             select_pair(p0, d, r0, u00, v00, u01, v01);
             select_pair(p1, d, r1, u10, v10, u11, v11);
@@ -374,7 +454,7 @@ __device__ __forceinline__ void c3_tile(const C3Args &a, int tile, const C3Strea
         }
     }
 
-    c3_finish<STATS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
+    c3_finish<STATS, BITS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
 }
 
 #ifndef OFL_C3_ONESHOT_WAVES
@@ -512,12 +592,13 @@ constexpr int kXpRowF2 = 128 + 4;             // LDS row stride in float2 (paddi
 constexpr int kXposeRows = 6;                 // source rows one streamed 128-px segment may cross before we transpose
 constexpr int kC3XcdRows = 1;                 // vertically adjacent tiles one XCD owns per dispatch group (1 = natural tile order)
 
-template <int QUANT, bool STATS>
+template <int QUANT, bool STATS, bool BITS = false>
 __device__ __forceinline__ void c3_sample_block(const C3Args &a, const float *__restrict__ fa, const uint8_t *__restrict__ ma,
                                                 const int (&gx)[4], int gy, const float (&fu)[4], const float (&fv)[4],
                                                 float (&su)[4], float (&sv)[4], bool (&ok)[4], C3Stat &st)
 {
     const int H = a.H, W = a.W;
+    const int mrow = a.mwpr * 4;              // BITS: `ma` is the field's bit plane, rows of mwpr words
     C3Pos tp[4];
     bool act[4], inside = true, outside = true;
 #pragma unroll
@@ -540,16 +621,23 @@ __device__ __forceinline__ void c3_sample_block(const C3Args &a, const float *__
             const size_t s0 = act[j] ? (size_t)tp[j].iy * W + tp[j].ix : 0;
             p0[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
             p1[j] = *reinterpret_cast<const Pair2 *>(fa + 2 * (s0 + W));
-            m0[j] = (uint32_t)ma[s0] | ((uint32_t)ma[s0 + 1] << 8);
-            m1[j] = (uint32_t)ma[s0 + W] | ((uint32_t)ma[s0 + W + 1] << 8);
+            if (BITS) {
+                const uint8_t *r0 = ma + (size_t)(act[j] ? tp[j].iy : 0) * mrow;
+                const int ix = act[j] ? tp[j].ix : 0;
+                m0[j] = c3_bits_at(r0, ix);
+                m1[j] = c3_bits_at(r0 + mrow, ix);
+            } else {
+                m0[j] = (uint32_t)ma[s0] | ((uint32_t)ma[s0 + 1] << 8);
+                m1[j] = (uint32_t)ma[s0 + W] | ((uint32_t)ma[s0 + W + 1] << 8);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const C3Tap w = c3_weights<QUANT>(tp[j]);
             su[j] = c3_blend(p0[j].lo_u, p0[j].hi_u, p1[j].lo_u, p1[j].hi_u, w);
             sv[j] = c3_blend(p0[j].lo_v, p0[j].hi_v, p1[j].lo_v, p1[j].hi_v, w);
-            const bool m00 = (m0[j] & 0xffu) != 0, m01 = (m0[j] & 0xff00u) != 0;
-            const bool m10 = (m1[j] & 0xffu) != 0, m11 = (m1[j] & 0xff00u) != 0;
+            const bool m00 = (m0[j] & (BITS ? 1u : 0xffu)) != 0, m01 = (m0[j] & (BITS ? 2u : 0xff00u)) != 0;
+            const bool m10 = (m1[j] & (BITS ? 1u : 0xffu)) != 0, m11 = (m1[j] & (BITS ? 2u : 0xff00u)) != 0;
             ok[j] = c3_valid<QUANT>(m00, m01, m10, m11, w);
             if (STATS) st.amax_m = fmaxf(st.amax_m, (m00 && act[j]) ? fmaxf(fabsf(p0[j].lo_u), fabsf(p0[j].lo_v)) : 0.0f);
         }
@@ -566,7 +654,11 @@ __device__ __forceinline__ void c3_sample_block(const C3Args &a, const float *__
         const size_t s0 = (size_t)y0c * W + ixc, s1 = (size_t)y1c * W + ixc;
         const Pair2 p0 = *reinterpret_cast<const Pair2 *>(fa + 2 * s0);
         const Pair2 p1 = *reinterpret_cast<const Pair2 *>(fa + 2 * s1);
-        const uint32_t q00 = ma[s0], q01 = ma[s0 + 1], q10 = ma[s1], q11 = ma[s1 + 1];
+        uint32_t q00, q01, q10, q11;
+        if (BITS) {
+            const uint8_t *r0p = ma + (size_t)y0c * mrow, *r1p = ma + (size_t)y1c * mrow;
+            q00 = c3_bit(r0p, ixc); q01 = c3_bit(r0p, min(ixc + 1, W - 1)); q10 = c3_bit(r1p, ixc); q11 = c3_bit(r1p, min(ixc + 1, W - 1));
+        } else { q00 = ma[s0]; q01 = ma[s0 + 1]; q10 = ma[s1]; q11 = ma[s1 + 1]; }
         float u00, v00, u01, v01, u10, v10, u11, v11, a00, a01, a10, a11;
         select_pair(p0, d, r0, u00, v00, u01, v01);
         select_pair(p1, d, r1, u10, v10, u11, v11);
@@ -580,8 +672,11 @@ __device__ __forceinline__ void c3_sample_block(const C3Args &a, const float *__
     }
 }
 
-template <int QUANT, bool STATS>
-__global__ __launch_bounds__(256, OFL_C3_ONESHOT_WAVES)
+#ifndef OFL_C3_BITS_WAVES
+#define OFL_C3_BITS_WAVES 5          // the packed-mask form needs a few registers more than the 6-wave budget leaves (11 spilled there)
+#endif
+template <int QUANT, bool STATS, bool BITS = false>      // BITS: the three masks are packed bit planes (ofl_compose3_bits_dev)
+__global__ __launch_bounds__(256, BITS ? OFL_C3_BITS_WAVES : OFL_C3_ONESHOT_WAVES)
 void compose3_xpose_kernel(const C3Args a)
 {
     static_assert(kC3LanesX == 32, "the transposed form assumes 128 x 8 tiles");
@@ -605,7 +700,7 @@ void compose3_xpose_kernel(const C3Args a)
     }
     if (tile >= a.ntiles) return;
     C3Stat st = { 0.0f, 0.0f, 0.0f };
-    const C3Stream in = c3_load_stream<kC3LanesX>(a, tile);
+    const C3Stream in = c3_load_stream<kC3LanesX, BITS>(a, tile);
     int b, y, xg[2];
     c3_tile_coords<kC3LanesX>(a, tile, b, y, xg);
     const int H = a.H, W = a.W;
@@ -622,7 +717,7 @@ void compose3_xpose_kernel(const C3Args a)
         rotated = fabsf(frow[2 * x1 + 1] - frow[2 * x0 + 1]) * 128.0f > (float)(a.xpose_rows * (x1 - x0 + 1));
     }
     if (!rotated) {
-        c3_tile<QUANT, STATS>(a, tile, in, st);
+        c3_tile<QUANT, STATS, BITS>(a, tile, in, st);
         if (STATS) c3_flush_stats(a, tile / a.tiles_per_field, st);
         return;
     }
@@ -646,7 +741,7 @@ void compose3_xpose_kernel(const C3Args a)
         float su[4], sv[4];
         bool  ok[4];
         const size_t field = (size_t)b * H * W;
-        c3_sample_block<QUANT, STATS>(a, a.fa + field * 2, a.ma + field, gx, ty * 8 + r, fu, fv, su, sv, ok, st);
+        c3_sample_block<QUANT, STATS, BITS>(a, a.fa + field * 2, BITS ? a.ma + (size_t)b * H * a.mwpr * 4 : a.ma + field, gx, ty * 8 + r, fu, fv, su, sv, ok, st);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             xp_v[r * kXpRowF2 + c0 + 8 * j] = make_float2(su[j], sv[j]);
@@ -666,7 +761,7 @@ void compose3_xpose_kernel(const C3Args a)
         const float bv[kC3Px] = { in.v[0].y, in.v[0].w, in.v[1].y, in.v[1].w };
         const bool  bm[kC3Px] = { (in.m[0] & 0xffu) != 0, (in.m[0] & 0xff00u) != 0, (in.m[1] & 0xffu) != 0, (in.m[1] & 0xff00u) != 0 };
         const size_t row = (size_t)b * H * W + (size_t)y * W;
-        c3_finish<STATS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
+        c3_finish<STATS, BITS>(a, row, xg, act, bu, bv, bm, su, sv, ok, st);
     }
     if (STATS) c3_flush_stats(a, tile / a.tiles_per_field, st);
 }
@@ -1469,6 +1564,43 @@ size_t dtype_size(int dtype)
     }
 }
 
+// uint8 masks <-> packed bit planes (rows padded to whole words): one thread per word
+__global__ __launch_bounds__(256)
+void mask_pack_kernel(const uint8_t *__restrict__ mask, size_t rows, int W, int wpr, uint32_t *__restrict__ bits)
+{
+    const size_t words = rows * (size_t)wpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / (size_t)wpr;
+        const int x0 = (int)(i - r * (size_t)wpr) * 32;
+        const uint8_t *m = mask + r * (size_t)W + x0;
+        uint32_t w = 0;
+        if (x0 + 32 <= W && (((size_t)m) & 15) == 0) {
+            const uint4 a = reinterpret_cast<const uint4 *>(m)[0], b = reinterpret_cast<const uint4 *>(m)[1];
+            const uint32_t d[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w |= ((d[k] >> (8 * e)) & 0xffu) ? 1u << (4 * k + e) : 0u;
+        } else {
+            for (int k = 0; k < 32 && x0 + k < W; ++k) w |= m[k] ? 1u << k : 0u;
+        }
+        bits[i] = w;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void mask_unpack_kernel(const uint32_t *__restrict__ bits, size_t rows, int W, int wpr, uint8_t *__restrict__ mask)
+{
+    const size_t words = rows * (size_t)wpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / (size_t)wpr;
+        const int x0 = (int)(i - r * (size_t)wpr) * 32;
+        const uint32_t w = bits[i];
+        uint8_t *m = mask + r * (size_t)W + x0;
+        for (int k = 0; k < 32 && x0 + k < W; ++k) m[k] = (w >> k) & 1u;
+    }
+}
+
 int check_dims(const char *who, int H, int W)
 {
     // cv2.remap asserts src/dst dims < SHRT_MAX (coordinates are int16 inside OpenCV)
@@ -1528,7 +1660,7 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
             tiles_x = (W + 4 * kLdsLX - 1) / (4 * kLdsLX); tiles_y = (H + 256 / kLdsLX - 1) / (256 / kLdsLX);
             nt = (long long)tiles_x * tiles_y * batch;
         }
-        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, variant == 3 ? xcd_rows : swz, xpose_rows, ablate };
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, 0, variant == 3 ? xcd_rows : swz, xpose_rows, ablate };
         int grid = rt().n_cu * c3_blocks_per_cu(quant, stats != nullptr, use_lds);      // persistent variants: what the chip keeps resident
         if (grid > (int)nt) grid = (int)nt;
         if (grid >= 8) grid &= ~7;
@@ -1537,7 +1669,7 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
                           else if (variant == 0) hipLaunchKernelGGL((compose3_kernel<Q, S>), dim3(grid), dim3(256), 0, s, a); \
                           else hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nblk), dim3(256), 0, s, a); } while (0)
 #else
-        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, xcd_rows, xpose_rows };
+        C3Args a = { fa, ma, fb, mb, out, mout, stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, th, 0, xcd_rows, xpose_rows };
 #define OFL_C3(Q, S) hipLaunchKernelGGL((compose3_xpose_kernel<Q, S>), dim3((int)nblk), dim3(256), 0, s, a)
 #endif
         if (quant == OFL_QUANT_OPENCV) { if (stats) OFL_C3(OFL_QUANT_OPENCV, true); else OFL_C3(OFL_QUANT_OPENCV, false); }
@@ -1553,6 +1685,63 @@ int ofl_compose3_dev(const float *fa, const uint8_t *ma, const float *fb, const 
             hipLaunchKernelGGL((compose3_generic_kernel<OFL_QUANT_EXACT>), dim3(nblocks), dim3(256), 0, s,
                                fa, ma, fb, mb, sign, H, W, n, out, mout, stats, th);
     }
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_mask_bits_bytes(int H, int W, int batch, size_t *bytes)
+{
+    if (!bytes || H <= 0 || W <= 0 || batch <= 0) return fail(OFL_E_INVALID, "ofl_mask_bits_bytes: bad arguments");
+    *bytes = (size_t)batch * H * ((W + 31) / 32) * 4 + 16;      // 16 bytes of slack: the gather reads 4 bytes from the byte of a tap's bit
+    return OFL_OK;
+}
+
+int ofl_mask_pack_dev(const uint8_t *mask, int H, int W, int batch, uint32_t *bits, void *stream)
+{
+    OFL_TRY(need_device());
+    OFL_TRY(check_dims("ofl_mask_pack", H, W));
+    if (!mask || !bits || batch <= 0) return fail(OFL_E_INVALID, "ofl_mask_pack: NULL pointer / batch < 1");
+    const size_t words = (size_t)batch * H * ((W + 31) / 32);
+    hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 65535)), dim3(256), 0, stream_of(stream),
+                       mask, (size_t)batch * H, W, (W + 31) / 32, bits);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_mask_unpack_dev(const uint32_t *bits, int H, int W, int batch, uint8_t *mask, void *stream)
+{
+    OFL_TRY(need_device());
+    OFL_TRY(check_dims("ofl_mask_unpack", H, W));
+    if (!mask || !bits || batch <= 0) return fail(OFL_E_INVALID, "ofl_mask_unpack: NULL pointer / batch < 1");
+    const size_t words = (size_t)batch * H * ((W + 31) / 32);
+    hipLaunchKernelGGL(mask_unpack_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 65535)), dim3(256), 0, stream_of(stream),
+                       bits, (size_t)batch * H, W, (W + 31) / 32, mask);
+    OFL_HIP(hipGetLastError());
+    return OFL_OK;
+}
+
+int ofl_compose3_bits_dev(const float *fa, const uint32_t *ma_bits, const float *fb, const uint32_t *mb_bits,
+                          int sign, int H, int W, int batch, float *out, uint32_t *mout_bits,
+                          uint32_t *stats, void *stream)
+{
+    OFL_TRY(need_device());
+    OFL_TRY(check_dims("ofl_compose3_bits", H, W));
+    if (!fa || !ma_bits || !fb || !mb_bits || !out || !mout_bits) return fail(OFL_E_INVALID, "ofl_compose3_bits: NULL pointer");
+    if (batch <= 0) return fail(OFL_E_INVALID, "ofl_compose3_bits: batch must be >= 1");
+    if (sign != 1 && sign != -1) return fail(OFL_E_INVALID, "ofl_compose3_bits: sign must be +1 or -1");
+    if (W % 2) return fail(OFL_E_INVALID, "ofl_compose3_bits: the packed-mask kernel takes even widths (odd ones: ofl_compose3_dev)");
+    hipStream_t s = stream_of(stream);
+    const int tiles_x = (W + kC3TileW - 1) / kC3TileW, tiles_y = (H + kC3TileH - 1) / kC3TileH;
+    const long long nt = (long long)tiles_x * tiles_y * batch;
+    if (nt > 0x7fffffffLL) return fail(OFL_E_INVALID, "ofl_compose3_bits: too many tiles");
+    C3Args a = { fa, reinterpret_cast<const uint8_t *>(ma_bits), fb, reinterpret_cast<const uint8_t *>(mb_bits), out,
+                 reinterpret_cast<uint8_t *>(mout_bits), stats, sign, H, W, tiles_x, tiles_x * tiles_y, (int)nt, 1e-3f, (W + 31) / 32, 1, kXposeRows
+#ifdef OFL_EXPERIMENTS
+                 , 0
+#endif
+    };
+    if (stats) hipLaunchKernelGGL((compose3_xpose_kernel<OFL_QUANT_OPENCV, true, true>), dim3((int)nt), dim3(256), 0, s, a);
+    else       hipLaunchKernelGGL((compose3_xpose_kernel<OFL_QUANT_OPENCV, false, true>), dim3((int)nt), dim3(256), 0, s, a);
     OFL_HIP(hipGetLastError());
     return OFL_OK;
 }

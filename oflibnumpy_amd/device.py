@@ -338,6 +338,32 @@ def compose3_launch(fa, fb, sign, out, stats_buf=None, stats_offset=0, batch=1, 
                                       out.vecs.ptr, out.mask.ptr, sp, quant, stream))
 
 
+def mask_bits_bytes(h, w, batch=1):
+    n = ctypes.c_size_t(0)
+    nat.check(_lib().ofl_mask_bits_bytes(h, w, batch, ctypes.byref(n)))
+    return n.value
+
+
+def mask_pack(mask_buf, h, w, batch=1, stream=None):
+    """uint8 masks [batch][H][W] -> packed bit planes [batch][H][(W + 31) / 32] uint32 (ofl_mask_pack_dev)"""
+    bits = DeviceBuffer(mask_bits_bytes(h, w, batch))
+    nat.check(_lib().ofl_mask_pack_dev(mask_buf.ptr, h, w, batch, bits.ptr, stream))
+    return bits
+
+
+def mask_unpack(bits_buf, h, w, batch=1, stream=None):
+    mask = DeviceBuffer(batch * h * w)
+    nat.check(_lib().ofl_mask_unpack_dev(bits_buf.ptr, h, w, batch, mask.ptr, stream))
+    return mask
+
+
+def compose3_bits_launch(fa_vecs, fa_bits, fb_vecs, fb_bits, sign, shape, out_vecs, out_bits, stats_buf=None, stats_offset=0, batch=1, stream=None):
+    """K2 on packed mask planes (ofl_compose3_bits_dev); asynchronous."""
+    sp = None if stats_buf is None else stats_buf.ptr + stats_offset
+    nat.check(_lib().ofl_compose3_bits_dev(fa_vecs.ptr, fa_bits.ptr, fb_vecs.ptr, fb_bits.ptr, sign, shape[0], shape[1], batch,
+                                           out_vecs.ptr, out_bits.ptr, sp, stream))
+
+
 _STATS_KNOW_MASK = 1 << 30        # private flag in DeviceFlow._stats: STAT_MASK_HAS_ZERO has been evaluated
 
 

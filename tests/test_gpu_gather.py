@@ -805,3 +805,61 @@ def test_gather_batch_equals_field_by_field(gpu):
                 assert np.array_equal(got[i], d1.to_host()) and np.array_equal(gotv[i], v1.to_host((h, w), np.uint8))
     lib = nat.load()
     assert lib.ofl_gather_bilinear_batch_dev(ib.ptr, 0, nat.F32, 2, h, w, 0, fb.ptr, h, w, 0, 0, -1, None, 0, None, dst.ptr, None, 0, 0, 0, None) == nat.E_INVALID
+
+
+def test_compose3_on_packed_mask_planes_is_bit_identical(gpu):
+    """ofl_compose3_bits_dev (masks as one bit per pixel, device-resident chains) == ofl_compose3_dev once unpacked: vectors, valid
+    mask and flag words, bit for bit -- axis-aligned and rotated sampling grids (the transposed gather), samples outside the
+    source, ragged tile edges (W not a multiple of 32 or 128, H not of 8), both signs, batches; pack / unpack round trips for
+    any width; DeviceFlowBatch composes packed batches on their planes."""
+    from oflibnumpy_amd import device as dev
+    from oflibnumpy_amd.batch import DeviceFlowBatch
+    of, nat = gpu, gpu.native
+    lib = nat.load()
+    rng = np.random.default_rng(5)
+    for h, w in ((37, 70), (64, 128), (130, 258), (96, 200)):
+        m = (rng.random((3, h, w)) > 0.2).astype(np.uint8)
+        back = dev.mask_unpack(dev.mask_pack(dev.DeviceBuffer.from_host(m), h, w, 3), h, w, 3).to_host((3, h, w), np.uint8)
+        assert np.array_equal(back, m)
+    m = (rng.random((2, 9, 45)) > 0.5).astype(np.uint8)          # odd width: the planes exist, the compose kernel refuses
+    assert np.array_equal(dev.mask_unpack(dev.mask_pack(dev.DeviceBuffer.from_host(m), 9, 45, 2), 9, 45, 2).to_host((2, 9, 45), np.uint8), m)
+    bits = dev.mask_pack(dev.DeviceBuffer.from_host(m), 9, 45, 2)
+    v = dev.DeviceBuffer.zeros(2 * 9 * 45 * 8)
+    assert lib.ofl_compose3_bits_dev(v.ptr, bits.ptr, v.ptr, bits.ptr, -1, 9, 45, 2, v.ptr, bits.ptr, None, None) == nat.E_INVALID
+    B = 3
+    for h, w in ((37, 70), (72, 256), (130, 258), (61, 392)):
+        n = h * w
+        yy, xx = np.mgrid[:h, :w].astype(np.float32)
+        samplers = {
+            "shift": np.stack([np.full((h, w), 3.3, np.float32), np.full((h, w), -2.7, np.float32)], -1),
+            "rotated": of.from_transforms([['rotation', w / 2, h / 2, -30]], [h, w], 't'),
+            "scaled": of.from_transforms([['scaling', w / 3, h / 3, 0.7]], [h, w], 't'),
+            "noise": (rng.standard_normal((h, w, 2)) * 6).astype(np.float32),
+        }
+        for name, fbv in samplers.items():
+            for sign in (-1, 1):
+                fa = (rng.standard_normal((B, h, w, 2)) * 2).astype(np.float32)
+                fb = np.stack([fbv + np.float32(0.01 * i) for i in range(B)]).astype(np.float32)
+                if name == "noise":
+                    fb[1] = 0.0                                  # a zero sampling field: flag words 4 .. 7 stay clear
+                ma = (rng.random((B, h, w)) > 0.1).astype(np.uint8)
+                mb = (rng.random((B, h, w)) > 0.1).astype(np.uint8)
+                d = {k: dev.DeviceBuffer.from_host(a) for k, a in (("fa", fa), ("fb", fb), ("ma", ma), ("mb", mb))}
+                out, mout, st = dev.DeviceBuffer(B * n * 8), dev.DeviceBuffer(B * n), dev.DeviceBuffer.zeros(32 * B)
+                nat.check(lib.ofl_compose3_dev(d["fa"].ptr, d["ma"].ptr, d["fb"].ptr, d["mb"].ptr, sign, h, w, B, out.ptr, mout.ptr, st.ptr, 0, None))
+                ba, bb = dev.mask_pack(d["ma"], h, w, B), dev.mask_pack(d["mb"], h, w, B)
+                out2, bo, st2 = dev.DeviceBuffer(B * n * 8), dev.DeviceBuffer.zeros(dev.mask_bits_bytes(h, w, B)), dev.DeviceBuffer.zeros(32 * B)
+                dev.compose3_bits_launch(d["fa"], ba, d["fb"], bb, sign, (h, w), out2, bo, st2, batch=B)
+                tag = (h, w, name, sign)
+                assert np.array_equal(out2.to_host((B, h, w, 2), np.float32).view(np.uint32), out.to_host((B, h, w, 2), np.float32).view(np.uint32)), tag
+                assert np.array_equal(dev.mask_unpack(bo, h, w, B).to_host((B, h, w), np.uint8), mout.to_host((B, h, w), np.uint8)), tag
+                assert np.array_equal(st2.to_host((B, 8), np.uint32), st.to_host((B, 8), np.uint32)), tag
+    # the batch class: packed in, packed out, same fields
+    h, w = 72, 256
+    f1 = [of.Flow((rng.standard_normal((h, w, 2)) * 2).astype(np.float32), 't', rng.random((h, w)) > 0.1) for _ in range(4)]
+    f2 = [of.Flow(of.from_transforms([['rotation', 100, 30, 10 + i]], [h, w], 't'), 't', rng.random((h, w)) > 0.1) for i in range(4)]
+    plain, words, _ = DeviceFlowBatch.from_flows(f1).compose3(DeviceFlowBatch.from_flows(f2))
+    packed, words2, _ = DeviceFlowBatch.from_flows(f1, packed=True).compose3(DeviceFlowBatch.from_flows(f2, packed=True))
+    assert packed.packed and np.array_equal(words, words2)
+    for a, b in zip(plain.to_flows(), packed.to_flows()):
+        assert np.array_equal(a.vecs.view(np.uint32), b.vecs.view(np.uint32)) and np.array_equal(a.mask, b.mask)

@@ -192,6 +192,23 @@ def sec_config4(it):
                                                             s[6].ptr, 0, None))) for s in sets], max(it, 10))
     yield entry("c4_share_32x1080p", "combine_with mode 3 't', 32 pairs of 1080p in one launch (K2)", (h, w), 27, *t, units=B,
                 kernel="compose3_xpose_kernel", note="BASELINE config 4, one GPU's share of the 256 pairs; sampling field = translation of 40 px")
+    if hasattr(dev, "compose3_bits_launch"):
+        # the same launch on PACKED mask planes (device-resident chains): 24.4 B/px really move; the fraction is still quoted on
+        # the 27 B/px of the contract
+        psets = []
+        for s in sets:
+            psets.append((s[0], dev.mask_pack(s[1], h, w, B), s[2], dev.mask_pack(s[3], h, w, B), s[4], dev.DeviceBuffer(dev.mask_bits_bytes(h, w, B)), s[6]))
+        t = timed([(lambda s=s: dev.compose3_bits_launch(s[0], s[1], s[2], s[3], -1, (h, w), s[4], s[5], s[6], batch=B)) for s in psets], max(it, 10))
+        yield entry("c4_share_32x1080p_bits", "the same on packed mask planes (K2, ofl_compose3_bits_dev)", (h, w), 27, *t, units=B,
+                    kernel="compose3_xpose_kernel<bits>", note="masks as one bit per pixel: 24.4 B/px move; fraction on the 27 B/px contract")
+        # the roles swapped: the SAMPLING field is the rotation (the pattern whose 1-byte mask taps cost most in partially used lines)
+        t = timed([(lambda s=s: nat.check(lib.ofl_compose3_dev(s[2].ptr, s[3].ptr, s[0].ptr, s[1].ptr, -1, h, w, B, s[4].ptr, s[5].ptr,
+                                                                s[6].ptr, 0, None))) for s in sets], max(it, 10))
+        yield entry("c4_rot_32x1080p", "32 pairs of 1080p, sampling field = the rotations (K2)", (h, w), 27, *t, units=B, kernel="compose3_xpose_kernel",
+                    note="config 4's pairs with the roles swapped: rotated sampling grids (-30 .. -22 degrees)")
+        t = timed([(lambda s=s: dev.compose3_bits_launch(s[2], s[3], s[0], s[1], -1, (h, w), s[4], s[5], s[6], batch=B)) for s in psets], max(it, 10))
+        yield entry("c4_rot_32x1080p_bits", "the same on packed mask planes", (h, w), 27, *t, units=B, kernel="compose3_xpose_kernel<bits>",
+                    note="rotated sampling grids, masks as bit planes")
 
 
 def sec_config3(it):

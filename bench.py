@@ -28,7 +28,7 @@ import numpy as np
 H, W = 2160, 3840
 BYTES_PER_PX = 27            # 2 x (8 + 1) read + (8 + 1) written
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
-TRAFFIC_FILES = ("profiles/r03_compose3_traffic.json", "profiles/r02_compose3_traffic.json", "profiles/r01_compose3_traffic.json")
+TRAFFIC_FILES = ("profiles/r04_compose3_traffic.json", "profiles/r03_compose3_traffic.json", "profiles/r02_compose3_traffic.json", "profiles/r01_compose3_traffic.json")
 
 
 PATTERN = "scale"

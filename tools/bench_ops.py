@@ -372,8 +372,12 @@ def collect(iters=12, sections=("config2", "config3", "config4", "delaunay", "co
             for e in gen:
                 # (compact: the driver keeps the TAIL of stdout, and this rides in the one JSON line; the verbose entry -- op,
                 # shape, note -- goes to stderr, and tools/bench_ops.py prints it when run on its own)
+                if e["key"].endswith("_bits") or e["key"].startswith(("c4_rot", "c3_switch")):
+                    if log:
+                        log(json.dumps(e))                      # (A/B and duplicate entries: stderr only, the line stays short)
+                    continue
                 out[e["key"]] = {"ms": e["device_ms"], "algorithmic_bytes": e["algorithmic_bytes"], "frac": e["frac_of_8TBps"],
-                                 "kernel": e["kernel"].split(" (")[0], "sets": e["rotating_sets"]}
+                                 "kernel": e["kernel"].split(" (")[0].split(" + ")[0], "sets": e["rotating_sets"]}
                 if log:
                     log(json.dumps(e))
         finally:

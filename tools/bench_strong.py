@@ -54,7 +54,7 @@ def run(of, dist, rank, world, comm_ok, log=lambda s: None, steps=6, which=("c4"
         barrier()
         return slowest((time.perf_counter() - t0) / iters)
 
-    out = {"n_gpus": world, "exchange": "none (1 GPU)" if world == 1 else ("through the host (ranks share a GPU): rehearsal" if shared_gpu or not comm_ok
+    out = {"n_gpus": world, "scaling": "strong", "exchange": "none (1 GPU)" if world == 1 else ("through the host (ranks share a GPU): rehearsal" if shared_gpu or not comm_ok
                                                                            else "RCCL over xGMI")}
     # ------------------------------------------------------------------ config 4: 256 pairs, strong
     if "c4" in which:
@@ -93,8 +93,7 @@ def run(of, dist, rank, world, comm_ok, log=lambda s: None, steps=6, which=("c4"
         t = timed(job, max(3, steps), warm=2)
         out["c4_256pairs"] = {"ms_per_256_pairs": round(t * 1e3, 4), "pairs_per_s": round(total / t, 1), "pairs_per_rank": B,
                               "broadcast_in_timed_region": bool(use_rccl), "algorithmic_bytes": 27 * n * total,
-                              "frac_of_node_roofline": round(27 * n * total / t / (8e12 * world), 4), "scaling": "strong",
-                              "kernel": "compose3_xpose_kernel"}
+                              "frac_of_node_roofline": round(27 * n * total / t / (8e12 * world), 4), "kernel": "compose3_xpose_kernel"}
         log("strong c4_256pairs: {:.3f} ms".format(t * 1e3))
         del va, ma, vb, mb, vo, mo, st, shared_v, shared_m
         dev.empty_cache()
@@ -116,7 +115,7 @@ def run(of, dist, rank, world, comm_ok, log=lambda s: None, steps=6, which=("c4"
             t = timed(lambda: dev.gather_rows(dimg, r0, rows, flow_rows, -1, want_valid=True), max(6, steps), warm=2)
             out["c5_t_bands"] = {"ms_per_field": round(t * 1e3, 4), "fields_per_s": round(1 / t, 2), "rows_per_rank": rows,
                                  "algorithmic_bytes": 34 * h * w, "frac_of_node_roofline": round(34 * h * w / t / (8e12 * world), 4),
-                                 "scaling": "strong", "kernel": "gather2_kernel"}
+                                 "kernel": "gather2_kernel"}
             log("strong c5_t_bands: {:.3f} ms".format(t * 1e3))
             del flow_rows
         if "c5s" in which:
@@ -130,7 +129,7 @@ def run(of, dist, rank, world, comm_ok, log=lambda s: None, steps=6, which=("c4"
             t = timed(fn, max(3, steps // 2), warm=1)
             out["c5_s_slab"] = {"ms_per_field": round(t * 1e3, 4), "fields_per_s": round(1 / t, 2), "rows_per_rank": rows,
                                 "algorithmic_bytes": 34 * h * w, "frac_of_node_roofline": round(34 * h * w / t / (8e12 * world), 4),
-                                "scaling": "strong", "kernel": "dl_* (slab-wise: step 1, two all-gathers, step 2)" if world > 1 else "dl_* (whole field)"}
+                                "kernel": "dl_* slab-wise + 2 all-gathers" if world > 1 else "dl_* whole field"}
             log("strong c5_s_slab: {:.3f} ms".format(t * 1e3))
         dev.empty_cache()
     return out

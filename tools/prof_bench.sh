@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 60 --warmup 6 --no-cpu-baseline --no-secondary --prewarm-ms 0 $@"
+ARGS="--steps 60 --warmup 6 --no-cpu-baseline --no-secondary --no-configs --no-strong --min-timed-ms 0 --prewarm-ms 0 $@"
 for PAT in scale shift rot; do
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$PAT/trace -- python3 $ROOT/bench.py $ARGS --pattern $PAT > $OUT/$PAT.trace.log 2>&1 || { echo "trace run ($PAT) failed"; tail -5 $OUT/$PAT.trace.log; exit 1; }
   grep -h '"metric"' $OUT/$PAT.trace.log | head -1 > $OUT/$PAT.bench_line.json

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 40 --warmup 5 --no-cpu-baseline $@"
+ARGS="--steps 40 --warmup 5 --no-cpu-baseline --no-configs --no-strong --min-timed-ms 0 $@"
 i=0
 for PASS in "${PASSES[@]}"; do
   i=$((i+1))

@@ -17,18 +17,27 @@ from collections import defaultdict
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    pre = ""
+    if name.startswith("[grid "):
+        pre, name = name.split("] ", 1)
+        pre += "] "
     name = name.split("(")[0]
-    return name[-70:]
+    return pre + name[-70:]
 
 
 def main(dirs):
+    by_grid = "--by-grid" in dirs          # one row per (kernel, grid size): the launches of different benchmark entries apart
+    dirs = [d for d in dirs if d != "--by-grid"]
     for d in dirs:
         print("== {}".format(d))
         for path in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
             dur = defaultdict(list)
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    dur[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                    name = row["Kernel_Name"]
+                    if by_grid and "Grid_Size_X" in row:
+                        name = "[grid {}x{}] ".format(row["Grid_Size_X"], row.get("Grid_Size_Y", "1")) + name
+                    dur[name].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
             print("-- kernel trace: {}".format(os.path.relpath(path, d)))
             print("{:>8} {:>12} {:>12} {:>12} {:>14}  {}".format("calls", "avg_us", "min_us", "max_us", "total_ms", "kernel"))
             for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):

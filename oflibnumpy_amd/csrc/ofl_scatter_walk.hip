@@ -32,7 +32,10 @@ struct CertDev {                       // device record written by the certify k
 };
 static_assert(sizeof(CertDev) == 16 + 64 + 64, "CertDev layout");
 
-struct WalkCert { D2 c[4]; double inv_len[4]; double delta; const uint32_t *diag; int diag_stride; };     // inv_len[k]: 1 / |c[k + 1] - c[k]|
+struct WalkCert {
+    D2 c[4]; double inv_len[4]; double delta; const uint32_t *diag; int diag_stride;     // inv_len[k]: 1 / |c[k + 1] - c[k]|
+    float pa[4], pb[4], pc[4], lim32;      // side k's inward distance as a float32 plane pa x + pb y + pc, and the (conservative) limit for it
+};
 
 __device__ __forceinline__ unsigned long long okey(double d)
 {
@@ -219,37 +222,24 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
     int diag;
     if (BITS) diag = (int)((wc.diag[(size_t)cy * wc.diag_stride + (cx >> 5)] >> (cx & 31)) & 1u);
     else      diag = incircle_filtered(pa, pb, pc, pd) > 0 ? 1 : 0;
-    // triangle 0 = (a, b, c) or (b, c, d); its vertex-1 coordinate w1 vanishes on the cell's diagonal, so w1 also tells
-    // on which side of the diagonal the position lies: the second triangle is only evaluated when it can matter
-    int t = 0;
-    int i0, i1, i2;
-    double w1, w2, det;
-    bool in;
-    {
-        tri_corners(diag, 0, i0, i1, i2);
-        const D2 q0 = diag ? pb : pa, q1 = diag ? pc : pb, q2 = diag ? pd : pc;
-        const double e1x = q1.x - q0.x, e1y = q1.y - q0.y, e2x = q2.x - q0.x, e2y = q2.y - q0.y;
-        det = e1x * e2y - e1y * e2x;                                    // > 0 (certificate)
-        const double dx = qx - q0.x, dy = qy - q0.y;
-        w1 = dx * e2y - dy * e2x; w2 = e1x * dy - e1y * dx;
-        const double tol = kEps * det;
-        in = fmin(det - w1 - w2, fmin(w1, w2)) >= -tol;
-        if (!in && w1 <= tol) {                                         // on or beyond the diagonal: the other half of the cell
-            t = 1;
-            tri_corners(diag, 1, i0, i1, i2);
-            const D2 r0p = q0, r1p = q2, r2p = diag ? pa : pd;          // (a, c, d) or (b, d, a): shares q0 and the diagonal
-            const double f1x = r1p.x - r0p.x, f1y = r1p.y - r0p.y, f2x = r2p.x - r0p.x, f2y = r2p.y - r0p.y;
-            const double det1 = f1x * f2y - f1y * f2x;
-            const double v1 = dx * f2y - dy * f2x, v2 = f1x * dy - f1y * dx;
-            const double tol1 = kEps * det1;
-            const bool in1 = fmin(det1 - v1 - v2, fmin(v1, v2)) >= -tol1;
-            // a miss keeps the triangle on whose side of the diagonal the position lies
-            if (in1 || w1 < -tol) { in = in1; w1 = v1; w2 = v2; det = det1; }
-            else { t = 0; tri_corners(diag, 0, i0, i1, i2); }
-        }
-    }
+    // The cell's diagonal runs q0 -> q2; triangle 0 = (q0, q1, q2) lies on its right, triangle 1 = (q0, q2, r2) on its left
+    // (diag 0: a, b, c, d; diag 1: b, c, d, a).  w1 -- triangle 0's coordinate of q1 times its doubled area, and minus
+    // triangle 1's coordinate of r2 -- vanishes on the diagonal, so its sign picks the ONE triangle that is evaluated: triangle 1
+    // when the position lies beyond the diagonal by more than triangle 0's own tolerance.  Both triangles share the products
+    // below up to sign (a - b == -(b - a) exactly), so each one's numbers are those of its own edge functions.
+    const D2 q0 = diag ? pb : pa, q1 = diag ? pc : pb, q2 = diag ? pd : pc, r2 = diag ? pa : pd;
+    const double e2x = q2.x - q0.x, e2y = q2.y - q0.y, dx = qx - q0.x, dy = qy - q0.y;
+    const double w1 = dx * e2y - dy * e2x;
+    const double e1x = q1.x - q0.x, e1y = q1.y - q0.y;
+    const double det0 = e1x * e2y - e1y * e2x;                          // > 0 (certificate)
+    const bool t = w1 < -(kEps * det0);
+    const double gx = t ? r2.x - q0.x : e1x, gy = t ? r2.y - q0.y : e1y;   // the edge q0 -> third vertex
+    double det = gx * e2y - gy * e2x, wq = gx * dy - gy * dx, wt = w1;  // x det: coordinates of q2 (wq) and of the third vertex (wt)
+    if (t) { det = -det; wq = -wq; wt = -wt; }
+    const bool in = fmin(det - wt - wq, fmin(wt, wq)) >= -(kEps * det);
     const double inv = rcp_newton(det);
-    const double c1 = w1 * inv, c2 = w2 * inv, c0 = 1.0 - c1 - c2;
+    const double c1 = wt * inv, c2 = wq * inv, c0 = 1.0 - c1 - c2;
+    const int i0 = diag, i1 = t ? (diag + 3) & 3 : diag + 1, i2 = diag + 2;      // corner numbers a = 0 ... d = 3
     const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
     const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
     const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
@@ -259,13 +249,12 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
         h.c0 = c0; h.c1 = c1; h.c2 = c2;
         return true;
     }
-    (void)t;
     ex = c0 * x0 + c1 * x1 + c2 * x2;                                  // Newton step: the triangle's affine map applied to the position
     ey = c0 * y0 + c1 * y1 + c2 * y2;
     return false;
 }
 
-template <int SP, bool BITS>      // the position (qx, qy) starts from the grid node (x, y) next to it (a grid node: itself)
+template <int SP, bool BITS, bool NODE = false>      // the position (qx, qy) starts from the grid node (x, y) next to it (NODE: it is that node)
 __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int H, int W, int x, int y, double qx, double qy, Hit &h,
                                             const WalkCert &wc)
 {
@@ -280,10 +269,11 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
     const float ja = 1.0f + (fxn.x - f0.x) * hx, jb = (fyn.x - f0.x) * hy;
     const float jc = (fxn.y - f0.y) * hx, jd = 1.0f + (fyn.y - f0.y) * hy;
     // residual of the node: P(node) - q
-    const float jdet = ja * jd - jb * jc, rx = sg * f0.x + (float)((double)x - qx), ry = sg * f0.y + (float)((double)y - qy);
+    const float jdet = ja * jd - jb * jc;
+    const float rx = NODE ? sg * f0.x : sg * f0.x + (float)((double)x - qx), ry = NODE ? sg * f0.y : sg * f0.y + (float)((double)y - qy);
     double ex = (double)x - (double)rx, ey = (double)y - (double)ry;
     if (fabsf(jdet) > 1e-3f) {
-        const float ij = 1.0f / jdet;
+        const float ij = __builtin_amdgcn_rcpf(jdet);                  // (1 ulp: an estimate)
         ex = (double)x - (double)((jd * rx - jb * ry) * ij);
         ey = (double)y - (double)((ja * ry - jc * rx) * ij);
     }
@@ -389,6 +379,17 @@ __device__ bool hull_band_locate(const float *__restrict__ flow, int sign, int H
     return inside_all;
 }
 
+// The same question for a grid node in float32, asked first: the plane form of the four distances costs a tenth of the
+// float64 cross products, and its limit leaves room for its rounding (set_planes), so "yes" here implies "yes" there; the
+// nodes in between fall through to the search and to hull_band_locate, which decides with the float64 distances as before.
+__device__ __forceinline__ bool clearly_outside32(const WalkCert &wc, float x, float y)
+{
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out |= fmaf(wc.pa[k], x, fmaf(wc.pb[k], y, wc.pc[k])) < wc.lim32;
+    return out;
+}
+
 #ifndef OFL_WALK_WAVES
 #define OFL_WALK_WAVES 5      // waves per SIMD the allocator leaves room for: the kernel is VALU-bound (5: 156 us, 7: 159 us, 8 spills: 246 us at 4K)
 #endif
@@ -406,8 +407,8 @@ void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ 
     Hit h;
     const int sign = SP;
     bool found = false;
-    if (!clearly_outside(wc, (double)x, (double)y)) {
-        found = walk_locate<SP, BITS>(flow, H, W, x, y, (double)x, (double)y, h, wc);
+    if (!clearly_outside32(wc, (float)x, (float)y)) {
+        found = walk_locate<SP, BITS, true>(flow, H, W, x, y, (double)x, (double)y, h, wc);
         if (!found) found = hull_band_locate(flow, sign, H, W, wc, (double)x, (double)y, h, fail);
     }
     if (found) {
@@ -458,6 +459,23 @@ void scatter_walk_query_kernel(const float *__restrict__ flow, const float *__re
 }  // namespace
 
 namespace ofl_sc {
+
+// float32 planes of the four hull sides for clearly_outside32.  With unit normals and |x|, |y| < W + H the float32
+// evaluation is off by less than (W + H + |pc|) * 2^-21 (coefficient rounding + two fused steps); the limit steps back by four
+// times that and a hundredth of a pixel.
+static void set_planes(WalkCert &wc, int H, int W)
+{
+    double worst = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        const D2 a = wc.c[k], b = wc.c[(k + 1) & 3];
+        const double A = -(b.y - a.y) * wc.inv_len[k], B = (b.x - a.x) * wc.inv_len[k], C = -(A * a.x + B * a.y);
+        wc.pa[k] = (float)A; wc.pb[k] = (float)B; wc.pc[k] = (float)C;
+        worst = fmax(worst, fabs(C));
+    }
+    const double slack = 4.0 * ((double)W + (double)H + worst) / 2097152.0 + 0.01;
+    wc.lim32 = (float)(-2.0 * wc.delta - slack);
+    if (!(wc.lim32 == wc.lim32)) wc.lim32 = -INFINITY;               // (never with a certificate: delta <= kBorderMax)
+}
 
 // host side of the certificate: launch, ONE small read-back, evaluation
 int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, int W, void *scratch128,
@@ -511,6 +529,7 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
         wc.inv_len[k] = 1.0 / sqrt(dx * dx + dy * dy);
     }
     wc.diag = cert->diag_bits; wc.diag_stride = (W + 31) / 32;
+    set_planes(wc, H, W);
     const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
     // (a variant that took flow-valued targets straight from the corner loads was measured SLOWER -- 168 vs 157 us at 4K:
     // its selects cost more registers than the three cached reloads it saved)
@@ -538,6 +557,7 @@ int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, 
         wc.inv_len[k] = 1.0 / sqrt(dx * dx + dy * dy);
     }
     wc.diag = nullptr; wc.diag_stride = 0;
+    set_planes(wc, H, W);
     if (n == 0) return OFL_OK;
     const size_t nb = (n + 255) / 256;
     const dim3 grid((unsigned)(nb < (1u << 20) ? nb : (1u << 20))), block(256);

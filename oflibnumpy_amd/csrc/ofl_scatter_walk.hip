@@ -180,6 +180,7 @@ void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint
 // ------------------------------------------------------------------------------------------------ walk
 struct Hit { uint32_t vi[3]; double c0, c1, c2; };
 
+
 struct __attribute__((aligned(8))) Pair2 { float lo_u, lo_v, hi_u, hi_v; };    // two adjacent vectors: ONE 16-byte load
 
 template <int SP>          // SP = sign with the point precision folded in: +-1 float64 positions, +-2 rounded to float32
@@ -204,10 +205,50 @@ __device__ __forceinline__ double rcp_newton(double d)
     return fma(x, r, x);
 }
 
+// The test of one source cell whose four warped corners (pa .. pd) and Delaunay diagonal are known.
+// The cell's diagonal runs q0 -> q2; triangle 0 = (q0, q1, q2) lies on its right, triangle 1 = (q0, q2, r2) on its left
+// (DIAG 0: a, b, c, d; DIAG 1: b, c, d, a).  w1 -- triangle 0's coordinate of q1 times its doubled area, and minus
+// triangle 1's coordinate of r2 -- vanishes on the diagonal, so its sign picks the ONE triangle that is evaluated: triangle 1
+// when the position lies beyond the diagonal by more than triangle 0's own tolerance.  Both triangles share the products
+// below up to sign (a - b == -(b - a) exactly), so each one's numbers are those of its own edge functions.
+// DIAG is a template argument because it is the same for every cell of an affine field and for whole regions of a smooth one:
+// the caller branches on it (uniform for almost every wave), and the sixteen selects of the corners disappear.
+template <int DIAG>
+__device__ __forceinline__ bool cell_core(const D2 &pa, const D2 &pb, const D2 &pc, const D2 &pd, int W, int cx, int cy,
+                                          double qx, double qy, Hit &h, double &ex, double &ey)
+{
+    const D2 q0 = DIAG ? pb : pa, q1 = DIAG ? pc : pb, q2 = DIAG ? pd : pc, r2 = DIAG ? pa : pd;
+    const double e2x = q2.x - q0.x, e2y = q2.y - q0.y, dx = qx - q0.x, dy = qy - q0.y;
+    const double w1 = dx * e2y - dy * e2x;
+    const double e1x = q1.x - q0.x, e1y = q1.y - q0.y;
+    const double det0 = e1x * e2y - e1y * e2x;                          // > 0 (certificate)
+    const bool t = w1 < -(kEps * det0);
+    const double gx = t ? r2.x - q0.x : e1x, gy = t ? r2.y - q0.y : e1y;   // the edge q0 -> third vertex
+    double det = gx * e2y - gy * e2x, wq = gx * dy - gy * dx, wt = w1;  // x det: coordinates of q2 (wq) and of the third vertex (wt)
+    if (t) { det = -det; wq = -wq; wt = -wt; }
+    const bool in = fmin(det - wt - wq, fmin(wt, wq)) >= -(kEps * det);
+    const double inv = rcp_newton(det);
+    const double c1 = wt * inv, c2 = wq * inv, c0 = 1.0 - c1 - c2;
+    constexpr int i0 = DIAG, i2 = DIAG + 2;                              // corner numbers a = 0 ... d = 3; corner k sits at
+    const int i1 = t ? (DIAG + 3) & 3 : DIAG + 1;                        // (cx + (((k + 1) >> 1) & 1), cy + (k >> 1))
+    const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
+    const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
+    const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
+    if (in) {
+        h.vi[0] = (uint32_t)y0 * (uint32_t)W + (uint32_t)x0; h.vi[1] = (uint32_t)y1 * (uint32_t)W + (uint32_t)x1;
+        h.vi[2] = (uint32_t)y2 * (uint32_t)W + (uint32_t)x2;
+        h.c0 = c0; h.c1 = c1; h.c2 = c2;
+        return true;
+    }
+    ex = c0 * x0 + c1 * x1 + c2 * x2;                                  // Newton step: the triangle's affine map applied to the position
+    ey = c0 * y0 + c1 * y1 + c2 * y2;
+    return false;
+}
+
 // Tests the two triangles of source cell (cx, cy) for the position (qx, qy) with SciPy's inclusion rule (division-free
 // edge functions; the certificate guarantees convex, positively oriented cells, so the Delaunay diagonal is one
-// in-circle sign).  On a miss the affine map of the less-missed triangle turns the position into a new estimate
-// (ex, ey) of its source index (a Newton step on the piecewise-affine map).
+// in-circle sign).  On a miss the affine map of the triangle on the position's side of the diagonal turns the position into
+// a new estimate (ex, ey) of its source index (a Newton step on the piecewise-affine map).
 template <int SP, bool BITS>
 __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, int cx, int cy,
                                          double qx, double qy, Hit &h, double &ex, double &ey, const WalkCert &wc)
@@ -222,36 +263,8 @@ __device__ __forceinline__ bool try_cell(const float *__restrict__ flow, int W, 
     int diag;
     if (BITS) diag = (int)((wc.diag[(size_t)cy * wc.diag_stride + (cx >> 5)] >> (cx & 31)) & 1u);
     else      diag = incircle_filtered(pa, pb, pc, pd) > 0 ? 1 : 0;
-    // The cell's diagonal runs q0 -> q2; triangle 0 = (q0, q1, q2) lies on its right, triangle 1 = (q0, q2, r2) on its left
-    // (diag 0: a, b, c, d; diag 1: b, c, d, a).  w1 -- triangle 0's coordinate of q1 times its doubled area, and minus
-    // triangle 1's coordinate of r2 -- vanishes on the diagonal, so its sign picks the ONE triangle that is evaluated: triangle 1
-    // when the position lies beyond the diagonal by more than triangle 0's own tolerance.  Both triangles share the products
-    // below up to sign (a - b == -(b - a) exactly), so each one's numbers are those of its own edge functions.
-    const D2 q0 = diag ? pb : pa, q1 = diag ? pc : pb, q2 = diag ? pd : pc, r2 = diag ? pa : pd;
-    const double e2x = q2.x - q0.x, e2y = q2.y - q0.y, dx = qx - q0.x, dy = qy - q0.y;
-    const double w1 = dx * e2y - dy * e2x;
-    const double e1x = q1.x - q0.x, e1y = q1.y - q0.y;
-    const double det0 = e1x * e2y - e1y * e2x;                          // > 0 (certificate)
-    const bool t = w1 < -(kEps * det0);
-    const double gx = t ? r2.x - q0.x : e1x, gy = t ? r2.y - q0.y : e1y;   // the edge q0 -> third vertex
-    double det = gx * e2y - gy * e2x, wq = gx * dy - gy * dx, wt = w1;  // x det: coordinates of q2 (wq) and of the third vertex (wt)
-    if (t) { det = -det; wq = -wq; wt = -wt; }
-    const bool in = fmin(det - wt - wq, fmin(wt, wq)) >= -(kEps * det);
-    const double inv = rcp_newton(det);
-    const double c1 = wt * inv, c2 = wq * inv, c0 = 1.0 - c1 - c2;
-    const int i0 = diag, i1 = t ? (diag + 3) & 3 : diag + 1, i2 = diag + 2;      // corner numbers a = 0 ... d = 3
-    const int x0 = cx + (((i0 + 1) >> 1) & 1), y0 = cy + (i0 >> 1);
-    const int x1 = cx + (((i1 + 1) >> 1) & 1), y1 = cy + (i1 >> 1);
-    const int x2 = cx + (((i2 + 1) >> 1) & 1), y2 = cy + (i2 >> 1);
-    if (in) {
-        h.vi[0] = (uint32_t)y0 * (uint32_t)W + (uint32_t)x0; h.vi[1] = (uint32_t)y1 * (uint32_t)W + (uint32_t)x1;
-        h.vi[2] = (uint32_t)y2 * (uint32_t)W + (uint32_t)x2;
-        h.c0 = c0; h.c1 = c1; h.c2 = c2;
-        return true;
-    }
-    ex = c0 * x0 + c1 * x1 + c2 * x2;                                  // Newton step: the triangle's affine map applied to the position
-    ey = c0 * y0 + c1 * y1 + c2 * y2;
-    return false;
+    if (diag) return cell_core<1>(pa, pb, pc, pd, W, cx, cy, qx, qy, h, ex, ey);
+    return cell_core<0>(pa, pb, pc, pd, W, cx, cy, qx, qy, h, ex, ey);
 }
 
 template <int SP, bool BITS, bool NODE = false>      // the position (qx, qy) starts from the grid node (x, y) next to it (NODE: it is that node)
@@ -279,7 +292,8 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
     }
     int pcx = -1, pcy = -1, ppcx = -2, ppcy = -2;
     for (int it = 0; it < kWalkIters; ++it) {
-        const int cx = (int)fmin(fmax(floor(ex), 0.0), (double)(W - 2)), cy = (int)fmin(fmax(floor(ey), 0.0), (double)(H - 2));
+        // (clamped first, so the truncating conversion is the floor; fmax sends a NaN to 0)
+        const int cx = (int)fmin(fmax(ex, 0.0), (double)(W - 2)), cy = (int)fmin(fmax(ey, 0.0), (double)(H - 2));
         if ((cx == pcx && cy == pcy) || (cx == ppcx && cy == ppcy)) break;      // no progress / a 2-cycle across an edge
         ppcx = pcx; ppcy = pcy; pcx = cx; pcy = cy;
         if (try_cell<SP, BITS>(flow, W, cx, cy, qx, qy, h, ex, ey, wc)) return true;
@@ -398,10 +412,27 @@ __global__ __launch_bounds__(256, OFL_WALK_WAVES)
 void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ vals, int C,
                          const uint8_t *__restrict__ vmask, int H, int W, int row0, int rows,
                          VT *__restrict__ out, uint8_t *__restrict__ valid, int valid_rule, WalkCert wc,
-                         uint32_t *__restrict__ fail)
+                         uint32_t *__restrict__ fail, int tiling)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int yl = blockIdx.y * 8 + (threadIdx.x >> 5), y = row0 + yl;
+    // tiling bit 1: tiles of 64 x 4 nodes instead of 32 x 8; bit 0: a 1-D grid whose workgroup b (XCD b % 8) takes tile
+    // (b % 8) * chunk + b / 8 -- every XCD sweeps ONE band of rows, so the halo lines of neighbouring tiles meet in one L2
+    const int tws = (tiling & 2) ? 6 : 5;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (tiling & 1) {
+        const int gx = (W + (1 << tws) - 1) >> tws, gy = (rows + (256 >> tws) - 1) / (256 >> tws);
+        const int rs = (tiling >> 2) & 3, xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        if (rs == 0) {                                           // one contiguous band of tiles per XCD
+            const int nb = gx * gy, chunk = (nb + 7) >> 3, tile = xcd * chunk + j;
+            if (j >= chunk || tile >= nb) return;
+            by = tile / gx; bx = tile - by * gx;
+        } else {                                                 // bands of 2^rs tile rows dealt round-robin to the XCDs, walked column by column
+            const int sr = (int)blockIdx.y, jj = j;              // (grid: 8 * (gx << rs) by rounds -- no division)
+            bx = jj >> rs; by = (((sr << 3) + xcd) << rs) + (jj & ((1 << rs) - 1));
+            if (by >= gy) return;
+        }
+    }
+    const int x = (bx << tws) + (threadIdx.x & ((1 << tws) - 1));
+    const int yl = by * (256 >> tws) + (threadIdx.x >> tws), y = row0 + yl;
     if (x >= W || yl >= rows) return;
     const size_t o = (size_t)yl * W + x;
     Hit h;
@@ -411,7 +442,27 @@ void scatter_walk_kernel(const float *__restrict__ flow, const VT *__restrict__ 
         found = walk_locate<SP, BITS, true>(flow, H, W, x, y, (double)x, (double)y, h, wc);
         if (!found) found = hull_band_locate(flow, sign, H, W, wc, (double)x, (double)y, h, fail);
     }
-    if (found) {
+    if (found && sizeof(VT) == 4 && C == 2 && !(valid_rule & OFL_SCATTER_ROUND) && (((uintptr_t)vals | (uintptr_t)out) & 7) == 0) {
+        // two-channel float32 values (flow fields: every scatter of the Flow algebra): resolve_emit's arithmetic on 8-byte loads
+        // and one 8-byte store; the negation (exact) is a sign flip of the rounded result
+        const float2 *v2 = reinterpret_cast<const float2 *>(vals);
+        const float2 a = v2[h.vi[0]], b = v2[h.vi[1]], c = v2[h.vi[2]];
+        const double vu = h.c0 * (double)a.x + h.c1 * (double)b.x + h.c2 * (double)c.x;
+        const double vv = h.c0 * (double)a.y + h.c1 * (double)b.y + h.c2 * (double)c.y;
+        const uint32_t flip = (valid_rule & OFL_SCATTER_NEGATE) ? 0x80000000u : 0u;
+        float2 r;
+        r.x = __uint_as_float(__float_as_uint((float)vu) ^ flip);
+        r.y = __uint_as_float(__float_as_uint((float)vv) ^ flip);
+        reinterpret_cast<float2 *>(out)[o] = r;
+        if (valid) {
+            double m;
+            if (vmask) m = h.c0 * (double)(vmask[h.vi[0]] != 0) + h.c1 * (double)(vmask[h.vi[1]] != 0) + h.c2 * (double)(vmask[h.vi[2]] != 0);
+            else       m = h.c0 + h.c1 + h.c2;
+            const float mf = (float)m;
+            const int vr = valid_rule & 3;
+            valid[o] = vr == 0 ? (mf == 1.0f) : (vr == 1 ? (m > 0.99) : (rint(m) == 1.0));
+        }
+    } else if (found) {
         const size_t vi[3] = { h.vi[0], h.vi[1], h.vi[2] };
         resolve_emit(vals, C, vmask, vi, h.c0, h.c1, h.c2, valid_rule, out, valid, o);
     } else {
@@ -530,14 +581,19 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
     }
     wc.diag = cert->diag_bits; wc.diag_stride = (W + 31) / 32;
     set_planes(wc, H, W);
-    const dim3 grid((W + 31) / 32, (rows + 7) / 8), block(256);
-    // (a variant that took flow-valued targets straight from the corner loads was measured SLOWER -- 168 vs 157 us at 4K:
-    // its selects cost more registers than the three cached reloads it saved)
+    const int tiling = OFL_KNOB_INT("OFL_WALK_TILING", 0);
+    const int tws = (tiling & 2) ? 6 : 5, gx = (W + (1 << tws) - 1) >> tws, gy = (rows + (256 >> tws) - 1) / (256 >> tws);
+    const int rs = (tiling >> 2) & 3, bands = ((gy + (1 << rs) - 1) >> rs), rounds = (bands + 7) / 8;
+    const dim3 grid(!(tiling & 1) ? gx : rs == 0 ? 8 * (((size_t)gx * gy + 7) / 8) : (size_t)8 * (gx << rs), !(tiling & 1) ? gy : rs == 0 ? 1 : rounds), block(256);
+    // (a variant that took flow-valued targets -- invert, switch_ref -- and their mask bytes straight from the registers of the
+    // cell test was measured SLOWER twice, in round 2 (168 vs 157 us at 4K) and again on this leaner kernel (85 vs 77 us): keeping
+    // the corner loads alive to the end costs 30 VGPRs, more than the three cached reloads it saves; fetching only the corners'
+    // mask bytes with the cell -- 6 VGPRs -- changed nothing: 78.7 vs 78.2 us)
 #define OFL_WALK_LAUNCH(SP)                                                                                                       \
     do { if (wc.diag) hipLaunchKernelGGL((scatter_walk_kernel<VT, SP, true>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, \
-                                         out, valid, valid_rule, wc, fail_dev);                                                          \
+                                         out, valid, valid_rule, wc, fail_dev, tiling);                                                  \
          else hipLaunchKernelGGL((scatter_walk_kernel<VT, SP, false>), grid, block, 0, s, flow, vals, C, vmask, H, W, row0, rows, out,  \
-                                 valid, valid_rule, wc, fail_dev); } while (0)
+                                 valid, valid_rule, wc, fail_dev, tiling); } while (0)
     if (sign_pp == 1) OFL_WALK_LAUNCH(1); else if (sign_pp == -1) OFL_WALK_LAUNCH(-1);
     else if (sign_pp == 2) OFL_WALK_LAUNCH(2); else OFL_WALK_LAUNCH(-2);
 #undef OFL_WALK_LAUNCH

@@ -22,6 +22,8 @@ def main():
     f = of.Flow.from_transforms([['rotation', w / 2, h / 2, -20], ['scaling', w / 3.84, h / 2.7, 0.9]], [h, w], 's')
     if args.op in ("invert", "switch"):
         d = of.Flow.from_transforms([['scaling', 1000, 800, 0.9]], [h, w], 's').to_device()
+    elif args.op == "invert_rot":                            # a certified mesh whose source cells lie along rotated rows
+        d = f.to_device()
     elif args.op == "speckle":
         m = np.random.default_rng(0).random((h, w)) > 0.05
         d = dev.DeviceFlow.from_host(f.vecs, 's', m)
@@ -63,6 +65,9 @@ def main():
         raise SystemExit("unknown op")
     d.stats()
     fn = (lambda: d.switch_ref()) if args.op == "switch" else (lambda: d.invert())
+    if args.op == "invert_rot":
+        fn()
+        assert d._certs and all(c.certified for c in d._certs.values()), "the rotated field was expected to take the certified walk"
     t = timed(fn, args.iters)
     report(args.op, (h, w), 18, *t)
 

@@ -569,6 +569,53 @@ print("lds-variant-ok")
         assert p.returncode == 0 and "lds-variant-ok" in p.stdout, (variant, p.stderr[-2000:])
 
 
+def test_general_gather_kernel_and_walk_tilings_in_subprocess(gpu):
+    """What the product library runs by default has a twin in the EXPERIMENTS build: the paired gather kernel WITHOUT the folded
+    (quantisation, arithmetic, rule) instantiations (OFL_G2_SPEC=0: one kernel for every combination, as before round 4), and the
+    certified walk with XCD-banded tile orders / 64 x 4 tiles (OFL_WALK_TILING).  Same bits as the oracle ('t') and as the default
+    order ('s', whose values the oracle pins to 1e-4 only): 8-bit, 16-bit and float images, 1 - 4 channels, with and without a mask."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import oflibnumpy_amd as of
+from oracle import np_oracle as O
+rng = np.random.default_rng(8)
+shape = (131, 258)
+tm = rng.random(shape) > 0.1
+f = of.Flow.from_transforms([['rotation', 100, 60, 17], ['scaling', 100, 60, 0.9]], list(shape), 't', rng.random(shape) > 0.05)
+o = O.OFlow(f.vecs, 't', f.mask)
+for dtype in (np.uint8, np.int16, np.float32):
+    for C in (1, 2, 3, 4):
+        img = (rng.random(shape + (C,)) * 255).astype(dtype)
+        for mask in (None, tm):
+            got, gv = f.apply(img, mask, return_valid_area=True)
+            want, wv = o.apply(img, mask, return_valid_area=True)
+            assert np.array_equal(got, want) and np.array_equal(gv, wv), (dtype, C, mask is None)
+fs = of.Flow.from_transforms([['rotation', 100, 60, 17], ['scaling', 100, 60, 0.9]], [200, 330], 's')
+inv = fs.invert()
+sw = fs.switch_ref()
+np.save(os.environ['OFL_TEST_OUT'], np.concatenate([inv.vecs.ravel(), inv.mask.ravel().astype(np.float32), sw.vecs.ravel(), sw.mask.ravel().astype(np.float32)]))
+print("twin-ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from oflibnumpy_amd import build_native
+    import tempfile
+    if not os.path.exists(build_native.EXP_OUT):
+        build_native.build_experiments()
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, (spec, tiling) in enumerate((("1", "0"), ("0", "5"), ("1", "13"), ("0", "1"), ("1", "7"))):
+            out = os.path.join(tmp, "o%d.npy" % k)
+            env = dict(os.environ, OFL_G2_SPEC=spec, OFL_WALK_TILING=tiling, OFL_LIB=build_native.EXP_OUT, OFL_TEST_OUT=out)
+            p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+            assert p.returncode == 0 and "twin-ok" in p.stdout, (spec, tiling, p.stderr[-2000:])
+            outs.append(np.load(out))
+    for o2 in outs[1:]:
+        np.testing.assert_array_equal(outs[0], o2)
+
+
 def test_device_resident_image_warp(gpu, oracle):
     """DeviceFlow.apply with an HBM-resident image (no PCIe between operations): 't' for uint8 / float32 with and
     without a target mask, 's' for float32, against the host API (which is pinned against the oracle above)."""

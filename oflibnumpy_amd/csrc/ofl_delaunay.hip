@@ -44,7 +44,10 @@ namespace {
 
 constexpr int      kRings    = 6;        // bucket rings of the per-thread star pass
 constexpr int      kOpenRings = 2;       // ... of which a cell still unbounded after this many is handed on at once
-constexpr int      kNearCap  = 12;       // polygon capacity of the per-thread pass (float32 cell in LDS)
+#ifndef OFL_NEAR_CAP
+#define OFL_NEAR_CAP 10
+#endif
+constexpr int      kNearCap  = OFL_NEAR_CAP;       // polygon capacity of the per-thread pass (float32 cell in LDS)
 constexpr int      kSlots    = 16;       // neighbour slots per point
 constexpr int      kNear2Rings = 6;      // coarse rings of the second per-thread pass ...
 constexpr unsigned kNear2MinPoints = 32768;   // unfinished points below which the second per-thread pass is skipped
@@ -841,8 +844,11 @@ void dl_star_fan_kernel(const float *__restrict__ flow, int sign, const uint8_t 
 // schedules for BASELINE config 5, whose source rows scatter over hundreds of buckets: one wave per 8 x 8 bucket tile -- half
 // empty waves, 24 -> 46 ms -- and a list compacted in bucket order -- no change: the pass is bound by the divergent clip
 // code of its 64 lanes, not by where the candidates come from.)
+#ifndef OFL_NEAR_WAVES
+#define OFL_NEAR_WAVES 5      // measured (product flags, same box): 4 waves per SIMD (116 VGPRs, cells of 12) config 5 22.88 ms, 5 waves (96 VGPRs + 9 spilled,
+#endif                        // cells of 10: 7 680 B of LDS per wave) 21.86 ms, 6 waves (80 + 18 spilled, cells of 8) 22.69 ms; cells of 10 at 4 waves: 22.90 ms
 template <bool HEAVY>       // false: every site of the list; true (a second launch, at once over when no bucket is heavy): the sites the first one marked kDegHeavy
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, HEAVY ? 1 : OFL_NEAR_WAVES)
 void dl_star_near_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, const unsigned char *__restrict__ dup, int H, int W,
                          const DlHead *__restrict__ head, const unsigned *__restrict__ todo,
                          const unsigned *__restrict__ bstart,

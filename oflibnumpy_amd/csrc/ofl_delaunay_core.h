@@ -390,6 +390,9 @@ int apply_heavy_run(PolyX &P, int p, const P2 &pp, int row, int x0, int x1, cons
 // leaves the star to the HEAVY instantiation (a launch of its own, only for such sites): the few hundred lines of the heavy search,
 // a call that is not inlined and a polygon whose address escapes cost the ordinary clip pass half its speed when they sat in it.
 template <bool HEAVY = false, class PolyX, class PosFn>
+#ifndef OFL_RING_W
+#define OFL_RING_W 4
+#endif
 DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const Grid &g,
                      const unsigned *bstart, const unsigned *sorted, PosFn pos, double &reach2,
                      const P2 *sorted_xy = nullptr,          // positions in `sorted` order (one contiguous read per run) or null
@@ -435,22 +438,22 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
         unsigned nlo = 0, nhi = 0;
         if (seg + 1 < nseg) bounds(seg + 1, nlo, nhi);
         DL_DBG(6, hi - lo);
-        for (unsigned j = lo; j < hi; j += 4) {
-            // four candidates at a time: their indices, then their positions, are in flight together
-            int c[4];
-            P2  q[4];
+        for (unsigned j = lo; j < hi; j += OFL_RING_W) {
+            // a few candidates at a time: their indices, then their positions, are in flight together
+            int c[OFL_RING_W];
+            P2  q[OFL_RING_W];
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-            for (int k = 0; k < 4; ++k) c[k] = j + k < hi ? (int)sorted[j + k] : -1;
+            for (int k = 0; k < OFL_RING_W; ++k) c[k] = j + k < hi ? (int)sorted[j + k] : -1;
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-            for (int k = 0; k < 4; ++k) q[k] = c[k] >= 0 ? (sorted_xy ? sorted_xy[j + k] : pos(c[k])) : pp;
+            for (int k = 0; k < OFL_RING_W; ++k) q[k] = c[k] >= 0 ? (sorted_xy ? sorted_xy[j + k] : pos(c[k])) : pp;
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < OFL_RING_W; ++k) {
                 if (c[k] < 0 || c[k] == p) continue;
                 const P2 C = { q[k].x - pp.x, q[k].y - pp.y };
                 const double d2 = C.x * C.x + C.y * C.y;

@@ -198,7 +198,8 @@ __device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned &total)
 
 // ------------------------------------------------------------------------------------------------ binning
 __global__ __launch_bounds__(256)
-void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W, DlHead *head)
+void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
+                    unsigned long long *__restrict__ partial)      // [workgroups][5]: keys of min x, max x, min y, max y; points kept
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
@@ -219,7 +220,9 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
         y1 = fmax(y1, __hiloint2double(__shfl_xor(__double2hiint(y1), off), __shfl_xor(__double2loint(y1), off)));
         cnt += (unsigned)__shfl_xor((int)cnt, off);
     }
-    // one set of atomics per workgroup (thousands of waves on five addresses serialise at the memory side)
+    // One record per workgroup, reduced by dl_params_kernel.  (Atomics on the header -- five per workgroup, then one set per
+    // workgroup -- are executed one after the other at the memory side: a thousand workgroups spent 50 of this kernel's 67 us
+    // at 4K queueing for ONE cache line, and twice the workgroups took twice as long.)
     __shared__ double s_b[4][4];
     __shared__ unsigned s_c[4];
     const int w = threadIdx.x >> 6;
@@ -228,11 +231,8 @@ void dl_bbox_kernel(const float *__restrict__ flow, int sign, const uint8_t *__r
     if (threadIdx.x == 0) {
         unsigned c = 0;
         for (int k = 0; k < 4; ++k) { x0 = fmin(x0, s_b[0][k]); x1 = fmax(x1, s_b[1][k]); y0 = fmin(y0, s_b[2][k]); y1 = fmax(y1, s_b[3][k]); c += s_c[k]; }
-        if (c) {
-            atomicMin(&head->kx0, okey(x0)); atomicMax(&head->kx1, okey(x1));
-            atomicMin(&head->ky0, okey(y0)); atomicMax(&head->ky1, okey(y1));
-            atomicAdd(&head->kept, c);
-        }
+        unsigned long long *rec = partial + 5 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        rec[0] = c ? okey(x0) : ~0ull; rec[1] = c ? okey(x1) : 0ull; rec[2] = c ? okey(y0) : ~0ull; rec[3] = c ? okey(y1) : 0ull; rec[4] = c;
     }
 }
 
@@ -243,8 +243,33 @@ __host__ __device__ inline unsigned slab_stamp_of(int H, int W, int row0, int ro
     return v ? v : 1u;
 }
 
-__global__ void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale, int H, int W, int slab, int row0, int rows)
+__global__ __launch_bounds__(256)
+void dl_params_kernel(DlHead *head, unsigned long long bcap, double bucket_scale, int H, int W, int slab, int row0, int rows,
+                      const unsigned long long *__restrict__ partial, unsigned n_partial)
 {
+    {   // the bounding box and the number of kept points from dl_bbox_kernel's records
+        unsigned long long k0 = ~0ull, k1 = 0ull, k2 = ~0ull, k3 = 0ull, c = 0ull;
+        for (unsigned i = threadIdx.x; i < n_partial; i += 256) {
+            const unsigned long long *rec = partial + 5 * (size_t)i;
+            k0 = rec[0] < k0 ? rec[0] : k0; k1 = rec[1] > k1 ? rec[1] : k1;
+            k2 = rec[2] < k2 ? rec[2] : k2; k3 = rec[3] > k3 ? rec[3] : k3; c += rec[4];
+        }
+        __shared__ unsigned long long s_k[5][256];
+        s_k[0][threadIdx.x] = k0; s_k[1][threadIdx.x] = k1; s_k[2][threadIdx.x] = k2; s_k[3][threadIdx.x] = k3; s_k[4][threadIdx.x] = c;
+        __syncthreads();
+        for (int half = 128; half > 0; half >>= 1) {
+            if ((int)threadIdx.x < half) {
+                const int t = threadIdx.x, u = t + half;
+                s_k[0][t] = s_k[0][u] < s_k[0][t] ? s_k[0][u] : s_k[0][t]; s_k[1][t] = s_k[1][u] > s_k[1][t] ? s_k[1][u] : s_k[1][t];
+                s_k[2][t] = s_k[2][u] < s_k[2][t] ? s_k[2][u] : s_k[2][t]; s_k[3][t] = s_k[3][u] > s_k[3][t] ? s_k[3][u] : s_k[3][t];
+                s_k[4][t] += s_k[4][u];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x != 0) return;
+        k0 = s_k[0][0]; k1 = s_k[1][0]; k2 = s_k[2][0]; k3 = s_k[3][0]; c = s_k[4][0];
+        head->kx0 = k0; head->kx1 = k1; head->ky0 = k2; head->ky1 = k3; head->kept = (unsigned)c;
+    }
     Grid g;
     g.ox = 0.0; g.oy = 0.0; g.s = 1.0; g.inv_s = 1.0; g.gx = 1; g.gy = 1;
     const unsigned n = head->kept;
@@ -2478,9 +2503,12 @@ int exact_stars(const float *flow, int sign_pp, const uint8_t *pmask, int H, int
     OFL_HIP(hipMemcpyAsync(ws.head, &init, sizeof(init), hipMemcpyHostToDevice, s));
     OFL_HIP(hipMemsetAsync(ws.bstart, 0, (ws.bcap + 1) * 4, s));
     const unsigned nblk = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(dl_bbox_kernel, dim3((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 1024 / ((W + 31) / 32) + 1))), dim3(256), 0, s, flow, sign_pp, pmask, H, W, ws.head);
+    const dim3 bgrid((W + 31) / 32, std::max(1, std::min((H + 7) / 8, 4096 / ((W + 31) / 32) + 1)));
+    unsigned long long *partial = (unsigned long long *)ws.pool;        // (the neighbour pool is free until the cooperative passes; 8 n + 65 536 words)
+    hipLaunchKernelGGL(dl_bbox_kernel, bgrid, dim3(256), 0, s, flow, sign_pp, pmask, H, W, partial);
     static const double bucket_scale = OFL_KNOB_DOUBLE("OFL_DL_BUCKET", 1.0);      // development knob (experiments build only)
-    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(1), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W, slab ? 1 : 0, row0, rows);
+    hipLaunchKernelGGL(dl_params_kernel, dim3(1), dim3(256), 0, s, ws.head, (unsigned long long)ws.bcap, bucket_scale, H, W, slab ? 1 : 0, row0, rows,
+                       (const unsigned long long *)partial, bgrid.x * bgrid.y);
     OFL_HIP(hipMemsetAsync(ws.dup, 0, n, s));
     hipLaunchKernelGGL(dl_count_kernel, dim3(nblk), dim3(256), 0, s, flow, sign_pp, pmask, H, W, (const DlHead *)ws.head, ws.bstart, ws.dup,
                        ws.todo_idx);                                     // (the fan pass's list is free until the cells are done)

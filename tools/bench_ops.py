@@ -221,6 +221,12 @@ def sec_config3(it):
     t = timed([(lambda d=d: d.invert()) for d in d2s], max(it, 12))
     yield entry("c3_invert_4k", "invert s->s (K3)", (h, w), 18, *t, kernel="scatter_walk_kernel",
                 note="BASELINE config 3; certified mesh: one kernel, no synchronisation (reference: scipy griddata, 64 s at 1080p on 1 core, SURVEY 6)")
+    def fresh(d):                    # a field seen for the first time: its mesh certificate (one pass + one 144-byte read-back) is part of the call
+        d._certs.clear()
+        return d.invert()
+    t = timed([(lambda d=d: fresh(d)) for d in d2s], max(it, 12))
+    yield entry("c3_invert_4k_fresh", "invert s->s of a field seen for the first time (certificate + K3)", (h, w), 18 + 9, *t,
+                kernel="scatter_certify_kernel + scatter_walk_kernel", note="the certificate reads the field once more and writes one bit per cell; it is cached per field afterwards (c3_invert_4k)")
     t = timed([(lambda a=a, b=b: a.combine_with(b, 1)) for a, b in zip(d2s, d3s)], max(6, it // 2))
     yield entry("c3_mode1_s_4k", "combine_with mode 1 's' (K3 + 2 x K2 + epilogue)", (h, w), 72, *t,
                 kernel="scatter_walk_kernel + 2 x compose3_xpose_kernel + axpy_kernel", note="BASELINE config 3")

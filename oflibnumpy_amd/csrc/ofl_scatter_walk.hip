@@ -534,7 +534,13 @@ int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, in
 {
     memset(cert, 0, sizeof(*cert));
     if (H < 2 || W < 2) return OFL_OK;                                   // no cells: never certified
-    CertDev init;
+    // the record travels through a pinned staging buffer of the calling thread (two halves: the initial values up, the result down):
+    // copies from / to pageable memory go through the runtime's own bounce buffers and cost this call -- a kernel, a read-back,
+    // a synchronisation -- a third of its 60 us of host time
+    static thread_local char *pinned = nullptr;
+    if (!pinned) { void *h = nullptr; if (hipHostMalloc(&h, 512, hipHostMallocDefault) == hipSuccess) pinned = (char *)h; else (void)hipGetLastError(); }
+    CertDev init_stack;
+    CertDev &init = pinned ? *reinterpret_cast<CertDev *>(pinned) : init_stack;
     memset(&init, 0, sizeof(init));
     for (int k = 0; k < 4; ++k) { init.dev_min[k] = ~0ull; init.dev_max[k] = 0ull; }
     CertDev *dev = (CertDev *)scratch128;
@@ -545,7 +551,8 @@ int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, in
     hipLaunchKernelGGL(scatter_certify_kernel, grid, block, 0, s, flow, sign_pp, pmask, H, W, dev, diag_bits, (W + 31) / 32);
     cert->diag_bits = diag_bits;
     OFL_HIP(hipGetLastError());
-    CertDev r;
+    CertDev r_stack;
+    CertDev &r = pinned ? *reinterpret_cast<CertDev *>(pinned + 256) : r_stack;
     OFL_HIP(hipMemcpyAsync(&r, dev, sizeof(r), hipMemcpyDeviceToHost, s));
     OFL_HIP(hipStreamSynchronize(s));
     cert->folded_cells = r.folded;

@@ -57,15 +57,16 @@ __device__ __forceinline__ double shfl_xor_d(double v, int off)
     return __hiloint2double(hi, lo);
 }
 
-// in-circle determinant of d against the positively oriented triangle (a, b, c), divided by the fourth power of the
-// local length scale: > 0 when d is inside the circumcircle
-__device__ __forceinline__ double incircle_rel(const D2 &a, const D2 &b, const D2 &c, const D2 &d)
+// Is d inside the circumcircle of the positively oriented triangle (a, b, c) by more than `tol` times the fourth power of the local
+// length scale?  (The in-circle determinant against tol * s^2 -- the quotient it stands for costs a float64 division, thirty-five
+// instructions of a kernel that is bound by them.)
+__device__ __forceinline__ bool incircle_beyond(const D2 &a, const D2 &b, const D2 &c, const D2 &d, double tol)
 {
     const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
     const double a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
     const double ic = ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx);
     const double s = a2 + b2 + c2;
-    return s > 0.0 ? ic / (s * s) : 0.0;
+    return s > 0.0 && ic > tol * (s * s);
 }
 
 __device__ __forceinline__ void tri_pts(int diag, int t, const D2 &pa, const D2 &pb, const D2 &pc, const D2 &pd,
@@ -74,6 +75,14 @@ __device__ __forceinline__ void tri_pts(int diag, int t, const D2 &pa, const D2 
     int i0, i1, i2;
     tri_corners(diag, t, i0, i1, i2);
     q0 = pick4(i0, pa, pb, pc, pd); q1 = pick4(i1, pa, pb, pc, pd); q2 = pick4(i2, pa, pb, pc, pd);
+}
+
+// pick_diagonal for a cell that is convex and positively oriented.  The certificate asks it for a cell's right and lower
+// NEIGHBOUR (which vertex faces the shared edge): a neighbour that is not convex is counted as folded by its own thread and voids
+// the certificate whatever is decided here.
+__device__ __forceinline__ int diag_if_convex(const D2 &a, const D2 &b, const D2 &c, const D2 &d)
+{
+    return incircle_filtered(a, b, c, d) > 0 ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ certificate
@@ -105,18 +114,18 @@ void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint
             // neighbours on that side; edges on the image border have no second triangle.
             if (x + 2 < W) {
                 const D2 pb2 = point_of(flow, sign, W, x + 2, y), pc2 = point_of(flow, sign, W, x + 2, y + 1);
-                const int dr = pick_diagonal(pb, pb2, pc2, pc);
+                const int dr = diag_if_convex(pb, pb2, pc2, pc);
                 const D2 opp = dr == 0 ? pc2 : pb2;                       // (a', c', d') or (b', d', a') holds the edge d'-a'
                 // this cell's triangle on the edge b-c: diag 0 -> (a, b, c) = triangle 0; diag 1 -> (b, c, d) = triangle 0
-                if (incircle_rel(u0, u1, u2, opp) > kEdgeTol) bad += 1;
+                if (incircle_beyond(u0, u1, u2, opp, kEdgeTol)) bad += 1;
             }
             if (y + 2 < H) {
                 const D2 pd2 = point_of(flow, sign, W, x, y + 2), pc3 = point_of(flow, sign, W, x + 1, y + 2);
-                const int db = pick_diagonal(pd, pc, pc3, pd2);
+                const int db = diag_if_convex(pd, pc, pc3, pd2);
                 const D2 opp = db == 0 ? pc3 : pd2;                       // (a", b", c") or (b", d", a") holds the edge a"-b"
                 // this cell's triangle on the edge c-d: diag 0 -> (a, c, d) = triangle 1; diag 1 -> (b, c, d) = triangle 0
                 const bool t1 = diag == 0;
-                if (incircle_rel(t1 ? v0 : u0, t1 ? v1 : u1, t1 ? v2 : u2, opp) > kEdgeTol) bad += 1;
+                if (incircle_beyond(t1 ? v0 : u0, t1 ? v1 : u1, t1 ? v2 : u2, opp, kEdgeTol)) bad += 1;
             }
         }
     }

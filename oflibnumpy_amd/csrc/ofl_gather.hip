@@ -1215,6 +1215,107 @@ __device__ __forceinline__ void gather_px(const T *__restrict__ src, const uint8
     }
 }
 
+// ---- the all-inside path in two phases: every pixel's loads are issued before the first pixel is blended ----
+// gather_px asks for a pixel's taps and blends them at once; four pixels of a lane one after the other are four dependent
+// rounds of loads behind the round of the flow itself (PMC: a wave of the 8-bit kernel lives 11.9 us for 2 000 cycles of
+// instructions, 70 % of it waiting; six waves per SIMD cannot hide five rounds of 2.3 us).  For a wave whose taps are all inside
+// the source -- nearly every wave -- the loads need no predication: px_load asks for all of them, px_blend is gather_px's
+// arithmetic on what they return.  Same values, same operations, same order per pixel: the same bits.
+template <typename T, int CT> struct PxRun { static constexpr bool value = sizeof(T) <= 2 || (sizeof(T) == 4 && CT <= 2); };
+
+template <typename T, int CT>
+struct PxLoad {
+    uint32_t run[2][4];                              // PxRun: the two taps of a row as one run of 2 * CT elements
+    typename Acc<T>::type v[PxRun<T, CT>::value ? 1 : 4][PxRun<T, CT>::value ? 1 : CT];      // otherwise: tap by tap
+    uint32_t m01, m23;                               // the source mask's two bytes per row
+};
+
+template <typename T, int CT, bool WIDE>        // WIDE: 6- and 12-byte runs may be read as 8 / 16 bytes (the caller checked the image's end)
+__device__ __forceinline__ void px_load(const T *__restrict__ src, const uint8_t *__restrict__ smask, int W, int ix, int iy,
+                                        bool want_valid, PxLoad<T, CT> &L)
+{
+    const uint32_t off0 = __umul24((uint32_t)iy, (uint32_t)W) + (uint32_t)ix, off2 = off0 + (uint32_t)W;
+    L.m01 = L.m23 = 0x0101u;
+    if (want_valid && smask) {
+        L.m01 = *reinterpret_cast<const uint16_t *>(smask + off0);
+        L.m23 = *reinterpret_cast<const uint16_t *>(smask + off2);
+    }
+    if constexpr (PxRun<T, CT>::value) {
+        constexpr int kRB = 2 * CT * (int)sizeof(T);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            L.run[r][0] = L.run[r][1] = L.run[r][2] = L.run[r][3] = 0u;
+            const uint8_t *pr = reinterpret_cast<const uint8_t *>(src) + (r ? off2 : off0) * (uint32_t)(CT * sizeof(T));
+            if constexpr ((kRB == 6 || kRB == 12) && WIDE) load_run<kRB + kRB / 3>(pr, L.run[r]);
+            else load_run<kRB>(pr, L.run[r]);
+        }
+    } else {
+        typedef typename Acc<T>::type A;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T *t = src + ((k >> 1) ? off2 : off0) * (uint32_t)CT + (uint32_t)((k & 1) * CT);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) L.v[k][c] = (A)t[c];
+        }
+    }
+}
+
+template <typename T, int CT>
+__device__ __forceinline__ void px_blend(const PxLoad<T, CT> &L, const Tap &tp, const int (&wi)[4], bool fixed_u8, bool sep, int arith, int rule,
+                                         bool want_valid, T (&res)[CT], bool &ok)
+{
+    typedef typename Acc<T>::type A;
+    const int m[4] = { (L.m01 & 0xffu) != 0, (L.m01 & 0xff00u) != 0, (L.m23 & 0xffu) != 0, (L.m23 & 0xff00u) != 0 };
+    bool done_sep = false;
+    if constexpr (PxRun<T, CT>::value && sizeof(T) == 1) {
+        if (fixed_u8 && sep) {                       // (gather_px: the separable fixed-point form)
+            const uint32_t wx = (uint32_t)(32 - tp.ax) | ((uint32_t)tp.ax << 8);
+            const int wy0 = 32 - tp.ay, wy1 = tp.ay;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                constexpr uint32_t kZero = 0x0C0C0000u;
+                const uint32_t sel = kZero | (uint32_t)c | ((uint32_t)(CT + c) << 8);
+                const uint32_t t0 = __builtin_amdgcn_perm(L.run[0][1], L.run[0][0], sel), t1 = __builtin_amdgcn_perm(L.run[1][1], L.run[1][0], sel);
+                const uint32_t h0 = __builtin_amdgcn_udot4(t0, wx, 0u, false), h1 = __builtin_amdgcn_udot4(t1, wx, 0u, false);
+                res[c] = (T)((__umul24(h0, (uint32_t)wy0) + __umul24(h1, (uint32_t)wy1) + 512u) >> 10);
+            }
+            done_sep = true;
+        }
+    }
+    if (!done_sep) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            A v[4];
+            if constexpr (PxRun<T, CT>::value) {
+                v[0] = (A)run_elem<T>(L.run[0], c); v[1] = (A)run_elem<T>(L.run[0], CT + c);
+                v[2] = (A)run_elem<T>(L.run[1], c); v[3] = (A)run_elem<T>(L.run[1], CT + c);
+            } else {
+                v[0] = L.v[0][c]; v[1] = L.v[1][c]; v[2] = L.v[2][c]; v[3] = L.v[3][c];
+            }
+            if constexpr (sizeof(T) == 8) {
+                res[c] = (T)blend4d(v[0], v[1], v[2], v[3], tp);
+            } else {
+                if (fixed_u8) {
+                    const int acc = __mul24((int)v[0], wi[0]) + __mul24((int)v[1], wi[1]) + __mul24((int)v[2], wi[2]) + __mul24((int)v[3], wi[3]);
+                    res[c] = (T)min(max((acc + (1 << 14)) >> 15, 0), 255);
+                } else {
+                    res[c] = finish<T>(blend4((float)v[0], (float)v[1], (float)v[2], (float)v[3], tp), arith);
+                }
+            }
+        }
+    }
+    ok = false;
+    if (want_valid) {
+        if (rule == OFL_RULE_GE_HALF) {
+            const int acc = __mul24(m[0], wi[0]) + __mul24(m[1], wi[1]) + __mul24(m[2], wi[2]) + __mul24(m[3], wi[3]);
+            ok = ((acc + (1 << 14)) >> 15) == 1;
+        } else {
+            const float sm = blend4((float)m[0], (float)m[1], (float)m[2], (float)m[3], tp);
+            ok = (rule == OFL_RULE_EQ1) ? (sm == 1.0f) : (cv_round(sm) == 1);
+        }
+    }
+}
+
 // taps, gather and blend of four pixels (gx[j], y) of one lane; wave-uniform all-outside / all-inside / border paths
 template <typename T, int CT>
 __device__ __forceinline__ void gather2_core(const T *__restrict__ src, const uint8_t *__restrict__ smask, int H, int W,
@@ -1254,9 +1355,42 @@ __device__ __forceinline__ void gather2_core(const T *__restrict__ src, const ui
 #pragma unroll
         for (int c = 0; c < CT; ++c) res[j][c] = (T)0;
     }
-    if (__all(outside)) {
+    const bool all_outside = __all(outside), all_inside = !all_outside && __all(inside);
+    if (all_outside) {
         // nothing to fetch: every tap of every pixel of this wave is outside the source
-    } else if (__all(inside)) {
+    } else if (all_inside && sizeof(T) < 8) {
+        // (float64 images keep the one-pixel-at-a-time form: their taps alone are 4 * CT * 2 registers per pixel)
+        constexpr int kRB = 2 * CT * (int)sizeof(T);
+        constexpr bool kPadded = PxRun<T, CT>::value && (kRB == 6 || kRB == 12);
+        bool wide = true;                            // may every 6- / 12-byte run of this lane be read as 8 / 16 bytes?
+        if constexpr (kPadded) {
+            const uint32_t total = (uint32_t)H * (uint32_t)W * (uint32_t)(CT * sizeof(T));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (act4[j]) wide = wide && (__umul24((uint32_t)(tp[j].iy + 1), (uint32_t)W) + (uint32_t)tp[j].ix) * (uint32_t)(CT * sizeof(T)) + kRB + kRB / 3 <= total;
+        }
+        // pixels in flight together: all four when a pixel's taps are runs (<= 8 registers), two otherwise (float images of 3 / 4
+        // channels: 12 / 16 registers per pixel)
+        constexpr int kGroup = PxRun<T, CT>::value ? 4 : 2;
+        const bool all_wide = __all(wide);
+        int lix[4], liy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lix[j] = act4[j] ? tp[j].ix : 0; liy[j] = act4[j] ? tp[j].iy : 0; }      // (a pixel off the frame reads the image's first taps)
+#pragma unroll
+        for (int j0 = 0; j0 < 4; j0 += kGroup) {
+            PxLoad<T, CT> L[kGroup];
+            if (all_wide) {                          // (the branch around the whole group, not inside it: each load phase is straight-line code)
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) px_load<T, CT, true>(src, smask, W, lix[j0 + j], liy[j0 + j], want_valid, L[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) px_load<T, CT, false>(src, smask, W, lix[j0 + j], liy[j0 + j], want_valid, L[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j)
+                if (act4[j0 + j]) px_blend<T, CT>(L[j], tp[j0 + j], wi[j0 + j], fixed_u8, quant == OFL_QUANT_OPENCV, arith, rule, want_valid, res[j0 + j], ok[j0 + j]);
+        }
+    } else if (all_inside) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (act4[j]) gather_px<T, CT, true>(src, smask, H, W, tp[j], wi[j], fixed_u8, quant == OFL_QUANT_OPENCV, arith, rule, want_valid, res[j], ok[j]);
@@ -1311,6 +1445,21 @@ void gather2_kernel(const T *__restrict__ src0, int H, int W,
     float fu[4], fv[4];
     bool  inf[4];
     uint32_t fmw[2] = { 0u, 0u };          // flow-mask bytes of the pixel pairs, fetched with the flow (not at the store)
+    // The common wave -- both pixel pairs of every lane inside the flow area, pairs 16-byte aligned -- asks for its two vector
+    // pairs and its two mask words in one go; the general form below predicates every load and waits for each (its loads sit in
+    // divergent branches: four dependent rounds of loads before the first tap is asked for).
+    const bool whole = aligned && act[0] && act[1] && row_in_flow && (unsigned)(xg[0] - pad_left) < (unsigned)fW && (unsigned)(xg[0] - pad_left + 1) < (unsigned)fW &&
+                       (unsigned)(xg[1] - pad_left) < (unsigned)fW && (unsigned)(xg[1] - pad_left + 1) < (unsigned)fW;
+    if (__all(whole)) {
+        const uint32_t o0 = __umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)(xg[0] - pad_left), o1 = __umul24((uint32_t)fy, (uint32_t)fW) + (uint32_t)(xg[1] - pad_left);
+        const float4 f0 = *reinterpret_cast<const float4 *>(flow + o0 * 2), f1 = *reinterpret_cast<const float4 *>(flow + o1 * 2);
+        if (fmask && valid) {
+            fmw[0] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(fmask + o0));
+            fmw[1] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(fmask + o1));
+        }
+        fu[0] = f0.x; fv[0] = f0.y; fu[1] = f0.z; fv[1] = f0.w; fu[2] = f1.x; fv[2] = f1.y; fu[3] = f1.z; fv[3] = f1.w;
+        inf[0] = inf[1] = inf[2] = inf[3] = true;
+    } else
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int fx = xg[g] - pad_left;

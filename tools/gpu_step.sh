@@ -29,6 +29,7 @@ for STEP in "$@"; do
     opspmc)    bash tools/prof_ops_pmc.sh $TAG || exit 1 ;;
     k1)        timeout -k 10 400 python tools/bench_k1.py > gpurun_out/${TAG}_k1.jsonl 2> gpurun_out/${TAG}_k1.err || { tail -5 gpurun_out/${TAG}_k1.err; exit 1; }; cut -c1-160 gpurun_out/${TAG}_k1.jsonl ;;
     walkab)    bash tools/walk_ab.sh $TAG || exit 1 ;;
+    k1pmc)     bash tools/prof_k1_pmc.sh ${TAG}_k1pmc || exit 1 ;;
     walk)      bash tools/prof_one.sh ${TAG}_walk --op invert --iters 10 > gpurun_out/${TAG}_walk.log 2>&1 || { tail -5 gpurun_out/${TAG}_walk.log; exit 1; }; grep walk gpurun_out/prof_${TAG}_walk/summary.txt | head -30 ;;
     parity)    timeout -k 10 600 python tools/scatter_parity_table.py > gpurun_out/${TAG}_parity.txt 2> gpurun_out/${TAG}_parity.err || { tail -5 gpurun_out/${TAG}_parity.err; exit 1; }; tail -30 gpurun_out/${TAG}_parity.txt ;;
     soak:*)  timeout -k 10 1100 bash tools/soak_all.sh "${STEP#soak:}" > gpurun_out/${TAG}_soak.log 2>&1; RC=$?; cat gpurun_out/${TAG}_soak.log; cat gpurun_out/soak/*.json > gpurun_out/${TAG}_soak.jsonl; [ $RC = 0 ] || exit 1 ;;

@@ -309,8 +309,17 @@ DL_HD int apply_range(PolyX &P, int p, const P2 &pp, unsigned lo, unsigned hi, c
     for (unsigned j0 = lo; j0 < hi; j0 += 4) {
         int c4[4];
         P2  q4[4];                                           // four candidates' indices, then their positions, in flight together
-        for (int k = 0; k < 4; ++k) c4[k] = j0 + k < hi ? (int)sorted[j0 + k] : -1;
-        for (int k = 0; k < 4; ++k) q4[k] = c4[k] >= 0 ? (sorted_xy ? sorted_xy[j0 + k] : pos(c4[k])) : pp;
+        for (int k = 0; k < 4; ++k) {
+            if (sorted_xy) {                                 // (as in apply_ring: unconditional loads at a clamped position)
+                const unsigned jj = j0 + k < hi ? j0 + k : hi - 1;
+                const int ck = (int)sorted[jj];
+                q4[k] = sorted_xy[jj];
+                c4[k] = j0 + k < hi ? ck : -1;
+            } else {
+                c4[k] = j0 + k < hi ? (int)sorted[j0 + k] : -1;
+                q4[k] = c4[k] >= 0 ? pos(c4[k]) : pp;
+            }
+        }
         for (int k = 0; k < 4; ++k) {
             const int c = c4[k];
             if (c < 0 || c == p) continue;
@@ -442,14 +451,34 @@ DL_HD int apply_ring(PolyX &P, int p, const P2 &pp, int bx, int by, int r, const
             // a few candidates at a time: their indices, then their positions, are in flight together
             int c[OFL_RING_W];
             P2  q[OFL_RING_W];
+            if (sorted_xy) {
+                // With the positions stored in list order both loads depend on the list position alone: asked for unconditionally, at a
+                // clamped position, ALL of them leave before the first is looked at.  (A load inside a branch is waited for where it
+                // stands, and left alone the compiler sinks each candidate's loads to its use behind the previous candidate's clip:
+                // a batch of four candidates was five round trips, not one.  The empty asm pins the raw values here.)
+                int ck[OFL_RING_W];
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-            for (int k = 0; k < OFL_RING_W; ++k) c[k] = j + k < hi ? (int)sorted[j + k] : -1;
+                for (int k = 0; k < OFL_RING_W; ++k) {
+                    const unsigned jj = j + k < hi ? j + k : hi - 1;
+                    ck[k] = (int)sorted[jj];
+                    q[k] = sorted_xy[jj];
+                }
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+                for (int k = 0; k < OFL_RING_W; ++k) asm volatile("" : "+v"(ck[k]), "+v"(q[k].x), "+v"(q[k].y));
+#endif
 #ifdef __HIPCC__
 #pragma unroll
 #endif
-            for (int k = 0; k < OFL_RING_W; ++k) q[k] = c[k] >= 0 ? (sorted_xy ? sorted_xy[j + k] : pos(c[k])) : pp;
+                for (int k = 0; k < OFL_RING_W; ++k) c[k] = j + k < hi ? ck[k] : -1;
+            } else {
+                for (int k = 0; k < OFL_RING_W; ++k) {
+                    c[k] = j + k < hi ? (int)sorted[j + k] : -1;
+                    q[k] = c[k] >= 0 ? pos(c[k]) : pp;
+                }
+            }
 #ifdef __HIPCC__
 #pragma unroll
 #endif
@@ -764,6 +793,7 @@ DL_HD int cell_verify(int ia, int W, const P2 &A, const P2 &B, const P2 &C, cons
         const unsigned lo = bstart[(size_t)row * g.gx + cb0], hi = bstart[(size_t)row * g.gx + cb1 + 1];
         if (hi - lo > 4 * kHeavy) return 0;                          // a dense cluster under the circles: left to the clip pass
         for (unsigned j = lo; j < hi; ++j) {
+            // (asking for a few candidates' positions together, as apply_ring does, changes nothing here: four cost a wave of occupancy, two +- 0)
             const P2 qa = sorted_xy ? sorted_xy[j] : pos((int)sorted[j]);
             const P2 Cq = { qa.x - O.x, qa.y - O.y };
             const float cxf = (float)Cq.x, cyf = (float)Cq.y, c2f = cxf * cxf + cyf * cyf;

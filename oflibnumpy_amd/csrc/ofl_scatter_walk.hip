@@ -24,6 +24,7 @@ namespace {
 constexpr double kEdgeTol   = 1e-12;   // relative in-circle excess that counts as "not locally Delaunay" (beyond rounding)
 constexpr double kBorderMax = 1e-4;    // px: largest deviation of a border point from its straight side for a certificate
 constexpr int    kWalkIters = 16;
+constexpr size_t kCertAffineAt = 192;  // byte offset of cert_affine_kernel's seven doubles in the certificate's 256-byte scratch
 
 struct CertDev {                       // device record written by the certify kernel (128 bytes)
     uint32_t folded, bad_edges, dropped, degenerate;
@@ -35,6 +36,10 @@ static_assert(sizeof(CertDev) == 16 + 64 + 64, "CertDev layout");
 struct WalkCert {
     D2 c[4]; double inv_len[4]; double delta; const uint32_t *diag; int diag_stride;     // inv_len[k]: 1 / |c[k + 1] - c[k]|
     float pa[4], pb[4], pc[4], lim32;      // side k's inward distance as a float32 plane pa x + pb y + pc, and the (conservative) limit for it
+    // the affine map through the warped corners, inverted: source index (ai[0] x + ai[1] y + ai[2], ai[3] x + ai[4] y + ai[5]) of a position,
+    // and the word the certificate leaves non-zero when some point of the field lies more than a quarter of a cell off that map
+    double ai[6];
+    const uint32_t *not_affine;
 };
 
 __device__ __forceinline__ unsigned long long okey(double d)
@@ -85,10 +90,37 @@ __device__ __forceinline__ int diag_if_convex(const D2 &a, const D2 &b, const D2
     return incircle_filtered(a, b, c, d) > 0 ? 1 : 0;
 }
 
+// The affine map x -> c0 + (c1 - c0) x / (W - 1) + (c3 - c0) y / (H - 1) through three warped corners, inverted (position -> source
+// index); false when it has no inverse.  Evaluated by the certificate (is every point of the field within a quarter of a cell of
+// it?) and by the walk's launcher (the first estimate of a node's source cell when it is) -- the same six numbers on both sides.
+__host__ __device__ inline bool corner_affine_inverse(const D2 &c0, const D2 &c1, const D2 &c3, int H, int W, double (&ai)[6])
+{
+    const double ax = (c1.x - c0.x) / (double)(W - 1), ay = (c1.y - c0.y) / (double)(W - 1);      // d position / d x
+    const double bx = (c3.x - c0.x) / (double)(H - 1), by = (c3.y - c0.y) / (double)(H - 1);      // d position / d y
+    const double det = ax * by - ay * bx;
+    if (!(fabs(det) > 1e-12) || !(fabs(det) < 1e12)) return false;
+    ai[0] = by / det;  ai[1] = -bx / det; ai[2] = -(ai[0] * c0.x + ai[1] * c0.y);
+    ai[3] = -ay / det; ai[4] = ax / det;  ai[5] = -(ai[3] * c0.x + ai[4] * c0.y);
+    return true;
+}
+
+// the inverse of the corners' affine map for the certificate pass: ai[0 .. 5], then 1.0 when the map has an inverse, else 0.0
+__global__ void cert_affine_kernel(const float *__restrict__ flow, int sign, int H, int W, double *__restrict__ affine, uint32_t *__restrict__ not_affine)
+{
+    if (not_affine) *not_affine = 0u;                   // (the certificate pass sets it)
+    double ai[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    bool ok = false;
+    if (H >= 2 && W >= 2)
+        ok = corner_affine_inverse(point_of(flow, sign, W, 0, 0), point_of(flow, sign, W, W - 1, 0), point_of(flow, sign, W, 0, H - 1), H, W, ai);
+    for (int k = 0; k < 6; ++k) affine[k] = ok ? ai[k] : 0.0;
+    affine[6] = ok ? 1.0 : 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------ certificate
 __global__ __launch_bounds__(256)
 void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint8_t *__restrict__ pmask, int H, int W,
                             CertDev *__restrict__ out, uint32_t *__restrict__ diag_bits, int diag_stride,
+                            const double *__restrict__ affine,      // cert_affine_kernel's seven numbers
                             int tile_row0, int tile_rows)      // this launch: tile rows [tile_row0, tile_row0 + gridDim.y) of tile_rows
 {
     // The pass runs as two launches: a first sixteenth of the rows, then the rest.  Where the first part has already counted tens of
@@ -142,7 +174,22 @@ void scatter_certify_kernel(const float *__restrict__ flow, int sign, const uint
     // determinant of the cell for every node that looks at it -- the same predicate on the same numbers, so the same bits out.
     if (diag_bits) {
         const unsigned long long m = __ballot(diag_bit != 0);
-        if ((threadIdx.x & 31) == 0 && y < H) diag_bits[(size_t)y * diag_stride + blockIdx.x] = (uint32_t)(m >> (threadIdx.x & 32));
+        // (row H - 1 holds no cell: its first word is the "not affine" flag below)
+        if ((threadIdx.x & 31) == 0 && y < H - 1) diag_bits[(size_t)y * diag_stride + blockIdx.x] = (uint32_t)(m >> (threadIdx.x & 32));
+        // Is the field the affine map through its corners, to a quarter of a cell?  Then the walk kernel starts every node from that
+        // map's inverse instead of a Newton step on the node's own flow -- one round of loads less per node.  An idempotent plain
+        // store by the workgroups that see a deviation: no atomics.
+        // (the inverse map comes from cert_affine_kernel: ten float64 divisions that one thread makes once, not every thread of the field)
+        int off = 0;
+        if (inpt) {
+            const double *ai = affine;                      // [6] and a validity word behind them
+            const D2 p = point_of(flow, sign, W, x, y);
+            // (float32 is plenty against a quarter of a cell at any practical size; where it is not -- a side of millions of nodes -- the field only loses the short cut)
+            const float px = (float)p.x, py = (float)p.y;
+            const float ex = fmaf((float)ai[0], px, fmaf((float)ai[1], py, (float)ai[2])) - (float)x, ey = fmaf((float)ai[3], px, fmaf((float)ai[4], py, (float)ai[5])) - (float)y;
+            off = !(fabsf(ex) <= 0.25f && fabsf(ey) <= 0.25f) || ai[6] == 0.0;
+        }
+        if (__syncthreads_or(off) && threadIdx.x == 0) diag_bits[(size_t)(H - 1) * diag_stride] = 1u;
     }
     // border: signed distance of every border point from the straight line between the two warped corners of its side
     const bool border_block = blockIdx.x == 0 || by == 0 || blockIdx.x == gridDim.x - 1 || by == tile_rows - 1;
@@ -288,6 +335,12 @@ template <int SP, bool BITS, bool NODE = false>      // the position (qx, qy) st
 __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int H, int W, int x, int y, double qx, double qy, Hit &h,
                                             const WalkCert &wc)
 {
+    double ex, ey;
+    if (NODE && wc.not_affine && *wc.not_affine == 0u) {
+        // (uniform) the field is the affine map through its corners to a quarter of a cell: that map's inverse is the estimate, and
+        // the node's own flow is not looked at -- one round of loads less
+        ex = fma(wc.ai[0], qx, fma(wc.ai[1], qy, wc.ai[2])); ey = fma(wc.ai[3], qx, fma(wc.ai[4], qy, wc.ai[5]));
+    } else {
     // first estimate of the source index: one Newton step from the node itself, i = q - J^-1 (P(q) - q), with the
     // Jacobian J = I + s * grad f from the differences to the node's right / lower neighbours (exact for affine fields;
     // float32 is plenty for an estimate that only selects the first cell)
@@ -301,11 +354,12 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
     // residual of the node: P(node) - q
     const float jdet = ja * jd - jb * jc;
     const float rx = NODE ? sg * f0.x : sg * f0.x + (float)((double)x - qx), ry = NODE ? sg * f0.y : sg * f0.y + (float)((double)y - qy);
-    double ex = (double)x - (double)rx, ey = (double)y - (double)ry;
+    ex = (double)x - (double)rx; ey = (double)y - (double)ry;
     if (fabsf(jdet) > 1e-3f) {
         const float ij = __builtin_amdgcn_rcpf(jdet);                  // (1 ulp: an estimate)
         ex = (double)x - (double)((jd * rx - jb * ry) * ij);
         ey = (double)y - (double)((ja * ry - jc * rx) * ij);
+    }
     }
     int pcx = -1, pcy = -1, ppcx = -2, ppcy = -2;
     for (int it = 0; it < kWalkIters; ++it) {
@@ -565,10 +619,14 @@ int certify_mesh(const float *flow, int sign_pp, const uint8_t *pmask, int H, in
     static_assert(sizeof(CertDev) <= kSlabStampAt, "the certificate record must end before the slab stamp");
     OFL_HIP(hipMemsetAsync((char *)scratch128 + kSlabStampAt, 0, 4, s));          // (callers give at least 256 bytes) a slab state in this workspace is void now
     const int tiles_x = (W + 31) / 32, tile_rows = (H + 7) / 8, first = tile_rows >= 32 ? tile_rows / 16 : tile_rows;
-    hipLaunchKernelGGL(scatter_certify_kernel, dim3(tiles_x, first), dim3(256), 0, s, flow, sign_pp, pmask, H, W, dev, diag_bits, tiles_x, 0, tile_rows);
+    double *affine = (double *)((char *)scratch128 + kCertAffineAt);              // (behind the record and the slab stamp, within the 256 bytes every caller gives)
+    static_assert(kCertAffineAt >= sizeof(CertDev) && kCertAffineAt >= kSlabStampAt + 4 && kCertAffineAt + 7 * sizeof(double) <= 256, "certificate scratch layout");
+    hipLaunchKernelGGL(cert_affine_kernel, dim3(1), dim3(1), 0, s, flow, sign_pp, H, W, affine,
+                       diag_bits ? diag_bits + (size_t)(H - 1) * ((W + 31) / 32) : (uint32_t *)nullptr);      // (the "not affine" word: row H - 1 of the plane)
+    hipLaunchKernelGGL(scatter_certify_kernel, dim3(tiles_x, first), dim3(256), 0, s, flow, sign_pp, pmask, H, W, dev, diag_bits, tiles_x, (const double *)affine, 0, tile_rows);
     if (first < tile_rows)
         hipLaunchKernelGGL(scatter_certify_kernel, dim3(tiles_x, tile_rows - first), dim3(256), 0, s, flow, sign_pp, pmask, H, W, dev, diag_bits, tiles_x,
-                           first, tile_rows);
+                           (const double *)affine, first, tile_rows);
     cert->diag_bits = diag_bits;
     OFL_HIP(hipGetLastError());
     CertDev r_stack;
@@ -608,6 +666,9 @@ int walk_launch(const float *flow, int sign_pp, const VT *vals, int C, const uin
     }
     wc.diag = cert->diag_bits; wc.diag_stride = (W + 31) / 32;
     set_planes(wc, H, W);
+    wc.not_affine = nullptr;
+    for (int k = 0; k < 6; ++k) wc.ai[k] = 0.0;
+    if (wc.diag && H >= 2 && W >= 2 && corner_affine_inverse(wc.c[0], wc.c[1], wc.c[3], H, W, wc.ai)) wc.not_affine = wc.diag + (size_t)(H - 1) * wc.diag_stride;
     const int tiling = OFL_KNOB_INT("OFL_WALK_TILING", 0);
     const int tws = (tiling & 2) ? 6 : 5, gx = (W + (1 << tws) - 1) >> tws, gy = (rows + (256 >> tws) - 1) / (256 >> tws);
     const int rs = (tiling >> 2) & 3, bands = ((gy + (1 << rs) - 1) >> rs), rounds = (bands + 7) / 8;
@@ -639,7 +700,8 @@ int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, 
         const double dx = wc.c[(k + 1) & 3].x - wc.c[k].x, dy = wc.c[(k + 1) & 3].y - wc.c[k].y;
         wc.inv_len[k] = 1.0 / sqrt(dx * dx + dy * dy);
     }
-    wc.diag = nullptr; wc.diag_stride = 0;
+    wc.diag = nullptr; wc.diag_stride = 0; wc.not_affine = nullptr;
+    for (int k = 0; k < 6; ++k) wc.ai[k] = 0.0;
     set_planes(wc, H, W);
     if (n == 0) return OFL_OK;
     const size_t nb = (n + 255) / 256;

@@ -216,6 +216,40 @@ def test_nodes_in_the_noise_band_of_the_border(gpu, oracle):
         np.testing.assert_allclose(gi.vecs[gi.mask], oi.vecs[oi.mask], rtol=RTOL, atol=ATOL)
 
 
+def test_certified_walk_first_estimate_affine_and_not(gpu, oracle):
+    """The walk's first estimate of a node's source cell: the inverse of the affine map through the warped corners when the
+    certificate finds every point of the field within a quarter of a cell of that map (its "not affine" word stays 0), the
+    Newton step on the node's own flow otherwise.  Both against SciPy through the oracle: a similarity transform (the short
+    cut), the same field with a smooth interior bulge of 0.4 .. 3 cells that keeps the corners and the certificate (the
+    fall-back -- with the short cut's estimate such nodes would start cells away), and a bulge of 0.1 cells (the short cut
+    with estimates that are off by a fraction of a cell: the walk's own steps make up for it)."""
+    of, O = gpu, oracle
+    from oflibnumpy_amd import device as dev
+    h, w = 150, 210
+    yy, xx = np.mgrid[:h, :w].astype(np.float64)
+    base = of.Flow.from_transforms([['rotation', 90, 70, 11], ['scaling', 100, 60, 0.93]], [h, w], 's').vecs.astype(np.float64)
+    bump = np.sin(np.pi * xx / (w - 1)) ** 2 * np.sin(np.pi * yy / (h - 1)) ** 2          # 0 on the border (and flat there), 1 in the middle
+    for amp, want_word in ((0.0, 0), (0.1, 0), (0.4, 1), (3.0, 1)):
+        v = base.copy()
+        v[..., 0] += amp * bump
+        v[..., 1] -= 0.7 * amp * bump
+        v = v.astype(np.float32)
+        c = certify(of, v)
+        assert c.certified == 1, (amp, c.folded_cells, c.bad_edges, c.border_dev)
+        d = dev.DeviceFlow.from_host(v, 's')
+        cert = d.mesh_cert(+1)
+        assert cert.certified
+        word = cert._diag_buf.to_host((h * ((w + 31) // 32),), np.uint32)[(h - 1) * ((w + 31) // 32)]
+        assert int(word != 0) == want_word, (amp, word)
+        f, o = of.Flow(v, 's'), O.OFlow(v, 's')
+        gi, oi = f.invert(), o.invert()
+        np.testing.assert_array_equal(gi.mask, oi.mask, err_msg=str(amp))
+        np.testing.assert_allclose(gi.vecs[gi.mask], oi.vecs[oi.mask], rtol=RTOL, atol=ATOL, err_msg=str(amp))
+        gs, os_ = f.switch_ref(), o.switch_ref()
+        np.testing.assert_array_equal(gs.mask, os_.mask, err_msg=str(amp))
+        np.testing.assert_allclose(gs.vecs[gs.mask], os_.vecs[os_.mask], rtol=RTOL, atol=ATOL, err_msg=str(amp))
+
+
 # ---------------------------------------------------------------------------------------------- exact path
 from scatter_util import nonunique_nodes, warped_points      # noqa: E402
 

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$ROOT/tools
 for LIB in libofl_hip_exp.so libofl_hip_w8.so; do
   [ -f $ROOT/oflibnumpy_amd/$LIB ] || continue
-  for T in ${WALK_TILINGS:-0 5 9 13}; do
+  for T in ${WALK_TILINGS:-0 5 9}; do
     export OFL_LIB=$ROOT/oflibnumpy_amd/$LIB OFL_WALK_TILING=$T
     for OP in invert invert_rot; do
       MS=$(python3 $ROOT/tools/bench_invert.py --op $OP --iters 30 2>/dev/null | grep -o '"device_ms": [0-9.]*' | head -1)

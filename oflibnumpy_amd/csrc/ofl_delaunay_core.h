@@ -606,6 +606,17 @@ DL_HD int star_fan(int p, int W, const P2 &pp, unsigned kept8, PosFn pos, SlotPo
 #pragma unroll
 #endif
     for (int c = 0; c < 4; ++c) whole[c] = ((kept8 >> (2 * c)) & (kept8 >> (2 * c + 1)) & (kept8 >> ((2 * c + 2) & 7)) & 1u) != 0;
+    // A whole cell must be convex and positively oriented for what follows: its diagonal is chosen by ONE in-circle sign, and the
+    // corner that diagonal does not lead to is taken on trust (`adj` below) -- in a cell with a reflex corner that corner can lie
+    // INSIDE the triangle of the other three (an outlier vector next to a motion boundary: the soak of the composed paths found
+    // one such node in 3.6 M), and the fan would be a triangle with a site in it.  Such a site is left to the clip pass, as
+    // cell_verify leaves the cell.
+    auto convex = [](const P2 &A, const P2 &B, const P2 &C, const P2 &D) {
+        auto cr = [](const P2 &o, const P2 &u, const P2 &v) { return (u.x - o.x) * (v.y - o.y) - (u.y - o.y) * (v.x - o.x); };
+        return cr(A, B, C) > 0.0 && cr(A, C, D) > 0.0 && cr(B, C, D) > 0.0 && cr(B, D, A) > 0.0;
+    };
+    if ((whole[0] && !convex(pp, Q[0], Q[1], Q[2])) || (whole[1] && !convex(Q[4], pp, Q[2], Q[3])) ||
+        (whole[2] && !convex(Q[5], Q[6], pp, Q[4])) || (whole[3] && !convex(Q[6], Q[7], Q[0], pp))) return 0;
     unsigned pmask8 = kept8 & 0x55u;                             // present slots: the kept axis neighbours ...
     if (((kept8 >> 1) & 1u) && (!whole[0] || ac(pp, Q[0], Q[1], Q[2]))) pmask8 |= 2u;         // ... and the diagonal ones a whole
     if (((kept8 >> 3) & 1u) && (!whole[1] || !ac(Q[4], pp, Q[2], Q[3]))) pmask8 |= 8u;        //     cell's diagonal leads to

@@ -336,7 +336,7 @@ __device__ __forceinline__ bool walk_locate(const float *__restrict__ flow, int 
                                             const WalkCert &wc)
 {
     double ex, ey;
-    if (NODE && wc.not_affine && *wc.not_affine == 0u) {
+    if (wc.not_affine && *wc.not_affine == 0u) {
         // (uniform) the field is the affine map through its corners to a quarter of a cell: that map's inverse is the estimate, and
         // the node's own flow is not looked at -- one round of loads less
         ex = fma(wc.ai[0], qx, fma(wc.ai[1], qy, wc.ai[2])); ey = fma(wc.ai[3], qx, fma(wc.ai[4], qy, wc.ai[5]));
@@ -702,6 +702,8 @@ int walk_query_launch(const float *flow, int sign_pp, const float *vals, int C, 
     }
     wc.diag = nullptr; wc.diag_stride = 0; wc.not_affine = nullptr;
     for (int k = 0; k < 6; ++k) wc.ai[k] = 0.0;
+    // (the query kernel decides diagonals itself, but the certificate's "not affine" word -- in the last row of its plane -- serves it too)
+    if (cert->diag_bits && H >= 2 && W >= 2 && corner_affine_inverse(wc.c[0], wc.c[1], wc.c[3], H, W, wc.ai)) wc.not_affine = cert->diag_bits + (size_t)(H - 1) * ((W + 31) / 32);
     set_planes(wc, H, W);
     if (n == 0) return OFL_OK;
     const size_t nb = (n + 255) / 256;

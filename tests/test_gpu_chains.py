@@ -286,3 +286,19 @@ def test_invert_and_switch_ref_vs_oracle_512(gpu, oracle, ref):
         np.testing.assert_array_equal(got.mask, want.mask)
         assert got.mask.sum() > 100000
         np.testing.assert_allclose(got.vecs, want.vecs, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.gpu
+def test_soak_seed_mesh_fan_with_a_site_inside(gpu, oracle):
+    """tools/soak_chains.py, seed 78000073 (mode 1 't', 90 x 136, rippled fields, a fifth of the points masked out): the last
+    stage -- res.switch_ref(), a scatter on the Delaunay path -- holds a grid cell whose corner a lies INSIDE the triangle of
+    its other three corners (an outlier vector next to a masked region).  The mesh-fan pass chose that cell's diagonal by the
+    in-circle sign of a convex cell and took corner a on trust: its sites' stars held the triangle (b, c, d) with site a in it,
+    and one node came out 0.6 px off SciPy (all paths alike: grid, query positions, bands).  star_fan now refuses a whole cell
+    that is not convex, as cell_verify does."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak_chains
+    n, bad, msgs = soak_chains.one_case(gpu, oracle, sys.modules[__name__], 78000073, 120, 160)
+    assert n > 100000 and bad == 0, msgs
